@@ -1,0 +1,537 @@
+"""
+CPU oracle for the GS / WGS hologram optimisation hot path.
+
+**This file is TEST INFRASTRUCTURE, not product code.**  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it; nothing under ``slmsuite_amd/`` does (the product path fails loudly when
+the HIP library is missing, it never falls back to this file).
+
+It is an independent NumPy restatement of the reference algorithm in
+``slmsuite/holography/algorithms`` (paths relative to the reference checkout);
+every function cites the reference lines it follows.  It deliberately issues
+the same *unfused* NumPy operation sequence as the reference (separate ufunc
+passes, ``np.fft.fft2`` + ``fftshift``), so that (i) its floating-point results
+track the reference to rounding and (ii) its wall-clock is a fair stand-in for
+the reference NumPy path when timed as ``cpu_baseline`` (kind = "port").
+
+Pinning: ``tests/test_oracle_golden.py`` checks this oracle against the golden
+vectors in ``tests/golden/*.npz``, which were produced by importing the real
+reference (``tools/make_golden.py``; the reference cannot travel to the GPU
+box, the fixtures do).
+"""
+import numpy as np
+
+# Method tables -- _header.py:53-81 (order defines ALGORITHM_INDEX).
+ALGORITHM_DEFAULTS = {
+    "GS": {"feedback": "computational"},
+    "WGS-Leonardo": {"feedback": "computational", "feedback_exponent": 0.8},
+    "WGS-Kim": {
+        "feedback": "computational",
+        "fix_phase_efficiency": None,
+        "fix_phase_iteration": 10,
+        "feedback_exponent": 0.8,
+    },
+    "WGS-Nogrette": {"feedback": "computational", "feedback_factor": 0.1},
+    "WGS-Wu": {"feedback": "computational", "feedback_exponent": 0.5},
+    "WGS-tanh": {"feedback": "computational", "feedback_factor": 0.2, "feedback_exponent": 0.5},
+}
+FEEDBACK_OPTIONS = (
+    "computational", "computational_spot", "experimental", "experimental_spot", "external_spot",
+)
+
+
+# --------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------
+def unpad_slices(shape, slm_shape):
+    """Centred crop indices (r0, r1, c0, c1).  toolbox/__init__.py:1699-1712."""
+    dh = (shape[0] - slm_shape[0]) / 2.0
+    dw = (shape[1] - slm_shape[1]) / 2.0
+    if dh < 0 or dw < 0:
+        raise ValueError("slm_shape larger than shape")
+    return (
+        int(np.floor(dh)), int(shape[0] - np.ceil(dh)),
+        int(np.floor(dw)), int(shape[1] - np.ceil(dw)),
+    )
+
+
+def padded_shape(slm_shape, padding_order=1, square_padding=True):
+    """Power-of-two padding rule.  _hologram.py:712-725 (precision=inf branch)."""
+    if padding_order > 0:
+        shp = np.power(2, np.ceil(np.log2(slm_shape)) + padding_order - 1).astype(int)
+    else:
+        shp = np.asarray(slm_shape)
+    shp = tuple(int(s) for s in shp)
+    if square_padding:
+        shp = (max(shp), max(shp))
+    return shp
+
+
+def l2norm(x):
+    """sqrt(nansum(|x|^2)).  _hologram.py:1979-2011."""
+    if np.iscomplexobj(x):
+        return np.sqrt(np.nansum(np.square(np.abs(x))))
+    return np.sqrt(np.nansum(np.square(x)))
+
+
+def take_sum(image, vectors, width):
+    """
+    Sum of ``width x width`` windows centred on floor(vectors) (float64 accumulation).
+    analysis/__init__.py:61-204 with centered=True, integrate=True, clip=False;
+    window offsets are floor(arange(w) - (w-1)/2)  (analysis._coordinates).
+    """
+    v = np.floor(np.asarray(vectors, dtype=float).reshape(2, -1)).astype(int)
+    off = np.floor(np.arange(width) - (width - 1) / 2.0).astype(int)
+    ox, oy = np.meshgrid(off, off)
+    ix = ox.ravel()[None, :] + v[0][:, None]
+    iy = oy.ravel()[None, :] + v[1][:, None]
+    return np.sum(image[iy, ix].astype(float), axis=-1)
+
+
+def calculate_stats(feedback_amp, target_amp, total=None, alias=True):
+    """
+    efficiency / uniformity / pkpk_err / std_err.  _stats.py:7-116 with
+    efficiency_compensation=False (the only value the computational groups use,
+    _stats.py:123-128, _spots.py:1634-1679).
+
+    ``alias=True`` reproduces quirk A23: the reference wraps its inputs with ``copy=None``
+    (_stats.py:51-52) and then rescales them IN PLACE (:65, :69), so requesting the
+    "computational" group nudges ``amp_ff`` and ``target`` by a factor within 1 ulp of 1
+    every iteration.  The golden fixtures were recorded with stats on, so the oracle keeps the
+    aliasing to stay bit-faithful; ``alias=False`` computes on copies (what the HIP engine does).
+    """
+    f_amp = np.array(feedback_amp, copy=None if alias else True)
+    t_amp = np.array(target_amp, copy=None if alias else True)
+    f_pwr = np.square(f_amp)
+    t_pwr = np.square(t_amp)
+    if total is not None:
+        efficiency = np.nansum(f_pwr) / total
+    s = np.sum(f_pwr)
+    f_pwr *= 1 / s
+    f_amp *= 1 / np.sqrt(s)
+    ts = np.nansum(t_pwr)
+    t_pwr *= 1 / ts
+    t_amp *= 1 / np.sqrt(ts)
+    if total is None:
+        efficiency = np.square(float(np.nansum(np.multiply(t_amp, f_amp))))
+    mask = np.logical_and(t_pwr != 0, np.logical_not(np.isnan(t_pwr)))
+    fm = f_pwr[mask]
+    tm = t_pwr[mask]
+    ratio = fm / tm
+    err = tm - fm
+    rmin, rmax = float(np.amin(ratio)), float(np.amax(ratio))
+    return {
+        "efficiency": float(efficiency),
+        "uniformity": float(1 - (rmax - rmin) / (rmax + rmin)),
+        "pkpk_err": float(err.size * float(np.amax(err) - np.amin(err))),
+        "std_err": float(err.size * float(np.std(err))),
+    }
+
+
+# --------------------------------------------------------------------------------------
+# the weight update (rows 9-10 of SURVEY 8a)
+# --------------------------------------------------------------------------------------
+def update_weights_generic(weight_amp, feedback_amp, target_amp, method, flags, dtype):
+    """
+    In-place WGS weight update.  _hologram.py:1822-1879 (nan_checks=True).
+    ``method`` is the full name ("WGS-Leonardo", ...).
+    """
+    m = method.lower()
+    if m[:4] != "wgs-":
+        raise ValueError("Weighting is only for WGS.")
+    m = m[4:]
+
+    fc = np.array(feedback_amp, copy=True, dtype=dtype)
+    fc *= 1 / l2norm(fc)
+    tgt = np.asarray(target_amp)
+
+    if "wu" in m or "tanh" in m:            # additive rules: target - p*feedback  (:1833-1835)
+        fc *= -flags["feedback_exponent"]
+        fc += tgt
+    else:                                   # multiplicative rules (:1837-1843)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            np.divide(fc, tgt, out=fc)
+        fc[fc == np.inf] = 1
+        fc[tgt == 0] = 1
+        np.nan_to_num(fc, copy=False, nan=1)
+
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if "leonardo" in m or "kim" in m:   # (:1846-1848)
+            np.power(fc, -flags["feedback_exponent"], out=fc)
+        elif "nogrette" in m:               # (:1849-1855)
+            fc *= -(1 / np.nanmean(fc))
+            fc += 1
+            fc *= -flags["feedback_factor"]
+            fc += 1
+            np.reciprocal(fc, out=fc)
+        elif "wu" in m:                     # (:1856-1857)  exponent applied a second time
+            fc = np.exp(flags["feedback_exponent"] * fc)
+        elif "tanh" in m:                   # (:1858-1860)
+            fc = flags["feedback_factor"] * np.tanh(flags["feedback_exponent"] * fc)
+            fc += 1
+        else:
+            raise ValueError(f"Method '{method}' not recognized")
+
+        fc[fc == np.inf] = 1
+        weight_amp *= fc
+    np.nan_to_num(weight_amp, copy=False, nan=0.0001)
+    weight_amp *= 1 / l2norm(weight_amp)
+    return weight_amp
+
+
+# --------------------------------------------------------------------------------------
+# hologram state + loop
+# --------------------------------------------------------------------------------------
+class OracleHologram:
+    """
+    State of one DFT-grid hologram and the GS/WGS loop.
+
+    Constructor conventions follow Hologram.__init__ (_hologram.py:196-439):
+    ``target`` is an array of the padded shape or an ``(h, w)`` tuple; ``amp=None`` means the
+    *scalar* 1/sqrt(S) (float64, :401-402); an array amp is L2-normalised; ``phase`` must be
+    given (the reference default is an unseeded RNG, quirk A14).
+    """
+
+    def __init__(self, target, amp=None, phase=None, slm_shape=None, dtype=np.float32,
+                 propagation_kernel=None, **flags):
+        self.dtype = np.float32 if np.dtype(dtype).itemsize == 4 else np.float64
+        self.ctype = np.complex64 if self.dtype is np.float32 else np.complex128
+        if isinstance(target, tuple) or (np.ndim(target) == 1 and len(target) == 2):
+            self.shape = (int(target[0]), int(target[1]))
+            target = None
+        else:
+            self.shape = tuple(np.shape(target))
+        if slm_shape is None:
+            if amp is not None:
+                slm_shape = np.shape(amp)
+            elif phase is not None:
+                slm_shape = np.shape(phase)
+            else:
+                slm_shape = self.shape
+        self.slm_shape = (int(slm_shape[0]), int(slm_shape[1]))
+
+        if amp is None:
+            self.amp = 1 / np.sqrt(np.prod(self.slm_shape))           # np.float64 scalar
+        else:
+            self.amp = np.array(amp, dtype=self.dtype)
+            self.amp *= 1 / l2norm(self.amp)
+        self.propagation_kernel = (
+            None if propagation_kernel is None else np.array(propagation_kernel, dtype=self.dtype)
+        )
+        self.flags = dict(flags)
+        self.set_target(target)
+        if phase is None:
+            raise ValueError("oracle runs need an explicit seed phase")
+        self.phase = np.array(phase, dtype=self.dtype)
+        self.reset()
+
+    # -- _set_target :741-769, reset_weights :603-614, reset :442-478 ----------------------
+    def set_target(self, target, reset_weights=False):
+        if target is None:
+            self.target = np.zeros(self.shape, dtype=self.dtype)
+        else:
+            self.target = np.array(target, dtype=self.dtype)
+            np.abs(self.target, out=self.target)
+            self.target *= 1 / l2norm(self.target)
+        if reset_weights:
+            self.reset_weights()
+
+    def reset_weights(self):
+        self.weights = self.target.copy()
+        if hasattr(self, "zero_weights"):
+            self.zero_weights *= 0
+        np.nan_to_num(self.weights, copy=False, nan=0)
+
+    def reset(self):
+        self.reset_weights()
+        self.iter = 0
+        self.stats = {"method": [], "flags": {}, "stats": {}}
+        self.amp_ff = None
+        self.phase_ff = None
+        self.nearfield = np.zeros(self.shape, dtype=self.ctype)
+        self.farfield = np.zeros(self.shape, dtype=self.ctype)
+
+    # -- operators ------------------------------------------------------------------------
+    def build_nearfield(self):
+        """_hologram.py:1000-1011."""
+        r0, r1, c0, c1 = unpad_slices(self.shape, self.slm_shape)
+        self.nearfield.fill(0)
+        if self.propagation_kernel is None:
+            self.nearfield[r0:r1, c0:c1] = self.amp * np.exp(1j * self.phase)
+        else:
+            self.nearfield[r0:r1, c0:c1] = self.amp * np.exp(1j * (self.phase + self.propagation_kernel))
+        return self.nearfield
+
+    def nearfield2farfield(self):
+        """_hologram.py:1038-1056 + _midloop_cleaning :951-953."""
+        nf = self.build_nearfield()
+        self.farfield = np.fft.fftshift(np.fft.fft2(np.fft.fftshift(nf), norm="ortho"))
+        self.amp_ff = np.abs(self.farfield, out=self.amp_ff)
+
+    def farfield2nearfield(self):
+        """_hologram.py:1058-1073 + _nearfield_extract :1026-1036."""
+        self.nearfield = np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(self.farfield), norm="ortho"))
+        r0, r1, c0, c1 = unpad_slices(self.shape, self.slm_shape)
+        self.phase = np.arctan2(
+            self.nearfield.imag[r0:r1, c0:c1], self.nearfield.real[r0:r1, c0:c1], out=self.phase
+        )
+        if self.propagation_kernel is not None:
+            self.phase -= self.propagation_kernel
+
+    def populate_results(self):
+        """_hologram.py:934-949."""
+        self.nearfield2farfield()
+        self.phase_ff = np.arctan2(self.farfield.imag, self.farfield.real, out=self.phase_ff)
+
+    def update_weights(self):
+        """Hologram._update_weights, _hologram.py:1914-1922."""
+        if self.flags["feedback"] == "computational":
+            update_weights_generic(self.weights, self.amp_ff, self.target,
+                                   self.flags["method"], self.flags, self.dtype)
+
+    # -- stats dictionary bookkeeping (drives WGS-Kim) ---------------------------------------
+    def compute_stats(self, stat_groups):
+        stats = {}
+        if "computational" in stat_groups:          # _stats.py:118-128
+            stats["computational"] = calculate_stats(self.amp_ff, self.target)
+        return stats
+
+    def update_stats(self, stat_groups):
+        """_stats.py:130-190 (raw_stats omitted)."""
+        stats = self.compute_stats(stat_groups)
+        it = self.iter
+        M = len(self.stats["method"])
+        if it + 1 > M:
+            self.stats["method"].extend([""] * (it + 1 - M))
+            M = it + 1
+        self.stats["method"][it] = self.flags["method"]
+        for flag in set(self.flags) | set(self.stats["flags"]):
+            lst = self.stats["flags"].setdefault(flag, [np.nan] * M)
+            if it + 1 > len(lst):
+                lst.extend([np.nan] * (it + 1 - len(lst)))
+            if flag in self.flags:
+                lst[it] = self.flags[flag]
+        groups = set(stats) | set(self.stats["stats"])
+        if groups:
+            names = set()
+            for g in stats:
+                names |= set(stats[g])
+            if self.stats["stats"]:
+                names |= set(self.stats["stats"][next(iter(self.stats["stats"]))])
+            for g in groups:
+                d = self.stats["stats"].setdefault(g, {})
+                for n in names:
+                    lst = d.setdefault(n, [np.nan] * M)
+                    if it + 1 > len(lst):
+                        lst.extend([np.nan] * (it + 1 - len(lst)))
+                    if g in stats and n in stats[g]:
+                        lst[it] = stats[g][n]
+
+    # -- the farfield routines (row 8) ---------------------------------------------------------
+    def mraf_masks(self):
+        """_hologram.py:1495-1548."""
+        if not np.isnan(np.sum(self.target)):
+            return None
+        noise = np.isnan(self.target)
+        zero = np.abs(self.target) == 0
+        if self.flags.get("zero_factor", 0) != 0:
+            Z = int(np.sum(zero))
+            if Z > 0 and not hasattr(self, "zero_weights"):
+                self.zero_weights = np.zeros((Z,), dtype=self.ctype)
+        signal = np.logical_not(np.logical_or(noise, zero))
+        return {"noise": noise, "zero": zero, "signal": signal}
+
+    def gs_farfield_routines(self, masks):
+        """_hologram.py:1550-1653."""
+        fl = self.flags
+        if "WGS" in fl["method"] and self.iter > 0:
+            self.update_weights()
+            if "Kim" in fl["method"]:
+                was_not_fixed = not fl["fixed_phase"]
+                if fl["fix_phase_efficiency"] is not None:
+                    st = self.stats["stats"]
+                    if len(st) == 0:
+                        raise ValueError("Must track statistics to fix phase based on efficiency!")
+                    eff = st[tuple(st.keys())[-1]]["efficiency"][self.iter]
+                    if eff > fl["fix_phase_efficiency"]:
+                        fl["fixed_phase"] = True
+                if was_not_fixed and self.iter >= fl["fix_phase_iteration"] - 1:
+                    prev = self.stats["flags"]["fixed_phase"]
+                    if all(not prev[-1 - i] for i in range(fl["fix_phase_iteration"])):
+                        fl["fixed_phase"] = True
+                if (fl["fixed_phase"] and self.phase_ff is None) or was_not_fixed:
+                    self.phase_ff = np.arctan2(self.farfield.imag, self.farfield.real, out=self.phase_ff)
+            else:
+                fl["fixed_phase"] = False
+
+        fixed = bool(fl.get("fixed_phase", False))
+        if masks is None:                           # :1590-1605
+            if (not fixed) or self.phase_ff is None:
+                self.phase_ff = np.arctan2(self.farfield.imag, self.farfield.real, out=self.phase_ff)
+            np.exp(1j * self.phase_ff, out=self.farfield)
+            np.multiply(self.farfield, self.weights, out=self.farfield)
+        else:                                       # MRAF :1606-1653
+            zero, noise, signal = masks["zero"], masks["noise"], masks["signal"]
+            mraf_factor = fl.get("mraf_factor", None)
+            if hasattr(self, "zero_weights"):
+                fz = self.farfield[zero]
+                self.zero_weights -= fl.get("zero_factor", 1) * np.abs(fz) * fz
+                self.farfield[zero] = self.zero_weights
+            else:
+                self.farfield[zero] = 0
+            if not fixed:
+                self.phase_ff = np.arctan2(self.farfield.imag, self.farfield.real, out=self.phase_ff)
+            np.exp(1j * self.phase_ff, where=signal, out=self.farfield)
+            np.multiply(self.farfield, self.weights, where=signal, out=self.farfield)
+            if mraf_factor is not None:
+                np.multiply(self.farfield, mraf_factor, where=noise, out=self.farfield)
+
+    # -- optimize (rows 2-3) ---------------------------------------------------------------------
+    def update_flags(self, method, feedback, stat_groups, **kwargs):
+        """_hologram.py:1370-1410."""
+        if method not in ALGORITHM_DEFAULTS:
+            raise ValueError(f"Unrecognized method '{method}'")
+        self.flags["method"] = method
+        for k, v in ALGORITHM_DEFAULTS[method].items():
+            if k not in self.flags:
+                self.flags[k] = v
+        if "fixed_phase" not in self.flags:
+            self.flags["fixed_phase"] = False
+        for k in kwargs:
+            self.flags[k] = kwargs[k]
+        for g in stat_groups:
+            if g not in FEEDBACK_OPTIONS:
+                raise ValueError(f"Statistics group '{g}' not recognized")
+        self.flags["stat_groups"] = stat_groups
+        if feedback is not None:
+            if feedback not in FEEDBACK_OPTIONS:
+                raise ValueError(f"Feedback '{feedback}' not recognized")
+            self.flags["feedback"] = feedback
+
+    def optimize(self, method="GS", maxiter=20, callback=None, feedback=None, stat_groups=(),
+                 populate=True, trace=None, **kwargs):
+        """
+        _hologram.py:1076-1368 + optimize_gs :1427-1493.  ``trace`` (optional callable) is
+        invoked as trace(self, stage) after each operator for step-level fixtures.
+        """
+        kwargs.pop("name", None)
+        self.update_flags(method, feedback, list(stat_groups), **kwargs)
+        masks = self.mraf_masks()
+        for _ in range(maxiter):
+            self.nearfield2farfield()
+            if trace is not None:
+                trace(self, "forward")
+            if callback is not None and callback(self):
+                break
+            self.update_stats(self.flags["stat_groups"])
+            self.gs_farfield_routines(masks)
+            if trace is not None:
+                trace(self, "constraint")
+            self.farfield2nearfield()
+            if trace is not None:
+                trace(self, "inverse")
+            self.iter += 1
+        if populate:
+            self.populate_results()
+
+
+class OracleSpotHologram(OracleHologram):
+    """
+    DFT-grid spot array with one pixel per spot (basis "knm", no camera).
+    SpotHologram.__init__ _spots.py:1090-1373; _set_target_spots :1490-1546;
+    _update_weights :1573-1624; _calculate_stats_computational_spot :1626-1679.
+    """
+
+    def __init__(self, shape, spot_vectors, spot_amp=None, slm_shape=None, phase=None,
+                 amp=None, dtype=np.float32, null_region=None, **flags):
+        v = np.asarray(spot_vectors, dtype=float).reshape(2, -1)
+        N = v.shape[1]
+        self.spot_knm = v
+        self.spot_amp = np.full(N, 1.0 / np.sqrt(N)) if spot_amp is None else np.ravel(spot_amp)
+        self.external_spot_amp = np.copy(self.spot_amp)
+        self.null_region_knm = null_region
+        self.spot_integration_width_knm = spot_integration_width(v)
+        if np.any(v[0] < 0) or np.any(v[1] < 0) or np.any(v[0] >= shape[1]) or np.any(v[1] >= shape[0]):
+            raise ValueError("Spots outside SLM computational space bounds!")
+        super().__init__((int(shape[0]), int(shape[1])), amp=amp, phase=phase,
+                         slm_shape=slm_shape, dtype=dtype, **flags)
+        self.set_target_spots(reset_weights=True)
+
+    def set_target_spots(self, reset_weights=False):
+        self.spot_knm_rounded = np.rint(self.spot_knm).astype(int)
+        if self.null_region_knm is None:
+            self.target.fill(0)
+        else:   # MRAF background: NaN = free, null_region = forced zero  (:1516-1524)
+            self.target.fill(np.nan)
+            self.target[self.null_region_knm] = 0
+        self.target[self.spot_knm_rounded[1], self.spot_knm_rounded[0]] = self.spot_amp
+        self.target /= l2norm(self.target)
+        if reset_weights:
+            self.reset_weights()
+
+    def update_weights(self):
+        fb = self.flags["feedback"]
+        if fb == "computational":
+            update_weights_generic(self.weights, self.amp_ff, self.target,
+                                   self.flags["method"], self.flags, self.dtype)
+            return
+        if fb == "computational_spot":
+            amp_fb = np.sqrt(take_sum(np.square(self.amp_ff), self.spot_knm_rounded,
+                                      self.spot_integration_width_knm))
+        elif fb == "external_spot":
+            amp_fb = self.external_spot_amp
+        else:
+            raise ValueError(f"Feedback '{fb}' not recognized.")
+        ky, kx = self.spot_knm_rounded[1], self.spot_knm_rounded[0]
+        self.weights[ky, kx] = update_weights_generic(
+            self.weights[ky, kx], np.array(amp_fb, dtype=self.dtype), self.spot_amp,
+            self.flags["method"], self.flags, self.dtype)
+
+    def compute_stats(self, stat_groups):
+        stats = super().compute_stats(stat_groups)
+        if "computational_spot" in stat_groups:
+            if self.shape == self.slm_shape:
+                ky, kx = self.spot_knm_rounded[1], self.spot_knm_rounded[0]
+                stats["computational_spot"] = calculate_stats(
+                    self.amp_ff[ky, kx], self.spot_amp, total=np.sum(np.square(self.amp_ff)))
+            else:
+                pwr = np.square(self.amp_ff)
+                fb = take_sum(pwr, self.spot_knm, self.spot_integration_width_knm)
+                stats["computational_spot"] = calculate_stats(
+                    np.sqrt(fb), self.spot_amp, total=np.sum(pwr))
+        return stats
+
+
+def smallest_distance_chebyshev(vectors):
+    """Brute-force restatement of toolbox.smallest_distance (toolbox/__init__.py:1127-1250)."""
+    v = np.asarray(vectors, dtype=float).reshape(2, -1)
+    n = v.shape[1]
+    if n < 2:
+        return np.inf
+    best = np.inf
+    for i in range(n - 1):
+        d = np.max(np.abs(v[:, i + 1:] - v[:, i:i + 1]), axis=0)
+        best = min(best, float(np.min(d)))
+    return best
+
+
+def spot_integration_width(spot_knm, psf_knm=0.0):
+    """Default integration width without hardware.  _spots.py:1284-1297 (quirk A19)."""
+    min_psf = 3
+    dist = np.max([smallest_distance_chebyshev(spot_knm) / 1.5, min_psf])
+    w = np.clip(10 * psf_knm, min_psf, dist)
+    return int(2 * np.floor(w / 2) + 1)
+
+
+def rectangular_array(shape, array_shape, array_pitch, array_center=None):
+    """Spot grid in "knm".  SpotHologram.make_rectangular_array, _spots.py:1441-1485."""
+    if np.isscalar(array_shape):
+        array_shape = (int(array_shape), int(array_shape))
+    if np.isscalar(array_pitch):
+        array_pitch = (array_pitch, array_pitch)
+    if array_center is None:
+        array_center = (shape[1] / 2.0, shape[0] / 2.0)
+    xe = (np.arange(array_shape[0]) - (array_shape[0] - 1) / 2.0) * array_pitch[0] + array_center[0]
+    ye = (np.arange(array_shape[1]) - (array_shape[1] - 1) / 2.0) * array_pitch[1] + array_center[1]
+    xg, yg = np.meshgrid(xe, ye, sparse=False, indexing="xy")
+    return np.vstack((xg.ravel(), yg.ravel()))

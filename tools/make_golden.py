@@ -1,0 +1,311 @@
+#!/usr/bin/env python
+"""
+Generate the golden fixtures under tests/golden/ by running the REAL reference
+(/root/reference, slmsuite 0.4.1, NumPy backend) on seeded inputs.
+
+Runs only in the build container (the reference never travels to the GPU box; the
+fixtures do).  Nothing from the reference is copied: fixtures hold inputs and outputs only.
+
+    python tools/make_golden.py            # small fixtures (seconds)
+    python tools/make_golden.py --cfg2     # additionally the 4096^2 config-2 summary (~3 min)
+"""
+import argparse
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from slmsuite_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    """SURVEY Appendix B recipe: empty cv2/h5py stubs, Agg backend, reference on sys.path."""
+    warnings.simplefilter("ignore")
+    import matplotlib
+    matplotlib.use("Agg")
+    for name in ("cv2", "h5py"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.path.insert(0, "/root/reference")
+    from slmsuite.holography import algorithms, toolbox, analysis
+    return algorithms, toolbox, analysis
+
+
+def record_run(holo, method, maxiter, save_iters, **kw):
+    """
+    One optimize(maxiter) call with a snapshot callback.  The callback fires after the forward
+    transform of loop body k (_hologram.py:1473), i.e. it sees the state *before* body k:
+    phase_k, weights_k, phase_ff as left by body k-1, plus amp_ff = |FFT(phase_k)|.
+    (Calling optimize(maxiter=1) repeatedly would NOT be equivalent for WGS-Kim: the trailing
+    _populate_results overwrites the frozen phase_ff, _hologram.py:949.)
+    """
+    out = {}
+
+    def snap(h):
+        k = h.iter - it0
+        if k in save_iters:
+            out[f"phase_{k}"] = np.array(h.phase, copy=True)
+            out[f"weights_{k}"] = np.array(h.weights, copy=True)
+            if h.phase_ff is not None:
+                out[f"phaseff_{k}"] = np.array(h.phase_ff, copy=True)
+            out[f"ampff_{k}"] = np.array(h.amp_ff, copy=True)
+            out[f"fixed_{k}"] = np.array(bool(h.flags.get("fixed_phase", False)))
+        return False
+
+    it0 = holo.iter
+    holo.optimize(method, maxiter=maxiter, verbose=False, callback=snap, **kw)
+    out["final_phase"] = np.array(holo.phase, copy=True)
+    out["final_weights"] = np.array(holo.weights, copy=True)
+    out["final_ampff"] = np.array(holo.amp_ff, copy=True)
+    out["final_phaseff"] = np.array(holo.phase_ff, copy=True)
+    out["fixed_history"] = np.array([bool(x) for x in holo.stats["flags"]["fixed_phase"]])
+    for g, d in holo.stats["stats"].items():
+        for n, lst in d.items():
+            out[f"stats_{g}_{n}"] = np.array(lst, dtype=float)
+    return out
+
+
+def slim(meta, arrays):
+    """Keep the fixtures small: P-sized per-iteration snapshots only where a test needs them."""
+    kind, variant = meta["kind"], meta.get("variant")
+    keep = {}
+    for k, v in arrays.items():
+        head, _, tail = k.rpartition("_")
+        if head in ("phase", "weights", "phaseff", "ampff", "fixed") and tail.isdigit():
+            it = int(tail)
+            if head == "fixed":
+                keep[k] = v
+            elif kind == "hologram" and variant == "A":
+                if (head in ("phase", "weights") and it in (1, 2, 5, 6)) or (head == "phaseff" and it == 5):
+                    keep[k] = v
+            elif kind in ("hologram", "mraf"):
+                if (head == "phase" and it in (1, 2, 5)) or (head == "weights" and it == 2):
+                    keep[k] = v
+            else:
+                keep[k] = v
+        elif k == "final_phaseff" and not (kind == "hologram" and variant == "A"):
+            continue
+        else:
+            keep[k] = v
+    return keep
+
+
+def save(name, meta, arrays):
+    arrays = slim(meta, dict(arrays))
+    arrays["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+METHOD_KW = {
+    "GS": {},
+    "WGS-Leonardo": {},
+    "WGS-Kim": {"fix_phase_iteration": 4},
+    "WGS-Nogrette": {},
+    "WGS-Wu": {},
+    "WGS-tanh": {},
+}
+
+
+def gen_hologram_cases(alg):
+    """F1/F2: every method x {A: 64^2 S=P scalar amp, B: 128^2 pad of 48x80, array amp + kernel}."""
+    for mi, (method, kw) in enumerate(METHOD_KW.items()):
+        for variant in ("A", "B"):
+            for dt in (np.float32, np.float64):
+                if dt is np.float64 and not (variant == "A" and method in ("GS", "WGS-Kim")):
+                    continue
+                seed = 100 + mi
+                if variant == "A":
+                    shape, slm = (64, 64), (64, 64)
+                    amp, kernel = None, None
+                else:
+                    shape, slm = (128, 128), (48, 80)
+                    amp = synth.gaussian_amp(slm, dtype=dt)
+                    kernel = (0.3 * synth.seed_phase(seed + 50, slm)).astype(dt)
+                target = synth.random_target(seed, shape, dtype=dt)
+                phase0 = synth.seed_phase(seed, slm, dtype=dt)
+                h = alg.Hologram(target.copy(), amp=None if amp is None else amp.copy(),
+                                 phase=phase0.copy(), slm_shape=slm, dtype=dt,
+                                 propagation_kernel=None if kernel is None else kernel.copy())
+                maxiter = 8
+                rec = record_run(h, method, maxiter, save_iters=(0, 1, 2, 3, 5, 6, 7),
+                                 stat_groups=["computational"], **kw)
+                meta = dict(kind="hologram", method=method, variant=variant, seed=seed,
+                            shape=shape, slm_shape=slm, dtype=np.dtype(dt).name, maxiter=maxiter,
+                            kwargs=kw, amp="gaussian" if amp is not None else None,
+                            kernel_seed=None if kernel is None else seed + 50)
+                tag = f"holo_{method.replace('-', '')}_{variant}_{'f32' if dt is np.float32 else 'f64'}"
+                save(tag, meta, rec)
+
+
+def mraf_target(seed, n=128, dtype=np.float32):
+    """zeros; centred (3n/4)^2 box = NaN (noise); centred (n/2)^2 = uniform(0.2, 1) image."""
+    t = np.zeros((n, n), dtype=dtype)
+    a, b = n // 8, n - n // 8
+    t[a:b, a:b] = np.nan
+    a, b = n // 4, n - n // 4
+    t[a:b, a:b] = synth.random_target(seed, (b - a, b - a), 0.2, 1.0, dtype=dtype)
+    return t
+
+
+def gen_mraf_cases(alg):
+    """F3: MRAF with mraf_factor in {None, 0.5}, zero_factor in {absent, 1}."""
+    for method in ("GS", "WGS-Leonardo"):
+        for mf in (None, 0.5):
+            for zf in (None, 1.0):
+                if zf is not None and mf is None:
+                    continue
+                if method == "GS" and zf is not None:
+                    continue
+                if method == "WGS-Leonardo" and mf is None:
+                    continue
+                seed = 300
+                shape, slm = (128, 128), (64, 96)
+                target = mraf_target(seed)
+                phase0 = synth.seed_phase(seed, slm)
+                kw = {}
+                if mf is not None:
+                    kw["mraf_factor"] = mf
+                if zf is not None:
+                    kw["zero_factor"] = zf
+                h = alg.Hologram(target.copy(), phase=phase0.copy(), slm_shape=slm)
+                rec = record_run(h, method, 5, save_iters=(0, 1, 2, 3, 5),
+                                 stat_groups=["computational"], **kw)
+                if hasattr(h, "zero_weights"):
+                    rec["final_zero_weights"] = np.array(h.zero_weights)
+                meta = dict(kind="mraf", method=method, seed=seed, shape=shape, slm_shape=slm,
+                            dtype="float32", maxiter=5, kwargs=kw)
+                tag = f"mraf_{method.replace('-', '')}_mf{mf}_zf{zf}"
+                save(tag, meta, rec)
+
+
+def gen_spot_cases(alg):
+    """F4: SpotHologram 256^2 pad of 72x120, 8x8 grid pitch 16; three feedback modes."""
+    shape, slm = (256, 256), (72, 120)
+    for fb in ("computational", "computational_spot", "external_spot"):
+        for method in ("WGS-Leonardo", "WGS-Kim"):
+            if method == "WGS-Kim" and fb != "computational_spot":
+                continue
+            seed = 400
+            phase0 = synth.seed_phase(seed, slm)
+            h = alg.SpotHologram.make_rectangular_array(
+                shape, array_shape=(8, 8), array_pitch=(16, 16), basis="knm",
+                slm_shape=slm, phase=phase0.copy())
+            kw = dict(METHOD_KW[method])
+            if fb == "external_spot":
+                h.external_spot_amp = h.spot_amp * (1 + 0.2 * (synth.uniform01(seed, (64,), 5) - 0.5))
+            sg = ["computational", "computational_spot"]
+            rec = record_run(h, method, 8, save_iters=(0, 1, 2, 3, 5, 6, 7), feedback=fb,
+                             stat_groups=sg, **kw)
+            rec["spot_knm"] = np.array(h.spot_knm)
+            rec["spot_knm_rounded"] = np.array(h.spot_knm_rounded)
+            rec["spot_amp"] = np.array(h.spot_amp)
+            rec["external_spot_amp"] = np.array(h.external_spot_amp)
+            rec["target_spots"] = np.array(h.target[h.spot_knm_rounded[1], h.spot_knm_rounded[0]])
+            rec["final_ampff_sub"] = rec["final_ampff"][::4, ::4].copy()
+            rec["final_ampff_spots"] = rec["final_ampff"][h.spot_knm_rounded[1], h.spot_knm_rounded[0]]
+            rec["final_weights_spots"] = rec["final_weights"][h.spot_knm_rounded[1], h.spot_knm_rounded[0]]
+            rec["final_weights_sum"] = np.array(float(np.sum(rec["final_weights"].astype(float))))
+            del rec["final_ampff"], rec["final_weights"]
+            # drop the big P-sized per-iteration arrays except weights at spots
+            ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+            for k in list(rec.keys()):
+                if k.startswith(("weights_", "ampff_", "phaseff_")):
+                    if k.startswith("phaseff_"):
+                        del rec[k]
+                        continue
+                    if k.startswith(("weights_", "ampff_")):
+                        rec[k + "_spots"] = rec[k][ky, kx]
+                        del rec[k]
+            meta = dict(kind="spot", method=method, feedback=fb, seed=seed, shape=shape, slm_shape=slm,
+                        dtype="float32", maxiter=8, kwargs=kw, array_shape=(8, 8), array_pitch=(16, 16),
+                        width=int(h.spot_integration_width_knm), stat_groups=sg)
+            save(f"spot_{method.replace('-', '')}_{fb}", meta, rec)
+
+
+def gen_helper_cases(alg, toolbox, analysis):
+    """F7: unpad/pad index tuples, get_padded_shape table, take windows, integration width."""
+    out = {}
+    pads = [((64, 64), (64, 64)), ((128, 128), (48, 80)), ((4096, 4096), (1152, 1920)),
+            ((65, 64), (30, 31)), ((9, 12), (4, 7)), ((256, 256), (72, 120)), ((8192, 8192), (1152, 1920))]
+    out["unpad_in"] = np.array([[a[0], a[1], b[0], b[1]] for a, b in pads])
+    out["unpad_out"] = np.array([toolbox.unpad(a, b) for a, b in pads])
+    ps = [((1152, 1920), 1, True), ((1152, 1920), 2, True), ((1152, 1920), 3, True),
+          ((720, 1280), 1, False), ((720, 1280), 2, False), ((512, 512), 1, True), ((600, 800), 0, False)]
+    out["padshape_in"] = np.array([[s[0], s[1], o, int(q)] for s, o, q in ps])
+    out["padshape_out"] = np.array([alg.Hologram.get_padded_shape(s, o, q) for s, o, q in ps])
+    img = synth.random_target(7, (40, 50))
+    vec = np.array([[5.2, 20.7, 44.0, 10.5], [6.9, 30.1, 3.0, 35.5]])
+    out["take_img"] = img
+    out["take_vec"] = vec
+    for w in (1, 3, 5):
+        out[f"take_w{w}"] = analysis.take(img, vec, w, centered=True, integrate=True)
+    save("helpers", dict(kind="helpers"), out)
+
+
+def gen_cfg1(alg):
+    """F6/cfg1: Hologram 512^2 random amplitude, GS, 20 iterations, f32."""
+    shape = (512, 512)
+    target = synth.random_target(1, shape)
+    phase0 = synth.seed_phase(1, shape)
+    h = alg.Hologram(target.copy(), phase=phase0.copy(), slm_shape=shape)
+    h.optimize("GS", maxiter=20, verbose=False, stat_groups=["computational"])
+    out = dict(phase_sub=np.array(h.phase[::4, ::4]), ampff_sub=np.array(h.amp_ff[::4, ::4]),
+               ampff_norm=np.array(float(np.sqrt(np.sum(np.square(h.amp_ff.astype(float)))))),
+               efficiency=np.array(h.stats["stats"]["computational"]["efficiency"]),
+               std_err=np.array(h.stats["stats"]["computational"]["std_err"]))
+    save("cfg1_summary", dict(kind="cfg1", seed=1, shape=shape, maxiter=20, method="GS", sub=4), out)
+
+
+def gen_cfg2(alg):
+    """F6/cfg2: SpotHologram 32x32 pitch 64 on 4096^2, S=1152x1920, WGS-Leonardo 50 it."""
+    import time
+    shape, slm = (4096, 4096), (1152, 1920)
+    phase0 = synth.seed_phase(2, slm)
+    h = alg.SpotHologram.make_rectangular_array(
+        shape, array_shape=(32, 32), array_pitch=(64, 64), basis="knm", slm_shape=slm, phase=phase0.copy())
+    t0 = time.time()
+    h.optimize("WGS-Leonardo", maxiter=50, verbose=False, stat_groups=[])
+    dt = time.time() - t0
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    out = dict(spot_ampff=np.array(h.amp_ff[ky, kx]), spot_weights=np.array(h.weights[ky, kx]),
+               ampff_sub=np.array(h.amp_ff[::16, ::16]), phase_sub=np.array(h.phase[::6, ::6]),
+               ampff_norm=np.array(float(np.sqrt(np.sum(np.square(h.amp_ff.astype(float)))))),
+               spot_knm_rounded=np.array(h.spot_knm_rounded), wall_s=np.array(dt))
+    save("cfg2_summary", dict(kind="cfg2", seed=2, shape=shape, slm_shape=slm, maxiter=50,
+                              method="WGS-Leonardo", sub_ampff=16, sub_phase=6, wall_s=dt), out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg2", action="store_true")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    alg, toolbox, analysis = import_reference()
+    steps = {
+        "hologram": lambda: gen_hologram_cases(alg),
+        "mraf": lambda: gen_mraf_cases(alg),
+        "spot": lambda: gen_spot_cases(alg),
+        "helpers": lambda: gen_helper_cases(alg, toolbox, analysis),
+        "cfg1": lambda: gen_cfg1(alg),
+    }
+    if args.cfg2:
+        steps["cfg2"] = lambda: gen_cfg2(alg)
+    for name, fn in steps.items():
+        if args.only and name != args.only:
+            continue
+        print(name)
+        fn()
+
+
+if __name__ == "__main__":
+    main()
