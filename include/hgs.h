@@ -1,0 +1,146 @@
+/*
+ * hgs.h -- C ABI of the MI355X hologram (Gerchberg-Saxton / weighted-GS) engine.
+ *
+ * This is the drop-in boundary for slmsuite's optimize() hot path.  The reference has no FFI of
+ * its own: the path sits behind the array-module alias `cp` (slmsuite/holography/algorithms/
+ * _header.py:15-32) and the overridable per-iteration methods of `Hologram`
+ * (slmsuite/holography/algorithms/_hologram.py).  Each entry point below replaces the reference
+ * method(s) cited next to it; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative hgs_status otherwise; the message of the
+ *     last error of the calling thread is available from hgs_last_error();
+ *   - an engine handle is single-threaded; different handles are independent;
+ *   - the engine owns all device memory and one HIP stream; host buffers are caller-owned,
+ *     C-contiguous, in the reference's natural layout (row-major, centred zero order), of the
+ *     engine's real type (float when real_bytes == 4, double when 8; complex = 2 reals);
+ *   - batched arrays are [batch][...]; passing exactly one hologram's bytes broadcasts it;
+ *   - calls are asynchronous on the engine stream unless they move data to/from the host.
+ *   - there is NO CPU fallback: without a usable gfx950 device hgs_create fails with
+ *     HGS_ERR_DEVICE.
+ */
+#ifndef HGS_H
+#define HGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hgs_engine hgs_engine;
+
+typedef enum {
+    HGS_OK = 0,
+    HGS_ERR_ARG = -1,      /* invalid argument (ValueError on the Python side)            */
+    HGS_ERR_DEVICE = -2,   /* no device / HIP runtime error (RuntimeError)                */
+    HGS_ERR_STATE = -3,    /* operation not valid in the current state                    */
+    HGS_ERR_UNSUPPORTED = -4
+} hgs_status;
+
+/* Geometry of one engine.  Hologram.__init__ (_hologram.py:196-439): `shape` -> pad_h/pad_w,
+ * `slm_shape` -> slm_h/slm_w, dtype (:391-398) -> real_bytes.  pad_h and pad_w must be powers of
+ * two in [64, 8192]; the SLM block is centred (toolbox.unpad, toolbox/__init__.py:1699-1712). */
+typedef struct {
+    int32_t device;      /* HIP device ordinal                                          */
+    int32_t pad_h, pad_w;
+    int32_t slm_h, slm_w;
+    int32_t real_bytes;  /* 4 | 8                                                       */
+    int32_t batch;       /* independent holograms advanced together        */
+    int32_t n_spots;     /* > 0 enables spot-window / external-spot feedback            */
+} hgs_config;
+
+/* ALGORITHM_INDEX (_header.py:72) */
+enum { HGS_GS = 0, HGS_WGS_LEONARDO = 1, HGS_WGS_KIM = 2, HGS_WGS_NOGRETTE = 3, HGS_WGS_WU = 4,
+       HGS_WGS_TANH = 5 };
+/* feedback sources of _update_weights (_hologram.py:1914, _spots.py:1573-1624) */
+enum { HGS_FB_PIXEL = 0 /* "computational" */, HGS_FB_SPOT_WINDOW = 1 /* "computational_spot" */,
+       HGS_FB_EXTERNAL = 2 /* "external_spot" */ };
+
+/* Per-call flags: the POD image of Hologram.flags (_hologram.py:1370-1410).  Fields marked
+ * in/out are advanced by the engine exactly as optimize_gs / _gs_farfield_routines do. */
+typedef struct {
+    int32_t method;              /* HGS_GS ...                                           */
+    int32_t feedback;            /* HGS_FB_*                                             */
+    int32_t iter;                /* in/out  self.iter (:1490)                            */
+    int32_t fixed_phase;         /* in/out  flags["fixed_phase"] (:1556-1585)            */
+    int32_t fix_phase_iteration; /* flags["fix_phase_iteration"]                         */
+    int32_t false_run;           /* in/out  trailing count of contiguous False entries in
+                                    stats["flags"]["fixed_phase"] (:1574-1577); -1 = history
+                                    contains a non-boolean entry (never fixes by iteration)   */
+    int32_t mraf_enabled;        /* target contains NaN (_mraf_helper_routines :1498)    */
+    int32_t has_mraf_factor;     /* flags["mraf_factor"] is not None                     */
+    int32_t zero_mode;           /* flags["zero_factor"] given and != 0 (:1514)          */
+    int32_t spot_window;         /* spot_integration_width_knm (_spots.py:1284-1297)     */
+    double feedback_exponent, feedback_factor, mraf_factor, zero_factor;
+} hgs_step;
+
+/* array selectors for hgs_set_array / hgs_get_array */
+enum {
+    HGS_PHASE = 0,        /* [batch][slm_h][slm_w] real      Hologram.phase              */
+    HGS_AMP = 1,          /* [slm_h][slm_w] real, unit L2    Hologram.amp (array form)   */
+    HGS_AMP_SCALAR = 2,   /* 1 real                          Hologram.amp (scalar form)  */
+    HGS_PROP_KERNEL = 3,  /* [slm_h][slm_w] real             Hologram.propagation_kernel */
+    HGS_TARGET = 4,       /* [batch][pad_h][pad_w] real      Hologram.target (may hold NaN) */
+    HGS_WEIGHTS = 5,      /* [batch][pad_h][pad_w] real      Hologram.weights            */
+    HGS_PHASE_FF = 6,     /* [batch][pad_h][pad_w] real      Hologram.phase_ff           */
+    HGS_FARFIELD = 7,     /* [batch][pad_h][pad_w] complex   Hologram.farfield           */
+    HGS_AMP_FF = 8,       /* [batch][pad_h][pad_w] real      Hologram.amp_ff             */
+    HGS_SPOT_INDEX = 9,   /* int32 [2][n_spots] (kx row 0, ky row 1)  spot_knm_rounded   */
+    HGS_SPOT_AMP = 10,    /* double [n_spots]                SpotHologram.spot_amp       */
+    HGS_EXTERNAL_AMP = 11,/* double [n_spots]                external_spot_amp           */
+    HGS_ZERO_WEIGHTS = 12 /* [batch][pad_h][pad_w] complex   dense image of zero_weights */
+};
+
+int hgs_create(const hgs_config* cfg, hgs_engine** out);
+int hgs_destroy(hgs_engine* e);
+
+/* host -> device / device -> host (synchronous).  Replaces the cp.array(...)/.get() traffic of
+ * Hologram.__init__, reset_phase (:536), set_weights (:829), get_phase (:786) ... */
+int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes);
+int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes);
+/* device -> caller-provided DEVICE buffer (e.g. a torch tensor handed to RCCL); synchronous */
+int hgs_get_array_device(hgs_engine* e, int which, void* dev, size_t nbytes);
+/* Hologram.reset_weights (:603-614): weights = target with NaN -> 0; zero_weights cleared */
+int hgs_reset_weights(hgs_engine* e);
+
+/* Hologram._nearfield2farfield (:1038-1056) + _midloop_cleaning (:951-953): fills farfield and
+ * amp_ff; with store_phase_ff != 0 also phase_ff = atan2(farfield) (_populate_results :934-949). */
+int hgs_nearfield2farfield(hgs_engine* e, int store_phase_ff);
+/* Hologram._gs_farfield_routines (:1550-1661) incl. _update_weights (:1914 / _spots.py:1573) and
+ * _update_weights_generic (:1786-1879); operates on the materialised farfield. */
+int hgs_farfield_constraint(hgs_engine* e, hgs_step* step);
+/* Hologram._farfield2nearfield (:1058-1073) + _nearfield_extract (:1026-1036). */
+int hgs_farfield2nearfield(hgs_engine* e);
+/* n_iter bodies of the optimize_gs loop (:1465-1490) with no callback and no statistics:
+ * the fused fast path (the farfield is never materialised when the method allows it).
+ * fixed_phase_history[n_iter] (optional) receives flags["fixed_phase"] as _update_stats would
+ * have recorded it in each iteration. */
+int hgs_iterate(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* fixed_phase_history);
+/* _HologramStats._calculate_stats (_stats.py:7-116), efficiency_compensation = False.
+ * group 0: "computational" (amp_ff vs target); group 1: "computational_spot"
+ * (window sums at spot_knm with total power, _spots.py:1626-1679).
+ * out[batch][4] = efficiency, uniformity, pkpk_err, std_err.  Needs a materialised farfield. */
+int hgs_stats(hgs_engine* e, int group, int width, const double* spot_xy_float, double* out);
+
+int hgs_sync(hgs_engine* e);
+
+/* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */
+enum { HGS_K_ROW = 0, HGS_K_COL_FUSED = 1, HGS_K_COL_FWD = 2, HGS_K_COL_INV = 3, HGS_K_ELEMENTWISE = 4,
+       HGS_K_COUNT = 5 };
+int hgs_profile_enable(hgs_engine* e, int on);
+/* out[HGS_K_COUNT][2] = {total milliseconds, launches} since the last call; syncs the stream */
+int hgs_profile_read(hgs_engine* e, double* out);
+/* elapsed milliseconds of hgs_iterate(step, n_iter) measured with a HIP event pair on the engine
+ * stream (SURVEY 8d timing protocol) */
+int hgs_iterate_timed(hgs_engine* e, hgs_step* step, int n_iter, double* ms);
+
+const char* hgs_last_error(void);
+/* library / device identification: "hgs <version> gfx950 <device name>" */
+const char* hgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGS_H */

@@ -1,0 +1,98 @@
+"""
+ctypes binding of libhgs.so (the C ABI declared in include/hgs.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C slmsuite_amd/csrc``.
+There is deliberately NO fallback: if the shared library or a gfx950 device is missing, using
+the engine raises -- the product path never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhgs.so")
+
+HGS_OK, HGS_ERR_ARG, HGS_ERR_DEVICE, HGS_ERR_STATE, HGS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+
+# array selectors (include/hgs.h)
+(PHASE, AMP, AMP_SCALAR, PROP_KERNEL, TARGET, WEIGHTS, PHASE_FF, FARFIELD, AMP_FF, SPOT_INDEX,
+ SPOT_AMP, EXTERNAL_AMP, ZERO_WEIGHTS) = range(13)
+FB_PIXEL, FB_SPOT_WINDOW, FB_EXTERNAL = 0, 1, 2
+K_NAMES = ("row", "col_fused", "col_fwd", "col_inv", "elementwise")
+
+
+class hgs_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("device", "pad_h", "pad_w", "slm_h", "slm_w", "real_bytes", "batch", "n_spots")]
+
+
+class hgs_step(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("method", "feedback", "iter", "fixed_phase", "fix_phase_iteration", "false_run",
+                 "mraf_enabled", "has_mraf_factor", "zero_mode", "spot_window")] + \
+               [(n, C.c_double) for n in
+                ("feedback_exponent", "feedback_factor", "mraf_factor", "zero_factor")]
+
+
+_lib = None
+
+
+class HgsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libhgs.so once and declare prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HgsError(
+            f"{LIB_PATH} not found: build the HIP engine first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C slmsuite_amd/csrc). "
+            "slmsuite_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    eng = C.c_void_p
+    protos = {
+        "hgs_create": (C.c_int, [P(hgs_config), P(eng)]),
+        "hgs_destroy": (C.c_int, [eng]),
+        "hgs_set_array": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
+        "hgs_get_array": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
+        "hgs_get_array_device": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
+        "hgs_reset_weights": (C.c_int, [eng]),
+        "hgs_nearfield2farfield": (C.c_int, [eng, C.c_int]),
+        "hgs_farfield_constraint": (C.c_int, [eng, P(hgs_step)]),
+        "hgs_farfield2nearfield": (C.c_int, [eng]),
+        "hgs_iterate": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_uint8)]),
+        "hgs_stats": (C.c_int, [eng, C.c_int, C.c_int, P(C.c_double), P(C.c_double)]),
+        "hgs_sync": (C.c_int, [eng]),
+        "hgs_profile_enable": (C.c_int, [eng, C.c_int]),
+        "hgs_profile_read": (C.c_int, [eng, P(C.c_double)]),
+        "hgs_iterate_timed": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_double)]),
+        "hgs_last_error": (C.c_char_p, []),
+        "hgs_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device",
+           "hgs_reset_weights", "hgs_nearfield2farfield", "hgs_farfield_constraint",
+           "hgs_farfield2nearfield", "hgs_iterate", "hgs_stats", "hgs_sync", "hgs_profile_enable",
+           "hgs_profile_read", "hgs_iterate_timed", "hgs_last_error", "hgs_version")
+
+
+def check(code):
+    """Map engine status codes onto the reference's exception types (ValueError / RuntimeError)."""
+    if code == HGS_OK:
+        return
+    msg = load().hgs_last_error().decode(errors="replace")
+    if code == HGS_ERR_ARG:
+        raise ValueError(msg)
+    if code == HGS_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HgsError(msg)

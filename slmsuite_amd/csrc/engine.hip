@@ -1,0 +1,849 @@
+// Host side of the hologram engine: device state, kernel sequencing, the C ABI of include/hgs.h.
+// One engine = one HIP stream + all device buffers of a batch of equally-shaped holograms.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hgs.h"
+#include "launch.hpp"
+
+namespace hgs {
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(HGS_ERR_DEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LCHK(x)                                                                                \
+    do {                                                                                       \
+        int e_ = (x);                                                                          \
+        if (e_ != 0)                                                                           \
+            return fail(HGS_ERR_DEVICE, "kernel launch failed: %s (%s:%d)",                    \
+                        hipGetErrorString((hipError_t)e_), __FILE__, __LINE__);                \
+    } while (0)
+
+static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual int init(const hgs_config& c) = 0;
+    virtual int set_array(int which, const void* host, size_t nbytes) = 0;
+    virtual int get_array(int which, void* dst, size_t nbytes, bool dst_device) = 0;
+    virtual int reset_weights() = 0;
+    virtual int n2f(int store_pff) = 0;
+    virtual int constraint(hgs_step* st) = 0;
+    virtual int f2n() = 0;
+    virtual int iterate(hgs_step* st, int n, uint8_t* hist) = 0;
+    virtual int stats(int group, int width, const double* xy, double* out) = 0;
+    virtual int sync() = 0;
+    virtual int profile_enable(int on) = 0;
+    virtual int profile_read(double* out) = 0;
+    virtual int iterate_timed(hgs_step* st, int n, double* ms) = 0;
+};
+
+template <typename R> struct Engine : EngineBase {
+    using C = Cx<R>;
+    hgs_config cfg{};
+    Geo g{};
+    hipStream_t stream = nullptr;
+    size_t S = 0, P = 0;  // elements per hologram
+    int B = 1;
+    // device buffers
+    R* phase = nullptr;
+    R* amp = nullptr;
+    R* kern = nullptr;
+    C* gh = nullptr;
+    R* w = nullptr;
+    R* t = nullptr;
+    R* pff = nullptr;
+    C* ff = nullptr;
+    R* aff = nullptr;
+    C* zw = nullptr;
+    void* staging = nullptr;  // B*P complex, natural-layout bounce buffer for set/get
+    C* tw_row = nullptr;
+    C* tw_col = nullptr;
+    double* wpartial = nullptr;
+    double* fpartial = nullptr;
+    double* epartial = nullptr;  // elementwise partials
+    double* sums = nullptr;      // [3][B]: fsum, nogsum, wsum
+    R* wscale = nullptr;
+    int* spot_xy = nullptr;
+    double* spot_amp = nullptr;
+    double* ext_amp = nullptr;
+    R* spot_fb = nullptr;
+    // host state
+    double amp_scalar = 0, amp_norm2 = 1.0;
+    bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
+    bool w_pending = false;  // weights stored un-normalised, wscale holds 1/||w||
+    bool has_target = false, has_spots = false;
+    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256;
+    // profiling
+    bool prof = false;
+    struct Ev { int kind; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    double prof_ms[HGS_K_COUNT] = {0};
+    double prof_n[HGS_K_COUNT] = {0};
+
+    ~Engine() override {
+        if (stream) hipStreamSynchronize(stream);
+        void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb};
+        for (void* p : ptrs)
+            if (p) hipFree(p);
+        for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        if (stream) hipStreamDestroy(stream);
+    }
+
+    template <typename T> int dalloc(T** p, size_t n) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+        HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), stream));
+        return 0;
+    }
+
+    int make_twiddles(C** dev, int N) {
+        std::vector<C> h(N);
+        for (int i = 0; i < N; ++i) {
+            const double a = -2.0 * M_PI * (double)i / (double)N;
+            h[i].x = (R)cos(a);
+            h[i].y = (R)sin(a);
+        }
+        // exact values on the axes (cos(pi/2) is 6e-17 in double, rounds fine, but keep them exact)
+        h[0].x = 1; h[0].y = 0;
+        h[N / 4].x = 0; h[N / 4].y = -1;
+        h[N / 2].x = -1; h[N / 2].y = 0;
+        h[3 * N / 4].x = 0; h[3 * N / 4].y = 1;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(dev), N * sizeof(C)));
+        HIPCHK(hipMemcpy(*dev, h.data(), N * sizeof(C), hipMemcpyHostToDevice));
+        return 0;
+    }
+
+    int init(const hgs_config& c) override {
+        cfg = c;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(HGS_ERR_DEVICE, "no HIP device available (the engine has no CPU fallback)");
+        if (c.device < 0 || c.device >= ndev) return fail(HGS_ERR_ARG, "device %d out of range", c.device);
+        HIPCHK(hipSetDevice(c.device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c.device));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (!is_pow2(c.pad_h) || !is_pow2(c.pad_w) || c.pad_h < 64 || c.pad_w < 64 || c.pad_h > 8192 ||
+            c.pad_w > 8192)
+            return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d) must be powers of two in [64, 8192]",
+                        c.pad_h, c.pad_w);
+        if (c.slm_h < 1 || c.slm_w < 1 || c.slm_h > c.pad_h || c.slm_w > c.pad_w)
+            return fail(HGS_ERR_ARG, "slm shape (%d, %d) does not fit the padded shape (%d, %d)", c.slm_h,
+                        c.slm_w, c.pad_h, c.pad_w);
+        if (c.batch < 1) return fail(HGS_ERR_ARG, "batch must be >= 1");
+        g.Ph = c.pad_h; g.Pw = c.pad_w; g.Sh = c.slm_h; g.Sw = c.slm_w;
+        g.r0 = (c.pad_h - c.slm_h) / 2;  // floor((P-S)/2)  toolbox.unpad
+        g.c0 = (c.pad_w - c.slm_w) / 2;
+        g.batch = B = c.batch;
+        S = (size_t)g.Sh * g.Sw;
+        P = (size_t)g.Ph * g.Pw;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+        // grid sizes: enough workgroups to fill the chip a few times over, balanced over the work
+        const int fpw = row_fpw(g.Pw);
+        const int row_units = (g.Sh + fpw - 1) / fpw;
+        int cap = env_int("HGS_ROW_BLOCKS", n_cu * 4);
+        cap = cap / B > 0 ? cap / B : 1;
+        int per = (row_units + cap - 1) / cap;
+        row_blocks = (row_units + per - 1) / per;
+        const int tiles = g.Pw / 4;
+        cap = env_int("HGS_COL_BLOCKS", n_cu * 3);
+        cap = cap / B > 0 ? cap / B : 1;
+        per = (tiles + cap - 1) / cap;
+        col_blocks = (tiles + per - 1) / per;
+        ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
+
+        if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
+        if (dalloc(&gh, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE;
+        if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&wpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&fpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&sums, (size_t)3 * B)) return HGS_ERR_DEVICE;
+        if (dalloc(&wscale, (size_t)B)) return HGS_ERR_DEVICE;
+        if (int e = fill_wscale_one()) return e;
+        if (int e = make_twiddles(&tw_row, g.Pw)) return e;
+        if (int e = make_twiddles(&tw_col, g.Ph)) return e;
+        if (c.n_spots > 0) {
+            if (dalloc(&spot_xy, (size_t)2 * c.n_spots)) return HGS_ERR_DEVICE;
+            if (dalloc(&spot_amp, (size_t)c.n_spots)) return HGS_ERR_DEVICE;
+            if (dalloc(&ext_amp, (size_t)c.n_spots)) return HGS_ERR_DEVICE;
+            if (dalloc(&spot_fb, (size_t)B * c.n_spots)) return HGS_ERR_DEVICE;
+        }
+        amp_scalar = 1.0 / std::sqrt((double)S);  // Hologram.__init__ :401-402
+        amp_norm2 = 1.0;
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int fill_wscale_one() {
+        hipLaunchKernelGGL(set_scalar<R>, dim3((B + 63) / 64), dim3(64), 0, stream, wscale, B, (R)1);
+        HIPCHK(hipGetLastError());
+        w_pending = false;
+        return 0;
+    }
+
+    // ---- lazily allocated farfield-sized buffers ----
+    int need_ff() {
+        if (!ff) { if (dalloc(&ff, B * P)) return HGS_ERR_DEVICE; }
+        if (!aff) { if (dalloc(&aff, B * P)) return HGS_ERR_DEVICE; }
+        return 0;
+    }
+    int need_pff() {
+        if (!pff) { if (dalloc(&pff, B * P)) return HGS_ERR_DEVICE; }
+        return 0;
+    }
+    int need_staging() {
+        if (!staging) HIPCHK(hipMalloc(&staging, B * P * sizeof(C)));
+        return 0;
+    }
+    int need_zw() {
+        if (!zw) { if (dalloc(&zw, B * P)) return HGS_ERR_DEVICE; }
+        return 0;
+    }
+
+    // ---- profiling wrapper ----
+    template <typename F> int timed(int kind, F&& f) {
+        if (!prof) return f();
+        Ev e;
+        e.kind = kind;
+        HIPCHK(hipEventCreate(&e.a));
+        HIPCHK(hipEventCreate(&e.b));
+        HIPCHK(hipEventRecord(e.a, stream));
+        int r = f();
+        HIPCHK(hipEventRecord(e.b, stream));
+        evs.push_back(e);
+        return r;
+    }
+    int profile_enable(int on) override { prof = on != 0; return 0; }
+    int profile_read(double* out) override {
+        HIPCHK(hipStreamSynchronize(stream));
+        for (auto& e : evs) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            prof_ms[e.kind] += ms;
+            prof_n[e.kind] += 1;
+            hipEventDestroy(e.a);
+            hipEventDestroy(e.b);
+        }
+        evs.clear();
+        for (int k = 0; k < HGS_K_COUNT; ++k) {
+            out[2 * k] = prof_ms[k];
+            out[2 * k + 1] = prof_n[k];
+            prof_ms[k] = prof_n[k] = 0;
+        }
+        return 0;
+    }
+
+    // ---- natural <-> column-major moves through the staging buffer ----
+    template <typename E> int upload_T(E* dst, const void* host, size_t nbytes) {
+        // host natural [B][Ph][Pw] -> device column-major [B][Pw][Ph]
+        const size_t one = P * sizeof(E);
+        if (nbytes != one * B && nbytes != one) return fail(HGS_ERR_ARG, "array size %zu does not match %zu x {1,%d}", nbytes, one, B);
+        if (int e = need_staging()) return e;
+        E* st = reinterpret_cast<E*>(staging);
+        for (int b = 0; b < B; ++b) {
+            const char* src = (const char*)host + (nbytes == one ? 0 : (size_t)b * one);
+            HIPCHK(hipMemcpyAsync(st + (size_t)b * P, src, one, hipMemcpyHostToDevice, stream));
+        }
+        dim3 grid((g.Pw + 31) / 32, (g.Ph + 31) / 32, B);
+        hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, (const E*)st, dst, g.Ph, g.Pw,
+                           (const R*)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    template <typename E> int download_T(const E* src, void* dst, size_t nbytes, bool dst_device, const R* scale) {
+        const size_t all = P * sizeof(E) * B;
+        if (nbytes != all) return fail(HGS_ERR_ARG, "array size %zu does not match %zu", nbytes, all);
+        if (int e = need_staging()) return e;
+        E* st = reinterpret_cast<E*>(staging);
+        dim3 grid((g.Ph + 31) / 32, (g.Pw + 31) / 32, B);
+        hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, src, st, g.Pw, g.Ph, scale);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(dst, st, all, dst_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int set_array(int which, const void* host, size_t nbytes) override {
+        if (!host) return fail(HGS_ERR_ARG, "null host pointer");
+        switch (which) {
+            case HGS_PHASE: {
+                const size_t one = S * sizeof(R);
+                if (nbytes != one * B && nbytes != one) return fail(HGS_ERR_ARG, "phase: bad size %zu", nbytes);
+                for (int b = 0; b < B; ++b)
+                    HIPCHK(hipMemcpyAsync(phase + (size_t)b * S, (const char*)host + (nbytes == one ? 0 : b * one), one,
+                                          hipMemcpyHostToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                farfield_valid = false;
+                return 0;
+            }
+            case HGS_AMP: {
+                if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "amp: bad size %zu", nbytes);
+                if (!amp) HIPCHK(hipMalloc(reinterpret_cast<void**>(&amp), S * sizeof(R)));
+                HIPCHK(hipMemcpy(amp, host, nbytes, hipMemcpyHostToDevice));
+                has_amp = true;
+                const R* h = (const R*)host;
+                double s = 0;
+                for (size_t i = 0; i < S; ++i) s += (double)h[i] * (double)h[i];
+                amp_norm2 = s;
+                farfield_valid = false;
+                return 0;
+            }
+            case HGS_AMP_SCALAR: {
+                if (nbytes != sizeof(R)) return fail(HGS_ERR_ARG, "amp scalar: bad size %zu", nbytes);
+                amp_scalar = (double)*(const R*)host;
+                has_amp = false;
+                amp_norm2 = amp_scalar * amp_scalar * (double)S;
+                farfield_valid = false;
+                return 0;
+            }
+            case HGS_PROP_KERNEL: {
+                if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "propagation kernel: bad size %zu", nbytes);
+                if (!kern) HIPCHK(hipMalloc(reinterpret_cast<void**>(&kern), S * sizeof(R)));
+                HIPCHK(hipMemcpy(kern, host, nbytes, hipMemcpyHostToDevice));
+                has_kern = true;
+                farfield_valid = false;
+                return 0;
+            }
+            case HGS_TARGET:
+                has_target = true;
+                return upload_T<R>(t, host, nbytes);
+            case HGS_WEIGHTS: {
+                int e = upload_T<R>(w, host, nbytes);
+                if (e) return e;
+                return fill_wscale_one();
+            }
+            case HGS_PHASE_FF: {
+                if (int e = need_pff()) return e;
+                have_pff = true;
+                return upload_T<R>(pff, host, nbytes);
+            }
+            case HGS_ZERO_WEIGHTS: {
+                if (int e = need_zw()) return e;
+                return upload_T<C>(zw, host, nbytes);
+            }
+            case HGS_SPOT_INDEX: {
+                if (cfg.n_spots <= 0) return fail(HGS_ERR_STATE, "engine was created with n_spots = 0");
+                if (nbytes != (size_t)2 * cfg.n_spots * sizeof(int32_t)) return fail(HGS_ERR_ARG, "spot index: bad size");
+                const int32_t* h = (const int32_t*)host;
+                const int hw = 0;  // bounds are checked against the window at constraint time
+                for (int n = 0; n < cfg.n_spots; ++n)
+                    if (h[n] < hw || h[n] >= g.Pw || h[cfg.n_spots + n] < 0 || h[cfg.n_spots + n] >= g.Ph)
+                        return fail(HGS_ERR_ARG, "spot %d outside the computational grid", n);
+                HIPCHK(hipMemcpy(spot_xy, host, nbytes, hipMemcpyHostToDevice));
+                spot_xy_host.assign(h, h + 2 * cfg.n_spots);
+                has_spots = true;
+                return 0;
+            }
+            case HGS_SPOT_AMP:
+            case HGS_EXTERNAL_AMP: {
+                if (cfg.n_spots <= 0) return fail(HGS_ERR_STATE, "engine was created with n_spots = 0");
+                if (nbytes != (size_t)cfg.n_spots * sizeof(double)) return fail(HGS_ERR_ARG, "spot amplitudes: bad size");
+                HIPCHK(hipMemcpy(which == HGS_SPOT_AMP ? spot_amp : ext_amp, host, nbytes, hipMemcpyHostToDevice));
+                return 0;
+            }
+        }
+        return fail(HGS_ERR_ARG, "unknown array selector %d", which);
+    }
+    std::vector<int32_t> spot_xy_host;
+
+    int normalize_weights_now() {
+        // fold the pending 1/||w|| into the stored weights (general path keeps them normalised)
+        if (!w_pending) return 0;
+        hipLaunchKernelGGL(scale_weights_kernel<R>, dim3(ew_blocks, B), dim3(256), 0, stream, w, (const R*)wscale, P);
+        HIPCHK(hipGetLastError());
+        return fill_wscale_one();
+    }
+    int get_array(int which, void* dst, size_t nbytes, bool dst_device) override {
+        if (!dst) return fail(HGS_ERR_ARG, "null destination pointer");
+        switch (which) {
+            case HGS_PHASE: {
+                if (nbytes != S * sizeof(R) * B) return fail(HGS_ERR_ARG, "phase: bad size %zu", nbytes);
+                HIPCHK(hipMemcpyAsync(dst, phase, nbytes, dst_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                return 0;
+            }
+            case HGS_TARGET: return download_T<R>(t, dst, nbytes, dst_device, nullptr);
+            case HGS_WEIGHTS: return download_T<R>(w, dst, nbytes, dst_device, w_pending ? wscale : nullptr);
+            case HGS_PHASE_FF:
+                if (!pff || !have_pff) return fail(HGS_ERR_STATE, "phase_ff has not been computed");
+                return download_T<R>(pff, dst, nbytes, dst_device, nullptr);
+            case HGS_FARFIELD:
+                if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "farfield is not materialised (call hgs_nearfield2farfield)");
+                return download_T<C>(ff, dst, nbytes, dst_device, nullptr);
+            case HGS_AMP_FF:
+                if (!aff || !farfield_valid) return fail(HGS_ERR_STATE, "amp_ff is not materialised (call hgs_nearfield2farfield)");
+                return download_T<R>(aff, dst, nbytes, dst_device, nullptr);
+            case HGS_ZERO_WEIGHTS:
+                if (!zw) return fail(HGS_ERR_STATE, "zero_weights not allocated");
+                return download_T<C>(zw, dst, nbytes, dst_device, nullptr);
+        }
+        return fail(HGS_ERR_ARG, "array selector %d cannot be read back", which);
+    }
+
+    int reset_weights() override {
+        hipLaunchKernelGGL(reset_weights_kernel<R>, dim3(ew_blocks * B), dim3(256), 0, stream, w, (const R*)t, zw, B * P);
+        HIPCHK(hipGetLastError());
+        return fill_wscale_one();
+    }
+
+    // ---- operator launches ----
+    RowArgs<R> row_args(bool finalize) {
+        RowArgs<R> a{};
+        a.g = g; a.phase = phase; a.amp = has_amp ? amp : nullptr; a.kern = has_kern ? kern : nullptr;
+        a.amp_scalar = (R)amp_scalar; a.gh = gh; a.tw = tw_row; a.scale = (R)(1.0 / std::sqrt((double)g.Pw));
+        a.wpartial = finalize ? wpartial : nullptr; a.n_wpartial = col_blocks; a.wscale = wscale;
+        return a;
+    }
+    int run_row(int mode, bool finalize) {
+        return timed(HGS_K_ROW, [&]() -> int {
+            LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks, B), stream, row_args(finalize)));
+            return 0;
+        });
+    }
+    ColArgs<R> col_args() {
+        ColArgs<R> a{};
+        a.g = g; a.gh = gh; a.ff = ff; a.amp_ff = aff; a.pff = pff; a.w = w; a.t = t; a.wscale = wscale;
+        a.wpartial = wpartial; a.fpartial = fpartial; a.tw = tw_col; a.scale = (R)(1.0 / std::sqrt((double)g.Ph));
+        return a;
+    }
+    int reduce(const double* partial, int n, double* out) {
+        hipLaunchKernelGGL(reduce_partials, dim3(B), dim3(256), 0, stream, partial, n, out);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+
+    int n2f(int store_pff) override {
+        if (int e = need_ff()) return e;
+        if (store_pff) { if (int e = need_pff()) return e; }
+        if (int e = run_row(0, false)) return e;
+        int r = timed(HGS_K_COL_FWD, [&]() -> int {
+            ColArgs<R> a = col_args();
+            a.store_pff = store_pff;
+            LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(col_blocks, B), stream, a));
+            return 0;
+        });
+        if (r) return r;
+        if (int e = reduce(fpartial, col_blocks, sums + 0 * B)) return e;
+        if (store_pff) have_pff = true;
+        farfield_valid = true;
+        return 0;
+    }
+
+    int f2n() override {
+        if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
+        int r = timed(HGS_K_COL_INV, [&]() -> int {
+            LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(col_blocks, B), stream, col_args()));
+            return 0;
+        });
+        if (r) return r;
+        farfield_valid = false;  // farfield now holds the constrained field, phase moves on
+        return run_row(1, false);
+    }
+
+    // flag evolution of _gs_farfield_routines (:1552-1585); returns what this iteration must do
+    struct Plan { int do_update, use_fixed, store_phase; };
+    Plan plan_iteration(hgs_step* st, uint8_t* hist_slot) {
+        Plan p{0, 0, 0};
+        // _update_stats ran before the routines: the history sees the flag as it is now (:1479)
+        if (hist_slot) *hist_slot = st->fixed_phase ? 1 : 0;
+        if (st->false_run >= 0) st->false_run = st->fixed_phase ? 0 : st->false_run + 1;
+        const bool wgs = st->method != HGS_GS;
+        if (wgs && st->iter > 0) {
+            p.do_update = 1;
+            if (st->method == HGS_WGS_KIM) {
+                const bool was_not_fixed = !st->fixed_phase;
+                if (was_not_fixed && st->iter >= st->fix_phase_iteration - 1 &&
+                    st->false_run >= st->fix_phase_iteration)
+                    st->fixed_phase = 1;
+                if ((st->fixed_phase && !have_pff) || was_not_fixed) p.store_phase = 1;
+            } else {
+                st->fixed_phase = 0;
+            }
+        }
+        // :1601  "if not fixed or phase_ff is None: phase_ff = atan2(F)".  A phase stored in this very
+        // iteration equals atan2(F), so "store + rebuild from F" is the same thing as using it.
+        if (st->fixed_phase && !have_pff) p.store_phase = 1;
+        p.use_fixed = (st->fixed_phase && have_pff && !p.store_phase) ? 1 : 0;
+        return p;
+    }
+
+    CParams<R> cparams(const hgs_step* st, const Plan& p) {
+        CParams<R> c{};
+        c.method = st->method; c.do_update = p.do_update; c.use_fixed = p.use_fixed; c.store_phase = p.store_phase;
+        c.mraf = st->mraf_enabled; c.has_mraf_factor = st->has_mraf_factor; c.zero_mode = st->zero_mode;
+        c.p_exp = (R)st->feedback_exponent; c.p_fac = (R)st->feedback_factor;
+        c.mraf_factor = (R)st->mraf_factor; c.zero_factor = (R)st->zero_factor;
+        c.inv_fnorm = (R)(1.0 / std::sqrt(amp_norm2));  // Parseval: ||F|| = ||nearfield|| = ||amp||
+        return c;
+    }
+
+    int check_step(const hgs_step* st) {
+        if (st->method < HGS_GS || st->method > HGS_WGS_TANH) return fail(HGS_ERR_ARG, "unknown method %d", st->method);
+        if (st->feedback < HGS_FB_PIXEL || st->feedback > HGS_FB_EXTERNAL) return fail(HGS_ERR_ARG, "unknown feedback %d", st->feedback);
+        if (!has_target) return fail(HGS_ERR_STATE, "target has not been set");
+        if (st->feedback != HGS_FB_PIXEL && st->method != HGS_GS) {
+            if (!has_spots) return fail(HGS_ERR_STATE, "spot feedback needs HGS_SPOT_INDEX / HGS_SPOT_AMP");
+            if (st->feedback == HGS_FB_SPOT_WINDOW) {
+                if (st->spot_window < 1) return fail(HGS_ERR_ARG, "spot_window must be >= 1");
+                const int flo = (int)std::floor(-(st->spot_window - 1) / 2.0);
+                const int fhi = flo + st->spot_window - 1;
+                for (int n = 0; n < cfg.n_spots; ++n) {
+                    const int x = spot_xy_host[n], y = spot_xy_host[cfg.n_spots + n];
+                    if (x + flo < 0 || y + flo < 0 || x + fhi >= g.Pw || y + fhi >= g.Ph)
+                        return fail(HGS_ERR_ARG, "integration window of spot %d leaves the grid (IndexError in the reference)", n);
+                }
+            }
+        }
+        return 0;
+    }
+
+    // general constraint on the materialised farfield
+    int constraint_planned(hgs_step* st, const Plan& p) {
+        if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "farfield is not materialised");
+        if (int e = need_pff()) return e;
+        if (int e = normalize_weights_now()) return e;
+        if (st->mraf_enabled && st->zero_mode) { if (int e = need_zw()) return e; }
+        if (st->mraf_enabled && st->fixed_phase && !have_pff && !p.store_phase)
+            return fail(HGS_ERR_STATE, "fixed_phase with MRAF needs a stored phase_ff (reference quirk A12)");
+        CParams<R> cp = cparams(st, p);
+        EwArgs<R> a{};
+        a.P = P; a.batch = B; a.ff = ff; a.amp_ff = aff; a.pff = pff; a.w = w; a.t = t;
+        a.fsum = sums + 0 * B; a.nogsum = sums + 1 * B; a.partial = epartial; a.wsum = nullptr; a.zero_weights = zw;
+        a.cp = cp;
+        const dim3 eg(ew_blocks, B), eb(256);
+        return timed(HGS_K_ELEMENTWISE, [&]() -> int {
+            bool pixel_update = false;
+            if (p.do_update) {
+                if (st->feedback == HGS_FB_PIXEL) {
+                    if (st->method == HGS_WGS_NOGRETTE) {
+                        hipLaunchKernelGGL(ew_nogrette_sum<R>, eg, eb, 0, stream, a);
+                        HIPCHK(hipGetLastError());
+                        if (int e = reduce(epartial, ew_blocks, sums + 1 * B)) return e;
+                    }
+                    hipLaunchKernelGGL(ew_weight_update<R>, eg, eb, 0, stream, a);
+                    HIPCHK(hipGetLastError());
+                    if (int e = reduce(epartial, ew_blocks, sums + 2 * B)) return e;
+                    pixel_update = true;
+                } else {
+                    SpotArgs<R> s{};
+                    s.g = g; s.n_spots = cfg.n_spots; s.width = st->spot_window; s.feedback = st->feedback;
+                    s.spot_xy = spot_xy; s.amp_ff = aff; s.ext_amp = ext_amp; s.spot_amp = spot_amp; s.w = w;
+                    s.fb = spot_fb; s.cp = cp;
+                    if (st->feedback == HGS_FB_SPOT_WINDOW) {
+                        hipLaunchKernelGGL(spot_window<R>, dim3((cfg.n_spots + 127) / 128, B), dim3(128), 0, stream, s);
+                        HIPCHK(hipGetLastError());
+                    }
+                    hipLaunchKernelGGL(spot_update<R>, dim3(B), dim3(256), 0, stream, s);
+                    HIPCHK(hipGetLastError());
+                }
+            }
+            a.wsum = pixel_update ? sums + 2 * B : nullptr;
+            // the rebuild recomputes and stores phase_ff whenever it is not "use_fixed"
+            hipLaunchKernelGGL(ew_rebuild<R>, eg, eb, 0, stream, a);
+            HIPCHK(hipGetLastError());
+            have_pff = true;
+            return 0;
+        });
+    }
+
+    int constraint(hgs_step* st) override {
+        if (int e = check_step(st)) return e;
+        Plan p = plan_iteration(st, nullptr);
+        return constraint_planned(st, p);
+    }
+
+    bool fused_ok(const hgs_step* st) const {
+        return !st->mraf_enabled && st->feedback == HGS_FB_PIXEL && st->method != HGS_WGS_NOGRETTE;
+    }
+
+    int iterate(hgs_step* st, int n, uint8_t* hist) override {
+        if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
+        if (n == 0) return 0;
+        if (int e = check_step(st)) return e;
+        const bool fused = fused_ok(st) && !env_int("HGS_FORCE_STEPWISE", 0);
+        if (!fused) {
+            for (int i = 0; i < n; ++i) {
+                if (int e = n2f(0)) return e;
+                Plan p = plan_iteration(st, hist ? hist + i : nullptr);
+                if (int e = constraint_planned(st, p)) return e;
+                if (int e = f2n()) return e;
+                st->iter++;
+            }
+            return 0;
+        }
+        farfield_valid = false;
+        if (int e = run_row(0, false)) return e;
+        for (int i = 0; i < n; ++i) {
+            Plan p = plan_iteration(st, hist ? hist + i : nullptr);
+            if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
+            int r = timed(HGS_K_COL_FUSED, [&]() -> int {
+                ColArgs<R> a = col_args();
+                a.cp = cparams(st, p);
+                LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
+                return 0;
+            });
+            if (r) return r;
+            if (p.store_phase) have_pff = true;
+            if (p.do_update) w_pending = true;
+            // the row kernel that follows folds the weight-norm partials into wscale
+            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0)) return e;
+            st->iter++;
+        }
+        return 0;
+    }
+
+    int iterate_timed(hgs_step* st, int n, double* ms) override {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipEventRecord(a, stream));
+        int r = iterate(st, n, nullptr);
+        HIPCHK(hipEventRecord(b, stream));
+        HIPCHK(hipEventSynchronize(b));
+        float f = 0;
+        HIPCHK(hipEventElapsedTime(&f, a, b));
+        *ms = f;
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+        return r;
+    }
+
+    // ---- statistics (_stats.py:7-116): device reductions, host finishing on a handful of doubles ----
+    static void finish_stats(const std::vector<double>& fvals, const std::vector<double>& tvals, double total,
+                             bool has_total, double* out) {
+        // host finishing for short vectors (spot groups): direct restatement on doubles
+        double sf = 0, st = 0, stf = 0;
+        const size_t n = fvals.size();
+        for (size_t i = 0; i < n; ++i) {
+            sf += fvals[i] * fvals[i];
+            if (tvals[i] == tvals[i]) st += tvals[i] * tvals[i];
+        }
+        double eff;
+        if (has_total) eff = sf / total;
+        for (size_t i = 0; i < n; ++i)
+            if (tvals[i] == tvals[i]) stf += (tvals[i] / std::sqrt(st)) * (fvals[i] / std::sqrt(sf));
+        if (!has_total) eff = stf * stf;
+        double rmin = INFINITY, rmax = -INFINITY, emin = INFINITY, emax = -INFINITY, es = 0, es2 = 0, cnt = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const double tp = tvals[i] * tvals[i] / st, fp = fvals[i] * fvals[i] / sf;
+            if (tp != 0 && tp == tp) {
+                const double ratio = fp / tp, err = tp - fp;
+                rmin = std::fmin(rmin, ratio); rmax = std::fmax(rmax, ratio);
+                emin = std::fmin(emin, err); emax = std::fmax(emax, err);
+                es += err; es2 += err * err; cnt += 1;
+            }
+        }
+        const double mean = es / cnt, var = std::fmax(0.0, es2 / cnt - mean * mean);
+        out[0] = eff;
+        out[1] = 1 - (rmax - rmin) / (rmax + rmin);
+        out[2] = cnt * (emax - emin);
+        out[3] = cnt * std::sqrt(var);
+    }
+
+    int stats(int group, int width, const double* xy, double* out) override {
+        if (!aff || !farfield_valid) return fail(HGS_ERR_STATE, "statistics need a materialised farfield");
+        const int nb = std::min(ew_blocks, 1024);
+        if (group == 0) {
+            double* d1 = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&d1), (size_t)B * nb * 7 * sizeof(double) + (size_t)B * 2 * sizeof(double)));
+            double* d_sfst = d1 + (size_t)B * nb * 7;
+            hipLaunchKernelGGL(stats_pass1<R>, dim3(nb, B), dim3(256), 0, stream, (const R*)aff, (const R*)t, P, d1);
+            HIPCHK(hipGetLastError());
+            std::vector<double> h((size_t)B * nb * 7);
+            HIPCHK(hipMemcpyAsync(h.data(), d1, (size_t)B * nb * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            std::vector<double> sfst(2 * B), stf(B);
+            for (int b = 0; b < B; ++b) {
+                double s0 = 0, s1 = 0, s2 = 0;
+                for (int i = 0; i < nb; ++i) {
+                    const double* o = &h[((size_t)b * nb + i) * 3];
+                    s0 += o[0]; s1 += o[1]; s2 += o[2];
+                }
+                sfst[2 * b] = s0; sfst[2 * b + 1] = s1; stf[b] = s2;
+            }
+            HIPCHK(hipMemcpyAsync(d_sfst, sfst.data(), 2 * B * sizeof(double), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(stats_pass2<R>, dim3(nb, B), dim3(256), 0, stream, (const R*)aff, (const R*)t, P,
+                               (const double*)d_sfst, d1);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h.data(), d1, (size_t)B * nb * 7 * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hipFree(d1);
+            for (int b = 0; b < B; ++b) {
+                double rmin = INFINITY, rmax = -INFINITY, emin = INFINITY, emax = -INFINITY, es = 0, es2 = 0, cnt = 0;
+                for (int i = 0; i < nb; ++i) {
+                    const double* o = &h[((size_t)b * nb + i) * 7];
+                    rmin = std::fmin(rmin, o[0]); rmax = std::fmax(rmax, o[1]);
+                    emin = std::fmin(emin, o[2]); emax = std::fmax(emax, o[3]);
+                    es += o[4]; es2 += o[5]; cnt += o[6];
+                }
+                const double eff = stf[b] / std::sqrt(sfst[2 * b] * sfst[2 * b + 1]);
+                const double mean = es / cnt, var = std::fmax(0.0, es2 / cnt - mean * mean);
+                out[4 * b + 0] = eff * eff;
+                out[4 * b + 1] = 1 - (rmax - rmin) / (rmax + rmin);
+                out[4 * b + 2] = cnt * (emax - emin);
+                out[4 * b + 3] = cnt * std::sqrt(var);
+            }
+            return 0;
+        }
+        if (group == 1) {
+            if (cfg.n_spots <= 0 || !xy) return fail(HGS_ERR_STATE, "spot statistics need spots");
+            const int N = cfg.n_spots;
+            // window sums at floor(spot_knm) (take() floors, quirk A18); width 1 = the pixel itself
+            std::vector<int32_t> ixy(2 * N);
+            const int flo = (int)std::floor(-(width - 1) / 2.0), fhi = flo + width - 1;
+            for (int n = 0; n < N; ++n) {
+                ixy[n] = (int32_t)std::floor(xy[n]);
+                ixy[N + n] = (int32_t)std::floor(xy[N + n]);
+                if (ixy[n] + flo < 0 || ixy[N + n] + flo < 0 || ixy[n] + fhi >= g.Pw || ixy[N + n] + fhi >= g.Ph)
+                    return fail(HGS_ERR_ARG, "integration window of spot %d leaves the grid", n);
+            }
+            int* dxy = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&dxy), 2 * N * sizeof(int)));
+            HIPCHK(hipMemcpyAsync(dxy, ixy.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice, stream));
+            SpotArgs<R> s{};
+            s.g = g; s.n_spots = N; s.width = width; s.feedback = 1; s.spot_xy = dxy; s.amp_ff = aff; s.fb = spot_fb;
+            hipLaunchKernelGGL(spot_window<R>, dim3((N + 127) / 128, B), dim3(128), 0, stream, s);
+            HIPCHK(hipGetLastError());
+            std::vector<R> fb((size_t)B * N);
+            std::vector<double> tv(N), fs(B);
+            HIPCHK(hipMemcpyAsync(fb.data(), spot_fb, (size_t)B * N * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(tv.data(), spot_amp, N * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(fs.data(), sums, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hipFree(dxy);
+            for (int b = 0; b < B; ++b) {
+                std::vector<double> fv(N);
+                for (int n = 0; n < N; ++n) fv[n] = (double)fb[(size_t)b * N + n];
+                finish_stats(fv, tv, fs[b], true, out + 4 * b);
+            }
+            return 0;
+        }
+        return fail(HGS_ERR_ARG, "unknown statistics group %d", group);
+    }
+
+    int sync() override {
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+};
+
+}  // namespace hgs
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+struct hgs_engine {
+    hgs::EngineBase* impl;
+};
+
+extern "C" {
+
+int hgs_create(const hgs_config* cfg, hgs_engine** out) {
+    if (!cfg || !out) return hgs::fail(HGS_ERR_ARG, "null argument");
+    *out = nullptr;
+    hgs::EngineBase* impl = nullptr;
+    if (cfg->real_bytes == 4) impl = new hgs::Engine<float>();
+    else if (cfg->real_bytes == 8) impl = new hgs::Engine<double>();
+    else return hgs::fail(HGS_ERR_ARG, "real_bytes must be 4 or 8 (got %d)", cfg->real_bytes);
+    int e = impl->init(*cfg);
+    if (e) {
+        delete impl;
+        return e;
+    }
+    *out = new hgs_engine{impl};
+    return 0;
+}
+
+int hgs_destroy(hgs_engine* e) {
+    if (!e) return 0;
+    delete e->impl;
+    delete e;
+    return 0;
+}
+
+#define ENG(e) \
+    if (!(e) || !(e)->impl) return hgs::fail(HGS_ERR_ARG, "null engine handle");
+
+int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes) { ENG(e) return e->impl->set_array(which, host, nbytes); }
+int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes) { ENG(e) return e->impl->get_array(which, host, nbytes, false); }
+int hgs_get_array_device(hgs_engine* e, int which, void* dev, size_t nbytes) { ENG(e) return e->impl->get_array(which, dev, nbytes, true); }
+int hgs_reset_weights(hgs_engine* e) { ENG(e) return e->impl->reset_weights(); }
+int hgs_nearfield2farfield(hgs_engine* e, int store_phase_ff) { ENG(e) return e->impl->n2f(store_phase_ff); }
+int hgs_farfield_constraint(hgs_engine* e, hgs_step* step) {
+    ENG(e)
+    if (!step) return hgs::fail(HGS_ERR_ARG, "null step");
+    return e->impl->constraint(step);
+}
+int hgs_farfield2nearfield(hgs_engine* e) { ENG(e) return e->impl->f2n(); }
+int hgs_iterate(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* hist) {
+    ENG(e)
+    if (!step) return hgs::fail(HGS_ERR_ARG, "null step");
+    return e->impl->iterate(step, n_iter, hist);
+}
+int hgs_stats(hgs_engine* e, int group, int width, const double* xy, double* out) {
+    ENG(e)
+    if (!out) return hgs::fail(HGS_ERR_ARG, "null output");
+    return e->impl->stats(group, width, xy, out);
+}
+int hgs_sync(hgs_engine* e) { ENG(e) return e->impl->sync(); }
+int hgs_profile_enable(hgs_engine* e, int on) { ENG(e) return e->impl->profile_enable(on); }
+int hgs_profile_read(hgs_engine* e, double* out) {
+    ENG(e)
+    if (!out) return hgs::fail(HGS_ERR_ARG, "null output");
+    return e->impl->profile_read(out);
+}
+int hgs_iterate_timed(hgs_engine* e, hgs_step* step, int n_iter, double* ms) {
+    ENG(e)
+    if (!step || !ms) return hgs::fail(HGS_ERR_ARG, "null argument");
+    return e->impl->iterate_timed(step, n_iter, ms);
+}
+
+const char* hgs_last_error(void) { return hgs::g_err.c_str(); }
+
+const char* hgs_version(void) {
+    static std::string v;
+    if (v.empty()) {
+        v = "hgs 0.1 gfx950";
+        int n = 0;
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, 0) == hipSuccess) v += std::string(" ") + p.name + " " + p.gcnArchName;
+        } else {
+            v += " (no device)";
+        }
+    }
+    return v.c_str();
+}
+
+}  // extern "C"

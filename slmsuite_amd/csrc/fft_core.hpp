@@ -1,0 +1,296 @@
+// In-workgroup power-of-two complex FFT for gfx950 (CDNA4), used by every transform kernel of the
+// hologram engine (replaces cp.fft.fft2 / ifft2 of the reference, _hologram.py:1048,1070).
+//
+// Design (MI355X-first, not a port of any FFT library):
+//   * One length-N transform is owned by T = N/16 lanes; lane j keeps the 16 elements
+//     x[j + m*T], m = 0..15, in VGPRs ("load layout").  For N = 4096 that is one 256-lane
+//     workgroup (4 wavefronts of 64) per transform, 32 data VGPRs per lane.
+//   * Stockham autosort, radix-16 stages (4096 = 16*16*16): butterflies run entirely in registers;
+//     between stages the partial results are scattered to LDS and re-gathered in load layout, so
+//     global loads AND global stores of the owning kernel are fully coalesced 512-B wave accesses
+//     and no bit-reversal pass exists.  The last stage needs no exchange: its outputs already sit
+//     in load layout (proved in tools/stockham_model.py).
+//   * Twiddles W_N^(r*k) are per-lane constants of a stage; they are fetched once per kernel from a
+//     table computed in double on the host and stay in VGPRs across all transforms a lane performs
+//     (forward and inverse share them: the inverse multiplies by the conjugate).
+//   * LDS image is padded by one element per 16 (pad(q) = q + q/16) which makes the radix-16
+//     scatter (stride 16 between neighbouring lanes) and the stride-1 gather conflict-free for
+//     8-byte ds_write_b64/ds_read_b64 (bank = element mod 32).
+//   * No MFMA: a radix-16 butterfly is 144 adds + a few constant rotations, bandwidth-bound work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
+
+namespace hgs {
+
+template <typename R> struct Cx { R x, y; };
+
+template <typename R> __device__ __forceinline__ Cx<R> mk(R x, R y) { Cx<R> c; c.x = x; c.y = y; return c; }
+template <typename R> __device__ __forceinline__ Cx<R> operator+(Cx<R> a, Cx<R> b) { return mk<R>(a.x + b.x, a.y + b.y); }
+template <typename R> __device__ __forceinline__ Cx<R> operator-(Cx<R> a, Cx<R> b) { return mk<R>(a.x - b.x, a.y - b.y); }
+template <typename R> __device__ __forceinline__ Cx<R> operator*(Cx<R> a, R s) { return mk<R>(a.x * s, a.y * s); }
+template <typename R> __device__ __forceinline__ Cx<R> cmul(Cx<R> a, Cx<R> b) {
+    return mk<R>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+template <typename R> __device__ __forceinline__ Cx<R> cmulc(Cx<R> a, Cx<R> b) {
+    return mk<R>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// DIR = -1 forward (e^{-i...}), +1 inverse.
+// multiply by e^{DIR * 2*pi*i * Q / 16}, Q compile-time.
+template <int Q, int DIR, typename R> __device__ __forceinline__ Cx<R> rot16(Cx<R> a) {
+    constexpr int q = ((Q % 16) + 16) % 16;
+    constexpr R C1 = (R)0.92387953251128675613;  // cos(pi/8)
+    constexpr R S1 = (R)0.38268343236508977173;  // sin(pi/8)
+    constexpr R H = (R)0.70710678118654752440;   // sqrt(1/2)
+    if constexpr (q == 0) return a;
+    else if constexpr (q == 8) return mk<R>(-a.x, -a.y);
+    else if constexpr (q == 4) return DIR < 0 ? mk<R>(a.y, -a.x) : mk<R>(-a.y, a.x);
+    else if constexpr (q == 12) return DIR < 0 ? mk<R>(-a.y, a.x) : mk<R>(a.y, -a.x);
+    else if constexpr (q % 2 == 0) {
+        // odd multiples of pi/4: (cos, sin) = (+-H, +-H)
+        constexpr R c = (q == 2 || q == 14) ? H : -H;
+        constexpr R s0 = (q == 2 || q == 6) ? H : -H;  // sin(2*pi*q/16)
+        constexpr R s = DIR < 0 ? -s0 : s0;
+        return mk<R>(a.x * c - a.y * s, a.x * s + a.y * c);
+    } else {
+        constexpr R cs[16] = {1, C1, H, S1, 0, -S1, -H, -C1, -1, -C1, -H, -S1, 0, S1, H, C1};
+        constexpr R sn[16] = {0, S1, H, C1, 1, C1, H, S1, 0, -S1, -H, -C1, -1, -C1, -H, -S1};
+        constexpr R c = cs[q];
+        constexpr R s = DIR < 0 ? -sn[q] : sn[q];
+        return mk<R>(a.x * c - a.y * s, a.x * s + a.y * c);
+    }
+}
+
+template <int DIR, typename R> __device__ __forceinline__ void dft2(Cx<R>& a, Cx<R>& b) {
+    Cx<R> t = a - b;
+    a = a + b;
+    b = t;
+}
+
+// 4-point DFT on (v0,v1,v2,v3), natural order in and out.
+template <int DIR, typename R>
+__device__ __forceinline__ void dft4(Cx<R>& v0, Cx<R>& v1, Cx<R>& v2, Cx<R>& v3) {
+    Cx<R> a0 = v0 + v2, a1 = v0 - v2, a2 = v1 + v3, a3 = rot16<4, DIR>(v1 - v3);
+    v0 = a0 + a2;
+    v1 = a1 + a3;
+    v2 = a0 - a2;
+    v3 = a1 - a3;
+}
+
+// R-point DFT, v[r] natural order in, V[p] natural order out (in place).
+template <int RADIX, int DIR, typename R> struct Dft;
+
+template <int DIR, typename R> struct Dft<2, DIR, R> {
+    static __device__ __forceinline__ void run(Cx<R> (&v)[2]) { dft2<DIR>(v[0], v[1]); }
+};
+template <int DIR, typename R> struct Dft<4, DIR, R> {
+    static __device__ __forceinline__ void run(Cx<R> (&v)[4]) { dft4<DIR>(v[0], v[1], v[2], v[3]); }
+};
+template <int DIR, typename R> struct Dft<8, DIR, R> {
+    // r = r1 + 2*r2 (r1<2, r2<4), p = 4*p1 + p2:  V[4p1+p2] = sum_r1 w2^(r1 p1) w8^(r1 p2) DFT4_r2(v[r1+2r2])[p2]
+    static __device__ __forceinline__ void run(Cx<R> (&v)[8]) {
+        dft4<DIR>(v[0], v[2], v[4], v[6]);
+        dft4<DIR>(v[1], v[3], v[5], v[7]);
+        Cx<R> t1 = rot16<2, DIR>(v[3]), t2 = rot16<4, DIR>(v[5]), t3 = rot16<6, DIR>(v[7]);
+        Cx<R> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+        v[0] = e0 + o0; v[4] = e0 - o0;
+        v[1] = e1 + t1; v[5] = e1 - t1;
+        v[2] = e2 + t2; v[6] = e2 - t2;
+        v[3] = e3 + t3; v[7] = e3 - t3;
+    }
+};
+template <int DIR, typename R> struct Dft<16, DIR, R> {
+    // r = r1 + 4*r2, p = 4*p1 + p2:
+    //   V[4p1+p2] = sum_r1 w4^(r1 p1) * [ w16^(r1 p2) * sum_r2 v[r1+4r2] w4^(r2 p2) ]
+    // TW: the stage twiddle W^(r k) = W^(r1 k) * W^(4 r2 k) is split (fewer twiddle registers):
+    // the caller pre-multiplies v[r1+4r2] by W^(4 r2 k); the common factor W^(r1 k) = bt[r1-1]
+    // of each inner 4-point transform is applied here to its outputs.
+    template <bool TW>
+    static __device__ __forceinline__ void run_tw(Cx<R> (&v)[16], const Cx<R>* bt) {
+        // step 1: DFT4 over r2 for each r1 -> t[r1][p2] stored at v[r1 + 4*p2]
+        dft4<DIR>(v[0], v[4], v[8], v[12]);
+        dft4<DIR>(v[1], v[5], v[9], v[13]);
+        dft4<DIR>(v[2], v[6], v[10], v[14]);
+        dft4<DIR>(v[3], v[7], v[11], v[15]);
+        if constexpr (TW) {
+            static_for<1, 4>([&](auto r1_) {
+                constexpr int r1 = r1_;
+                static_for<0, 4>([&](auto p2_) {
+                    constexpr int p2 = p2_;
+                    v[r1 + 4 * p2] = DIR < 0 ? cmul(v[r1 + 4 * p2], bt[r1 - 1]) : cmulc(v[r1 + 4 * p2], bt[r1 - 1]);
+                });
+            });
+        }
+        // step 2: twiddle t[r1][p2] *= w16^(r1*p2)
+        v[5] = rot16<1, DIR>(v[5]);   v[6] = rot16<2, DIR>(v[6]);   v[7] = rot16<3, DIR>(v[7]);
+        v[9] = rot16<2, DIR>(v[9]);   v[10] = rot16<4, DIR>(v[10]); v[11] = rot16<6, DIR>(v[11]);
+        v[13] = rot16<3, DIR>(v[13]); v[14] = rot16<6, DIR>(v[14]); v[15] = rot16<9, DIR>(v[15]);
+        // step 3: DFT4 over r1 for each p2 -> V[4*p1 + p2]; inputs at v[r1 + 4*p2]
+        dft4<DIR>(v[0], v[1], v[2], v[3]);      // p2 = 0 -> V[0], V[4], V[8], V[12]
+        dft4<DIR>(v[4], v[5], v[6], v[7]);      // p2 = 1 -> V[1], V[5], V[9], V[13]
+        dft4<DIR>(v[8], v[9], v[10], v[11]);    // p2 = 2
+        dft4<DIR>(v[12], v[13], v[14], v[15]);  // p2 = 3
+        // now v[p1 + 4*p2] holds V[4*p1 + p2]: transpose the 4x4 index to natural order
+        Cx<R> t;
+        t = v[1]; v[1] = v[4]; v[4] = t;
+        t = v[2]; v[2] = v[8]; v[8] = t;
+        t = v[3]; v[3] = v[12]; v[12] = t;
+        t = v[6]; v[6] = v[9]; v[9] = t;
+        t = v[7]; v[7] = v[13]; v[13] = t;
+        t = v[11]; v[11] = v[14]; v[14] = t;
+    }
+    static __device__ __forceinline__ void run(Cx<R> (&v)[16]) { run_tw<false>(v, nullptr); }
+};
+
+// ---- radix schedules ---------------------------------------------------------------------------
+template <int N> struct Sched;
+template <> struct Sched<64>   { static constexpr int S = 2; static constexpr int r[4] = {16, 4, 1, 1}; };
+template <> struct Sched<128>  { static constexpr int S = 2; static constexpr int r[4] = {16, 8, 1, 1}; };
+template <> struct Sched<256>  { static constexpr int S = 2; static constexpr int r[4] = {16, 16, 1, 1}; };
+template <> struct Sched<512>  { static constexpr int S = 3; static constexpr int r[4] = {16, 16, 2, 1}; };
+template <> struct Sched<1024> { static constexpr int S = 3; static constexpr int r[4] = {16, 16, 4, 1}; };
+template <> struct Sched<2048> { static constexpr int S = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
+template <> struct Sched<4096> { static constexpr int S = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
+template <> struct Sched<8192> { static constexpr int S = 4; static constexpr int r[4] = {16, 16, 16, 2}; };
+
+template <int N, int STAGE> constexpr int sched_ns() {  // product of radices before STAGE
+    int ns = 1;
+    for (int s = 0; s < STAGE; ++s) ns *= Sched<N>::r[s];
+    return ns;
+}
+constexpr int tw_regs(int radix) {  // twiddle registers a stage of this radix keeps per lane
+    return radix == 16 ? 6 : (16 / radix) * (radix - 1);
+}
+template <int N, int STAGE> constexpr int tw_offset() {  // first twiddle register of STAGE
+    int off = 0;
+    for (int s = 1; s < STAGE; ++s) off += tw_regs(Sched<N>::r[s]);
+    return off;
+}
+template <int N> constexpr int tw_count() { return tw_offset<N, Sched<N>::S>(); }
+
+__device__ __forceinline__ int lds_pad(int q) { return q + (q >> 4); }
+template <int N> constexpr int lds_elems() { return N + N / 16; }
+
+// ---- the workgroup FFT -----------------------------------------------------------------------------
+// Usage: WgFft<R,N> f; f.init(table, j);  ... f.template run<DIR>(v, lds, j);
+// `lds` points at this transform's private region of lds_elems<N>() complex elements.
+// All T = N/16 lanes of the transform (and every other lane of the workgroup) must call run():
+// it contains __syncthreads().
+template <typename R, int N> struct WgFft {
+    static constexpr int E = 16;
+    static constexpr int T = N / 16;
+    static constexpr int NTW = tw_count<N>() > 0 ? tw_count<N>() : 1;
+    Cx<R> tw[NTW];
+
+    // table[i] = exp(-2*pi*i*i/N), i < N  (forward sign)
+    __device__ __forceinline__ void init(const Cx<R>* __restrict__ table, int j) {
+        static_for<1, Sched<N>::S>([&](auto s_) {
+            constexpr int s = s_;
+            constexpr int RAD = Sched<N>::r[s];
+            constexpr int B = E / RAD;
+            constexpr int NS = sched_ns<N, s>();
+            constexpr int OFF = tw_offset<N, s>();
+            constexpr int STEP = N / (NS * RAD);
+            if constexpr (RAD == 16) {
+                // split form: tw[OFF+q-1] = W^(4 q k) (pre-twiddles), tw[OFF+3+q-1] = W^(q k), q = 1..3
+                const int k = j % NS;
+                static_for<1, 4>([&](auto q_) {
+                    constexpr int q = q_;
+                    tw[OFF + q - 1] = table[(4 * q * k * STEP) & (N - 1)];
+                    tw[OFF + 3 + q - 1] = table[(q * k * STEP) & (N - 1)];
+                });
+            } else {
+                static_for<0, B>([&](auto b_) {
+                    constexpr int b = b_;
+                    const int k = (j + b * T) % NS;
+                    static_for<1, RAD>([&](auto r_) {
+                        constexpr int r = r_;
+                        tw[OFF + b * (RAD - 1) + (r - 1)] = table[(r * k * STEP) & (N - 1)];
+                    });
+                });
+            }
+        });
+    }
+
+    // LDS position of logical element q of the current exchange, relative to a padded base:
+    // pad(base + d) == pad(base) + d + d/16 whenever d % 16 == 0 or (base % 16 == 0 and d < 16),
+    // which lets every ds_write/ds_read of a stage use one address VGPR + immediate offsets.
+    template <int DIR, int s> __device__ __forceinline__ void stage(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+        constexpr int RAD = Sched<N>::r[s];
+        constexpr int B = E / RAD;
+        constexpr int NS = sched_ns<N, s>();
+        constexpr int OFF = tw_offset<N, s>();
+        static_for<0, B>([&](auto b_) {
+            constexpr int b = b_;
+            Cx<R> u[RAD];
+            static_for<0, RAD>([&](auto r_) { constexpr int r = r_; u[r] = v[b + r * B]; });
+            if constexpr (RAD == 16 && s > 0) {
+                static_for<1, 4>([&](auto r2_) {
+                    constexpr int r2 = r2_;
+                    static_for<0, 4>([&](auto r1_) {
+                        constexpr int r = r1_ + 4 * r2;
+                        u[r] = DIR < 0 ? cmul(u[r], tw[OFF + r2 - 1]) : cmulc(u[r], tw[OFF + r2 - 1]);
+                    });
+                });
+                Dft<16, DIR, R>::template run_tw<true>(u, &tw[OFF + 3]);
+            } else {
+                if constexpr (s > 0) {
+                    static_for<1, RAD>([&](auto r_) {
+                        constexpr int r = r_;
+                        const Cx<R> w = tw[OFF + b * (RAD - 1) + (r - 1)];
+                        u[r] = DIR < 0 ? cmul(u[r], w) : cmulc(u[r], w);
+                    });
+                }
+                Dft<RAD, DIR, R>::run(u);
+            }
+            if constexpr (s == Sched<N>::S - 1) {
+                static_for<0, RAD>([&](auto r_) { constexpr int r = r_; v[b + r * B] = u[r]; });
+            } else {
+                const int jv = j + b * T;
+                const int k = jv % NS;
+                const int base = (jv / NS) * (NS * RAD) + k;
+                if constexpr (NS % 16 == 0 || (NS == 1 && RAD == 16)) {
+                    Cx<R>* p = lds + lds_pad(base);
+                    static_for<0, RAD>([&](auto r_) {
+                        constexpr int r = r_;
+                        p[r * NS + (r * NS) / 16] = u[r];
+                    });
+                } else {
+                    static_for<0, RAD>([&](auto r_) {
+                        constexpr int r = r_;
+                        lds[lds_pad(base + r * NS)] = u[r];
+                    });
+                }
+            }
+        });
+        if constexpr (s != Sched<N>::S - 1) {
+            __syncthreads();
+            if constexpr (T % 16 == 0) {
+                const Cx<R>* p = lds + lds_pad(j);
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = p[m * (T + T / 16)]; });
+            } else {
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = lds[lds_pad(j + m * T)]; });
+            }
+            __syncthreads();
+        }
+    }
+
+    template <int DIR> __device__ __forceinline__ void run(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+        static_for<0, Sched<N>::S>([&](auto s_) {
+            constexpr int s = s_;
+            this->template stage<DIR, s>(v, lds, j);
+        });
+    }
+};
+
+}  // namespace hgs

@@ -1,0 +1,774 @@
+// Device kernels of the hologram engine (gfx950).  See DESIGN.md for the data layout and roofline
+// of each kernel.  Reference semantics cited per kernel (paths relative to the slmsuite checkout).
+//
+// Layouts in HBM (per hologram b of the batch; R = real type, C = complex of R):
+//   phase / amp / kernel : [Sh][Sw] R, natural (the reference's arrays).
+//   GH  : the half-transformed field, ONLY the Sh SLM rows (all other rows of the zero-padded
+//         nearfield are zero, so their row transforms are never computed or stored):
+//         tile-of-4-columns layout  GH[ct][r][c4],  kx = 4*ct + c4   (C, Sh*Pw elements)
+//         -> the column kernel reads/writes one contiguous Sh*32-byte block per tile,
+//            the row kernel touches 32-byte pieces that adjacent rows complete to full lines.
+//   weights / target / phase_ff / farfield / amp_ff : COLUMN-major [kx][ky] (P elements), so the
+//         column kernels stream them fully coalesced.  hgs_set_array/hgs_get_array transpose.
+//
+// Centred transforms (fftshift . fft2 . fftshift with norm="ortho", _hologram.py:1048) are folded
+// into sign flips: C[k'] = N^-1/2 (-1)^k' FFT[(-1)^j' x[j']]  (valid for N % 4 == 0), so no shift
+// pass and no index rotation exists; arrays always hold the reference's centred values.
+#pragma once
+#include "fft_core.hpp"
+
+// minimum waves per SIMD the transform kernels are register-allocated for (tunable at build time)
+#ifndef HGS_ROW_OCC
+#define HGS_ROW_OCC 3
+#endif
+#ifndef HGS_COL_OCC
+#define HGS_COL_OCC 3
+#endif
+
+namespace hgs {
+
+struct Geo {
+    int Ph, Pw, Sh, Sw, r0, c0, batch;
+};
+
+// method codes follow ALGORITHM_INDEX (_header.py:72)
+enum { M_GS = 0, M_LEONARDO = 1, M_KIM = 2, M_NOGRETTE = 3, M_WU = 4, M_TANH = 5 };
+
+template <typename R> struct CParams {
+    int method;
+    int do_update;    // WGS and iter > 0 (_hologram.py:1552)
+    int use_fixed;    // rebuild with stored phase_ff (Kim fixed phase, :1601)
+    int store_phase;  // write phase_ff = atan2(F) (:1583, :1602)
+    int mraf;         // target holds NaN (noise) / 0 (zero) regions (:1606-1653)
+    int has_mraf_factor;
+    int zero_mode;    // 0: zero region := 0 ; 1: zero_weights feedback (:1613-1616)
+    R p_exp, p_fac, mraf_factor, zero_factor;
+    R inv_fnorm;      // 1/||amp_ff||, used when fnorm_ptr == nullptr (Parseval constant)
+};
+
+// sin/cos for the bounded arguments of this engine (|phase + kernel| of a few thousand radians at
+// most): 3-term Cody-Waite reduction by pi/2 + minimax polynomials on [-pi/4, pi/4]; <= ~1.5 ulp,
+// ~25 VALU ops and no large-argument slow path (ocml's sincosf carries a Payne-Hanek branch that
+// costs >100 VGPRs when 16 of them are unrolled).  Arguments beyond 2^13 take the ocml path.
+__device__ __forceinline__ void sincos_bounded(float x, float* s, float* c) {
+    if (__builtin_expect(fabsf(x) > 8192.0f, 0)) {
+        sincosf(x, s, c);
+        return;
+    }
+    const float q = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-q, 1.5703125f, x);
+    r = fmaf(-q, 4.837512969970703125e-4f, r);
+    r = fmaf(-q, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                          z * z, fmaf(-0.5f, z, 1.0f));
+    const int n = (int)q;
+    const float ss = (n & 1) ? pc : ps;
+    const float cc = (n & 1) ? ps : pc;
+    *s = (n & 2) ? -ss : ss;
+    *c = ((n + 1) & 2) ? -cc : cc;
+}
+
+template <typename R> struct Math;
+template <> struct Math<float> {
+    static __device__ __forceinline__ void sincos(float a, float* s, float* c) { sincos_bounded(a, s, c); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
+    static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
+    static __device__ __forceinline__ float powneg(float x, float p) { return exp2f(-p * log2f(x)); }
+    static __device__ __forceinline__ float exp(float x) { return expf(x); }
+    static __device__ __forceinline__ float tanh(float x) { return tanhf(x); }
+    static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+};
+template <> struct Math<double> {
+    static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double powneg(double x, double p) { return ::pow(x, -p); }
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
+    static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
+};
+
+template <typename R> __device__ __forceinline__ bool is_nan(R x) { return x != x; }
+template <typename R> __device__ __forceinline__ bool is_pinf(R x) { return x == (R)INFINITY; }
+
+// ---- block reduction of a double (sum) into partial[slot]; all lanes call ---------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// scratch: at least 16 doubles of LDS not in use by anyone else at the call
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x < 64) {
+        t = (lane < nw) ? scratch[lane] : 0.0;
+        t = wave_sum(t);
+    }
+    return t;  // valid in thread 0
+}
+
+// ---- the WGS weight rule for one element (rows 9-10; _hologram.py:1830-1873) -------------------------
+//   fb  : feedback amplitude already divided by its L2 norm
+//   returns the multiplicative factor fc
+template <typename R>
+__device__ __forceinline__ R weight_factor(int method, R fb, R t, R p_exp, R p_fac, R nog_neg_inv_mean) {
+    using M = Math<R>;
+    R fc;
+    if (method == M_WU || method == M_TANH) {
+        fc = fb * (-p_exp) + t;                       // :1834-1835
+        if (method == M_WU) fc = M::exp(p_exp * fc);  // :1857
+        else fc = p_fac * M::tanh(p_exp * fc) + (R)1; // :1859-1860
+    } else {
+        fc = fb / t;                                  // :1837
+        if (is_pinf(fc)) fc = 1;                      // :1840
+        if (t == (R)0) fc = 1;                        // :1841
+        if (is_nan(fc)) fc = 1;                       // :1843
+        if (method == M_NOGRETTE) {                   // :1851-1855
+            fc = fc * nog_neg_inv_mean + (R)1;
+            fc = fc * (-p_fac) + (R)1;
+            fc = (R)1 / fc;
+        } else {
+            fc = M::powneg(fc, p_exp);                // :1848
+        }
+    }
+    if (is_pinf(fc)) fc = 1;                          // :1867
+    return fc;
+}
+
+// =====================================================================================================
+// ROW kernels: transforms along x over the Sh SLM rows.
+//   MODE 0 : phase -> G            (_build_nearfield :1000 + row half of fft2 :1048)
+//   MODE 1 : H -> phase            (row half of ifft2 :1070 + _nearfield_extract :1026)
+//   MODE 2 : H -> phase -> G       (MODE 1 then MODE 0 of the next iteration, fused: the row never
+//                                   leaves the CU between the two iterations)
+// grid = (<= ceil(Sh / FPW), batch), block = WG;  FPW = WG / T rows per workgroup pass; a workgroup
+// strides over rows so the per-lane twiddle registers are fetched once per kernel.
+// =====================================================================================================
+template <int N> struct RowCfg {
+    static constexpr int T = N / 16;
+    static constexpr int WG = T >= 256 ? T : 256;
+    static constexpr int FPW = WG / T;
+};
+
+template <typename R> struct RowArgs {
+    Geo g;
+    R* phase;            // [b][Sh][Sw]
+    const R* amp;        // [Sh][Sw] or nullptr (shared by the batch)
+    const R* kern;       // [Sh][Sw] or nullptr
+    R amp_scalar;
+    Cx<R>* gh;           // [b][Pw/4][Sh][4]
+    const Cx<R>* tw;     // W_Pw table
+    R scale;             // 1/sqrt(Pw)
+    // weight-norm finalisation carried by block (0, b): wscale[b] = 1/sqrt(sum partial[b][:])
+    const double* wpartial;
+    int n_wpartial;
+    R* wscale;
+};
+
+template <typename R, int N, int MODE>
+__global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs<R> a) {
+    using M = Math<R>;
+    constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo g = a.g;
+    const int tid = threadIdx.x;
+    const int f = tid / T, j = tid % T;
+    const int b = blockIdx.y;
+    Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + f * lds_elems<N>();
+
+    // deferred weight normalisation: one block per hologram folds the partial sums of the last
+    // weight update into the scalar every later reader multiplies by (_hologram.py:1877).
+    if (a.wpartial != nullptr && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = tid; i < a.n_wpartial; i += blockDim.x) s += a.wpartial[(size_t)b * a.n_wpartial + i];
+        double* scratch = reinterpret_cast<double*>(smem);
+        s = block_sum(s, scratch);
+        if (tid == 0) a.wscale[b] = (R)(1.0 / ::sqrt(s));
+        __syncthreads();
+    }
+
+    WgFft<R, N> fft;
+    fft.init(a.tw, j);
+
+    const R sgn = (j & 1) ? (R)-1 : (R)1;  // (-1)^(j + m*T), T even
+    // GH element (r, k = j + m*T) sits at ((k>>2)*Sh + r)*4 + (k&3) = lane part + m * (T*Sh)
+    Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw;
+    const unsigned gh_lane = (unsigned)(j >> 2) * g.Sh * 4u + (unsigned)(j & 3);
+    const unsigned gh_step = (unsigned)T * g.Sh;
+    const int c_lane = j - g.c0;   // SLM column of element m is c_lane + m*T
+
+#pragma unroll 1
+    for (int rbase = blockIdx.x * FPW; rbase < g.Sh; rbase += gridDim.x * FPW) {
+        const int r = rbase + f;
+        const bool valid = r < g.Sh;
+        const int rr = valid ? r : 0;
+        Cx<R> v[16];
+        const size_t srow = (size_t)rr * g.Sw;
+        R* ph = a.phase + (size_t)b * g.Sh * g.Sw + srow;
+        const R* kn = a.kern ? a.kern + srow : nullptr;
+        const R* am = a.amp ? a.amp + srow : nullptr;
+        Cx<R>* ghr = gh + (size_t)rr * 4;
+
+        if constexpr (MODE != 0) {
+            // ---- load H row, centred inverse transform along x ----
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                Cx<R> h = mk<R>(0, 0);
+                if (valid) h = (ghr + (size_t)m * gh_step)[gh_lane];
+                v[m] = h * sgn;
+            });
+            fft.template run<+1>(v, lds, j);
+            const R sc = sgn * a.scale;
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                const int c = c_lane + m * T;
+                if (valid && c >= 0 && c < g.Sw) {
+                    // nf = sgn * scale * v;  _nearfield_extract :1030, :1036
+                    R p = M::atan2(v[m].y * sc, v[m].x * sc);
+                    if (kn != nullptr) p -= kn[c];
+                    ph[c] = p;
+                    v[m].x = p;  // keep for the fused rebuild
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if constexpr (MODE != 1) {
+            // ---- build the nearfield row (amp * exp(i(phase+kernel)), zero padded), transform ----
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                const int c = c_lane + m * T;
+                Cx<R> nf = mk<R>(0, 0);
+                if (valid && c >= 0 && c < g.Sw) {
+                    R p = (MODE == 2) ? v[m].x : ph[c];
+                    if (kn != nullptr) p += kn[c];
+                    R s, co;
+                    M::sincos(p, &s, &co);
+                    const R amv = ((am != nullptr) ? am[c] : a.amp_scalar) * sgn;
+                    nf = mk<R>(amv * co, amv * s);
+                }
+                v[m] = nf;
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fft.template run<-1>(v, lds, j);
+            if (valid) {
+                const R sc = sgn * a.scale;
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
+                });
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// COLUMN kernel: transforms along y for a tile of 4 adjacent columns.
+//   FWD   : G -> F            (column half of fft2, zero rows outside the SLM are never read)
+//   STORE : write F, |F| (and optionally atan2 F) to the column-major farfield arrays
+//           (_midloop_cleaning :953, _populate_results :948-949) + sum |F|^2 partial
+//   CONS  : farfield constraint + weight update inline (_gs_farfield_routines :1550-1605,
+//           _update_weights_generic :1822-1879), pixel feedback, no MRAF
+//   LOAD  : read the (already constrained) farfield array instead
+//   INV   : F -> H            (column half of ifft2; only the Sh SLM rows are produced)
+// grid = (<= Pw/4, batch), block = T*CPAR; a workgroup strides over tiles, the 4 columns of a tile
+// run CPAR at a time.
+// =====================================================================================================
+enum { C_FWD = 1, C_STORE = 2, C_CONS = 4, C_LOAD = 8, C_INV = 16 };
+
+template <int N> struct ColCfg {
+    static constexpr int T = N / 16;
+    static constexpr int CPAR = T >= 256 ? 1 : (256 / T > 4 ? 4 : 256 / T);
+    static constexpr int WG = T * CPAR;
+    static constexpr int PASSES = 4 / CPAR;
+};
+
+template <typename R> struct ColArgs {
+    Geo g;
+    Cx<R>* gh;
+    Cx<R>* ff;        // column-major farfield (STORE / LOAD) or nullptr
+    R* amp_ff;        // column-major (STORE) or nullptr
+    R* pff;           // column-major phase_ff or nullptr
+    R* w;             // column-major weights
+    const R* t;       // column-major target
+    const R* wscale;  // [batch] pending 1/||w||
+    double* wpartial; // [batch][gridDim.x] sum w'^2 (CONS with do_update)
+    double* fpartial; // [batch][gridDim.x] sum |F|^2 (STORE)
+    const Cx<R>* tw;  // W_Ph table
+    R scale;          // 1/sqrt(Ph)
+    int store_pff;    // STORE: also write phase_ff
+    CParams<R> cp;
+};
+
+template <typename R, int N, int MODE>
+__global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs<R> a) {
+    using M = Math<R>;
+    constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo g = a.g;
+    const int tid = threadIdx.x;
+    const int cpar = tid / T, j = tid % T;
+    const int b = blockIdx.y;
+    Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
+    double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
+
+    WgFft<R, N> fft;
+    fft.init(a.tw, j);
+    const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const size_t P = (size_t)g.Ph * g.Pw;
+    const R wsc = (MODE & C_CONS) ? a.wscale[b] : (R)1;
+    const R sc = sgn * a.scale;
+    double acc_w = 0, acc_f = 0;
+    const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
+
+#pragma unroll 1
+    for (int ct = blockIdx.x; ct < g.Pw / 4; ct += gridDim.x) {
+        Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+#pragma unroll 1
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int c4 = pass * CPAR + cpar;
+            const int kx = ct * 4 + c4;
+            const size_t cb = (size_t)b * P + (size_t)kx * g.Ph;   // column base in the P arrays
+            Cx<R> v[16];
+            if constexpr (MODE & C_FWD) {
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const int r = r_lane + m * T;
+                    Cx<R> x = mk<R>(0, 0);
+                    if (r >= 0 && r < g.Sh) x = gh[(unsigned)r * 4u + (unsigned)c4];
+                    v[m] = x * sgn;
+                });
+                fft.template run<-1>(v, lds, j);
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sc; });
+            }
+            if constexpr (MODE & C_STORE) {
+                Cx<R>* ffc = a.ff + cb;
+                R* afc = a.amp_ff + cb;
+                R* pfc = a.pff ? a.pff + cb : nullptr;
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const unsigned idx = (unsigned)(j + m * T);
+                    const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
+                    ffc[idx] = v[m];
+                    afc[idx] = M::sqrt(p2);
+                    if (a.store_pff) pfc[idx] = M::atan2(v[m].y, v[m].x);
+                    acc_f += (double)p2;
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            if constexpr (MODE & C_CONS) {
+                const CParams<R> cp = a.cp;
+                R* wc = a.w + cb;
+                const R* tc = a.t + cb;
+                R* pfc = a.pff ? a.pff + cb : nullptr;
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const unsigned idx = (unsigned)(j + m * T);
+                    const Cx<R> F = v[m];
+                    R wv = wc[idx] * wsc;
+                    const R p2 = F.x * F.x + F.y * F.y;
+                    if (cp.do_update) {
+                        const R t = tc[idx];
+                        const R fb = M::sqrt(p2) * cp.inv_fnorm;
+                        const R fc = weight_factor<R>(cp.method, fb, t, cp.p_exp, cp.p_fac, (R)0);
+                        wv = wv * fc;
+                        if (is_nan(wv)) wv = (R)0.0001;   // :1873
+                        wc[idx] = wv;
+                        acc_w += (double)wv * (double)wv;
+                    }
+                    R co, si;
+                    if (cp.use_fixed) {
+                        M::sincos(pfc[idx], &si, &co);
+                    } else {
+                        // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 -> 1  (quirk A6)
+                        if (p2 > (R)0) {
+                            const R inv = M::rsqrt(p2);
+                            co = F.x * inv;
+                            si = F.y * inv;
+                        } else {
+                            co = 1;
+                            si = 0;
+                        }
+                        if (cp.store_phase) pfc[idx] = M::atan2(F.y, F.x);
+                    }
+                    v[m] = mk<R>(wv * co, wv * si);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            if constexpr (MODE & C_LOAD) {
+                const Cx<R>* ffc = a.ff + cb;
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = ffc[(unsigned)(j + m * T)]; });
+            }
+            if constexpr (MODE & C_INV) {
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgn; });
+                fft.template run<+1>(v, lds, j);
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const int r = r_lane + m * T;
+                    if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u + (unsigned)c4] = v[m] * sc;
+                });
+            }
+        }
+    }
+    if constexpr (MODE & C_CONS) {
+        if (a.cp.do_update) {
+            const double s = block_sum(acc_w, scratch);
+            if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
+        }
+    }
+    if constexpr (MODE & C_STORE) {
+        const double s = block_sum(acc_f, scratch);
+        if (tid == 0) a.fpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// =====================================================================================================
+// Elementwise kernels of the general (stepwise) path over column-major P-sized arrays.
+// =====================================================================================================
+template <typename R> struct EwArgs {
+    size_t P;          // elements per hologram
+    int batch;
+    Cx<R>* ff;
+    R* amp_ff;
+    R* pff;
+    R* w;
+    const R* t;
+    const double* fsum;   // [batch] sum |F|^2 (nansum)       -> 1/||F||
+    const double* nogsum; // [batch] sum fc (Nogrette)
+    double* partial;      // [batch][gridDim.x] output partial sums
+    const double* wsum;   // [batch] sum w'^2                  -> 1/||w'||
+    Cx<R>* zero_weights;  // [batch][P] sparse-as-dense accumulator for zero_factor, or nullptr
+    CParams<R> cp;
+};
+
+// Nogrette needs nanmean(fc) over the whole array before the update (:1851, quirk A9).
+template <typename R> __global__ void ew_nogrette_sum(EwArgs<R> a) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.y;
+    const R inv_fn = (R)(1.0 / ::sqrt(a.fsum[b]));
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.P; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = (size_t)b * a.P + i;
+        const R t = a.t[idx];
+        R fc = a.amp_ff[idx] * inv_fn / t;
+        if (is_pinf(fc)) fc = 1;
+        if (t == (R)0) fc = 1;
+        if (is_nan(fc)) fc = 1;
+        acc += (double)fc;
+    }
+    const double s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) a.partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+}
+
+// w' = nanfix(w * fc)  (un-normalised) + partial sum of w'^2.
+template <typename R> __global__ void ew_weight_update(EwArgs<R> a) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.y;
+    const R inv_fn = (R)(1.0 / ::sqrt(a.fsum[b]));
+    R nog = 0;
+    if (a.cp.method == M_NOGRETTE) nog = (R)(-(1.0 / (a.nogsum[b] / (double)a.P)));
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.P; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = (size_t)b * a.P + i;
+        const R fc = weight_factor<R>(a.cp.method, a.amp_ff[idx] * inv_fn, a.t[idx], a.cp.p_exp, a.cp.p_fac, nog);
+        R wv = a.w[idx] * fc;
+        if (is_nan(wv)) wv = (R)0.0001;
+        a.w[idx] = wv;
+        acc += (double)wv * (double)wv;
+    }
+    const double s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) a.partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+}
+
+// Normalise weights (if an update happened) and rebuild the farfield (:1590-1653).
+template <typename R> __global__ void ew_rebuild(EwArgs<R> a) {
+    using M = Math<R>;
+    const int b = blockIdx.y;
+    const CParams<R> cp = a.cp;
+    const R wsc = (a.wsum != nullptr) ? (R)(1.0 / ::sqrt(a.wsum[b])) : (R)1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.P; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = (size_t)b * a.P + i;
+        Cx<R> F = a.ff[idx];
+        R wv = a.w[idx];
+        if (a.wsum != nullptr) {
+            wv *= wsc;
+            a.w[idx] = wv;
+        }
+        bool signal = true, noise = false;
+        if (cp.mraf) {
+            const R t = a.t[idx];
+            noise = is_nan(t);
+            const bool zero = (!noise) && (M::abs(t) == (R)0);
+            signal = !(noise || zero);
+            if (zero) {
+                if (cp.zero_mode) {  // :1613-1616
+                    Cx<R> zw = a.zero_weights[idx];
+                    const R mag = M::sqrt(F.x * F.x + F.y * F.y) * cp.zero_factor;
+                    zw.x -= mag * F.x;
+                    zw.y -= mag * F.y;
+                    a.zero_weights[idx] = zw;
+                    F = zw;
+                } else {
+                    F = mk<R>(0, 0);
+                }
+            }
+        }
+        R p;
+        if (cp.use_fixed) {
+            p = a.pff[idx];
+        } else {
+            p = M::atan2(F.y, F.x);
+            a.pff[idx] = p;
+        }
+        if (signal) {
+            R s, c;
+            M::sincos(p, &s, &c);
+            F = mk<R>(wv * c, wv * s);
+        } else if (noise && cp.has_mraf_factor) {
+            F = F * cp.mraf_factor;
+        }
+        a.ff[idx] = F;
+    }
+}
+
+// phase_ff = atan2(F) only (Kim transition with MRAF-free stepwise mode, :1583)
+template <typename R> __global__ void ew_store_phase(EwArgs<R> a) {
+    using M = Math<R>;
+    const int b = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.P; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = (size_t)b * a.P + i;
+        const Cx<R> F = a.ff[idx];
+        a.pff[idx] = M::atan2(F.y, F.x);
+    }
+}
+
+// ---- tiny helpers -------------------------------------------------------------------------------------
+// out[b] = sum_i partial[b][i]
+static __global__ void reduce_partials(const double* partial, int n, double* out) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.x;
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[(size_t)b * n + i];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[b] = s;
+}
+
+template <typename R> __global__ void set_scalar(R* p, int n, R v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// wscale[b] = 1/sqrt(sum[b])
+template <typename R> __global__ void scale_from_sum(const double* sum, R* wscale, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wscale[i] = (R)(1.0 / ::sqrt(sum[i]));
+}
+
+// Tiled transpose between the host-facing natural [rows][cols] layout and the engine's
+// column-major layout, with an optional per-hologram scale (pending weight normalisation).
+template <typename E, typename R>
+__global__ void transpose_scale(const E* __restrict__ in, E* __restrict__ out, int rows, int cols,
+                                const R* scale) {
+    __shared__ E tile[32][33];
+    const int b = blockIdx.z;
+    const size_t off = (size_t)b * rows * cols;
+    const R s = scale ? scale[b] : (R)1;
+    int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y)
+        if (x < cols && y0 + i < rows) tile[i][threadIdx.x] = in[off + (size_t)(y0 + i) * cols + x];
+    __syncthreads();
+    x = blockIdx.y * 32 + threadIdx.x;
+    y0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y)
+        if (x < rows && y0 + i < cols) {
+            E v = tile[threadIdx.x][i];
+            if (scale) v = v * s;
+            out[off + (size_t)(y0 + i) * rows + x] = v;
+        }
+}
+
+// ---- spot-window feedback (SpotHologram._update_weights "computational_spot", _spots.py:1590-1624) ----
+template <typename R> struct SpotArgs {
+    Geo g;
+    int n_spots, width, feedback;   // feedback: 1 = window sums of amp_ff^2, 2 = external amplitudes
+    const int* spot_xy;             // [2][N] rounded (kx row 0, ky row 1), shared by the batch
+    const R* amp_ff;                // column-major
+    const double* ext_amp;          // [N] external_spot_amp (feedback 2)
+    const double* spot_amp;         // [N] target amplitudes (un-normalised list, quirk A17)
+    R* w;                           // column-major weights (normalised storage)
+    R* fb;                          // [batch][N] scratch: feedback amplitudes
+    CParams<R> cp;
+};
+
+// fb[n] = sqrt( sum_{w x w window at floor(v)} amp_ff^2 ) in float64 (analysis.take, quirk A18)
+template <typename R> __global__ void spot_window(SpotArgs<R> a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= a.n_spots) return;
+    const size_t P = (size_t)a.g.Ph * a.g.Pw;
+    const int kx = a.spot_xy[n], ky = a.spot_xy[a.n_spots + n];
+    const int lo = -((a.width - 1) / 2) - (((a.width - 1) & 1) ? 1 : 0);  // floor(-(w-1)/2)
+    double s = 0;
+    for (int dy = 0; dy < a.width; ++dy)
+        for (int dx = 0; dx < a.width; ++dx) {
+            const int x = kx + lo + dx, y = ky + lo + dy;
+            const R v = a.amp_ff[(size_t)b * P + (size_t)x * a.g.Ph + y];
+            const R v2 = v * v;  // cp.square in working precision, then astype(float) (:1592, take :202)
+            s += (double)v2;
+        }
+    a.fb[(size_t)b * a.n_spots + n] = (R)::sqrt(s);
+}
+
+// One block per hologram: N-vector weight update with target = spot_amp, normalised as an N-vector
+// and written back into the P-array (quirk A17).
+template <typename R> __global__ void spot_update(SpotArgs<R> a) {
+    __shared__ double scratch[16];
+    __shared__ double bc;
+    const int b = blockIdx.x;
+    const size_t P = (size_t)a.g.Ph * a.g.Pw;
+    const int N = a.n_spots;
+    // ||feedback||
+    double acc = 0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const R f = (a.feedback == 2) ? (R)a.ext_amp[n] : a.fb[(size_t)b * N + n];
+        if (!is_nan(f)) acc += (double)(f * f);
+    }
+    double s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) bc = s;
+    __syncthreads();
+    const R inv_fn = (R)1 / (R)::sqrt(bc);
+    __syncthreads();
+    R nog = 0;
+    if (a.cp.method == M_NOGRETTE) {
+        acc = 0;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            const R f = (a.feedback == 2) ? (R)a.ext_amp[n] : a.fb[(size_t)b * N + n];
+            const R t = (R)a.spot_amp[n];
+            R fc = f * inv_fn / t;
+            if (is_pinf(fc)) fc = 1;
+            if (t == (R)0) fc = 1;
+            if (is_nan(fc)) fc = 1;
+            acc += (double)fc;
+        }
+        s = block_sum(acc, scratch);
+        if (threadIdx.x == 0) bc = s;
+        __syncthreads();
+        nog = (R)(-(1.0 / (bc / (double)N)));
+        __syncthreads();
+    }
+    acc = 0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int kx = a.spot_xy[n], ky = a.spot_xy[N + n];
+        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + ky;
+        const R f = (a.feedback == 2) ? (R)a.ext_amp[n] : a.fb[(size_t)b * N + n];
+        const R fc = weight_factor<R>(a.cp.method, f * inv_fn, (R)a.spot_amp[n], a.cp.p_exp, a.cp.p_fac, nog);
+        R wv = a.w[idx] * fc;
+        if (is_nan(wv)) wv = (R)0.0001;
+        a.w[idx] = wv;
+        acc += (double)wv * (double)wv;
+    }
+    s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) bc = s;
+    __syncthreads();
+    const R wsc = (R)1 / (R)::sqrt(bc);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int kx = a.spot_xy[n], ky = a.spot_xy[N + n];
+        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + ky;
+        a.w[idx] *= wsc;
+    }
+}
+
+
+template <typename R> __global__ void scale_weights_kernel(R* w, const R* wscale, size_t P) {
+    const int b = blockIdx.y;
+    const R s = wscale[b];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x)
+        w[(size_t)b * P + i] *= s;
+}
+
+// Hologram.reset_weights (_hologram.py:603-614): weights = target, NaN -> 0; zero_weights cleared
+template <typename R> __global__ void reset_weights_kernel(R* w, const R* t, Cx<R>* zw, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const R v = t[i];
+        w[i] = (v != v) ? (R)0 : v;
+        if (zw) zw[i] = mk<R>(0, 0);
+    }
+}
+
+// ---- statistics (_stats.py:7-116), device part ---------------------------------------------------------
+// pass 1 over (feedback, target): sum f^2, nansum t^2, nansum t*f
+template <typename R> __global__ void stats_pass1(const R* f, const R* t, size_t n, double* out) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.y;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double fv = (double)f[(size_t)b * n + i], tv = (double)t[(size_t)b * n + i];
+        a0 += fv * fv;
+        if (tv == tv) {
+            a1 += tv * tv;
+            if (fv == fv) a2 += tv * fv;
+        }
+    }
+    const double s0 = block_sum(a0, scratch), s1 = block_sum(a1, scratch), s2 = block_sum(a2, scratch);
+    if (threadIdx.x == 0) {
+        double* o = out + ((size_t)b * gridDim.x + blockIdx.x) * 3;
+        o[0] = s0;
+        o[1] = s1;
+        o[2] = s2;
+    }
+}
+// pass 2 over the mask (t != 0, not NaN): ratio = (f^2/Sf)/(t^2/St): min, max; err = t^2/St - f^2/Sf:
+// min, max, sum, sum of squares, count
+template <typename R>
+__global__ void stats_pass2(const R* f, const R* t, size_t n, const double* sf_st, double* out) {
+    __shared__ double red[7][16];
+    const int b = blockIdx.y;
+    const double isf = 1.0 / sf_st[2 * b], ist = 1.0 / sf_st[2 * b + 1];
+    double rmin = INFINITY, rmax = -INFINITY, emin = INFINITY, emax = -INFINITY, es = 0, es2 = 0, cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double fv = (double)f[(size_t)b * n + i], tv = (double)t[(size_t)b * n + i];
+        if (tv == tv && tv != 0.0) {
+            const double fp = fv * fv * isf, tp = tv * tv * ist;
+            if (tp != 0.0) {
+                const double ratio = fp / tp, err = tp - fp;
+                rmin = fmin(rmin, ratio);
+                rmax = fmax(rmax, ratio);
+                emin = fmin(emin, err);
+                emax = fmax(emax, err);
+                es += err;
+                es2 += err * err;
+                cnt += 1;
+            }
+        }
+    }
+    double vals[7] = {rmin, rmax, emin, emax, es, es2, cnt};
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = 0; k < 7; ++k) {
+        double v = vals[k];
+        for (int o = 32; o > 0; o >>= 1) {
+            const double u = __shfl_down(v, o, 64);
+            v = (k == 0 || k == 2) ? fmin(v, u) : (k == 1 || k == 3) ? fmax(v, u) : v + u;
+        }
+        if (lane == 0) red[k][wid] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = out + ((size_t)b * gridDim.x + blockIdx.x) * 7;
+        for (int k = 0; k < 7; ++k) {
+            double v = red[k][0];
+            for (int i = 1; i < nw; ++i)
+                v = (k == 0 || k == 2) ? fmin(v, red[k][i]) : (k == 1 || k == 3) ? fmax(v, red[k][i]) : v + red[k][i];
+            o[k] = v;
+        }
+    }
+}
+
+}  // namespace hgs

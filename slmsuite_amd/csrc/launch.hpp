@@ -1,0 +1,17 @@
+// Launch front-ends for the heavy templated kernels.  The instantiations live in their own
+// translation units (launch_row_*.hip / launch_col_*.hip) so hipcc can build them in parallel.
+#pragma once
+#include "kernels.hpp"
+
+namespace hgs {
+
+// returns hipError_t as int
+template <typename R> int launch_row(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a);
+template <typename R> int launch_col(int N, int mode, dim3 grid, hipStream_t s, const ColArgs<R>& a);
+
+// blocks of the transform kernels resident per CU are bounded by LDS; exposed for grid sizing
+template <typename R> size_t row_lds_bytes(int N);
+template <typename R> size_t col_lds_bytes(int N);
+int row_fpw(int N);   // rows per workgroup pass
+
+}  // namespace hgs

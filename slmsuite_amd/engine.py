@@ -1,0 +1,147 @@
+"""
+Thin NumPy-facing wrapper of one engine handle (include/hgs.h).  All compute happens in the HIP
+library; this class only marshals buffers and flags.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+ALGORITHM_INDEX = {"GS": 0, "WGS-Leonardo": 1, "WGS-Kim": 2, "WGS-Nogrette": 3, "WGS-Wu": 4, "WGS-tanh": 5}
+FEEDBACK_INDEX = {"computational": L.FB_PIXEL, "computational_spot": L.FB_SPOT_WINDOW,
+                  "external_spot": L.FB_EXTERNAL}
+
+
+class Engine:
+    def __init__(self, shape, slm_shape, dtype=np.float32, batch=1, n_spots=0, device=0):
+        self.lib = L.load()
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError(f"Data type {dtype} not supported.")
+        self.ctype = np.dtype(np.complex64 if self.dtype == np.float32 else np.complex128)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.slm_shape = (int(slm_shape[0]), int(slm_shape[1]))
+        self.batch = int(batch)
+        self.n_spots = int(n_spots)
+        cfg = L.hgs_config(device=int(device), pad_h=self.shape[0], pad_w=self.shape[1],
+                           slm_h=self.slm_shape[0], slm_w=self.slm_shape[1],
+                           real_bytes=self.dtype.itemsize, batch=self.batch, n_spots=self.n_spots)
+        self._h = C.c_void_p()
+        L.check(self.lib.hgs_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.hgs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- arrays ----------------------------------------------------------------------------
+    def _np(self, which, arr):
+        if which in (L.SPOT_INDEX,):
+            return np.ascontiguousarray(arr, dtype=np.int32)
+        if which in (L.SPOT_AMP, L.EXTERNAL_AMP):
+            return np.ascontiguousarray(arr, dtype=np.float64)
+        if which in (L.FARFIELD, L.ZERO_WEIGHTS):
+            return np.ascontiguousarray(arr, dtype=self.ctype)
+        return np.ascontiguousarray(arr, dtype=self.dtype)
+
+    def set(self, which, arr):
+        a = self._np(which, arr)
+        L.check(self.lib.hgs_set_array(self._h, which, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def get(self, which):
+        if which == L.PHASE:
+            out = np.empty((self.batch,) + self.slm_shape, dtype=self.dtype)
+        elif which in (L.FARFIELD, L.ZERO_WEIGHTS):
+            out = np.empty((self.batch,) + self.shape, dtype=self.ctype)
+        else:
+            out = np.empty((self.batch,) + self.shape, dtype=self.dtype)
+        L.check(self.lib.hgs_get_array(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def get_into_device(self, which, dev_ptr, nbytes):
+        L.check(self.lib.hgs_get_array_device(self._h, which, C.c_void_p(dev_ptr), nbytes))
+
+    def reset_weights(self):
+        L.check(self.lib.hgs_reset_weights(self._h))
+
+    # -- operators ---------------------------------------------------------------------------
+    def nearfield2farfield(self, store_phase_ff=False):
+        L.check(self.lib.hgs_nearfield2farfield(self._h, int(bool(store_phase_ff))))
+
+    def farfield_constraint(self, step):
+        L.check(self.lib.hgs_farfield_constraint(self._h, C.byref(step)))
+
+    def farfield2nearfield(self):
+        L.check(self.lib.hgs_farfield2nearfield(self._h))
+
+    def iterate(self, step, n_iter):
+        hist = (C.c_uint8 * max(1, n_iter))()
+        L.check(self.lib.hgs_iterate(self._h, C.byref(step), int(n_iter), hist))
+        return [bool(hist[i]) for i in range(n_iter)]
+
+    def iterate_timed(self, step, n_iter):
+        ms = C.c_double()
+        L.check(self.lib.hgs_iterate_timed(self._h, C.byref(step), int(n_iter), C.byref(ms)))
+        return ms.value
+
+    def stats(self, group, width=1, spot_xy=None):
+        out = (C.c_double * (4 * self.batch))()
+        xy = None
+        if spot_xy is not None:
+            xy_np = np.ascontiguousarray(spot_xy, dtype=np.float64)
+            xy = xy_np.ctypes.data_as(C.POINTER(C.c_double))
+        L.check(self.lib.hgs_stats(self._h, int(group), int(width), xy, out))
+        res = np.array(out[:]).reshape(self.batch, 4)
+        return [dict(efficiency=float(r[0]), uniformity=float(r[1]), pkpk_err=float(r[2]), std_err=float(r[3]))
+                for r in res]
+
+    def sync(self):
+        L.check(self.lib.hgs_sync(self._h))
+
+    def profile_enable(self, on=True):
+        L.check(self.lib.hgs_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        out = (C.c_double * (2 * len(L.K_NAMES)))()
+        L.check(self.lib.hgs_profile_read(self._h, out))
+        return {n: dict(ms=out[2 * i], launches=int(out[2 * i + 1])) for i, n in enumerate(L.K_NAMES)}
+
+    def version(self):
+        return self.lib.hgs_version().decode()
+
+
+def make_step(flags, iteration, false_run=0, mraf_enabled=False, spot_window=3):
+    """POD image of Hologram.flags for one engine call (see hgs_step in include/hgs.h)."""
+    method = flags["method"]
+    if method not in ALGORITHM_INDEX:
+        raise ValueError(f"Unsupported optimization method '{method}'")
+    fb = flags.get("feedback", "computational")
+    if fb not in FEEDBACK_INDEX:
+        raise NotImplementedError(
+            f"Feedback '{fb}' needs camera hardware; the MI355X engine covers the computational and "
+            "external_spot feedback modes")
+    mf = flags.get("mraf_factor", None)
+    zf = flags.get("zero_factor", 0)
+    st = L.hgs_step()
+    st.method = ALGORITHM_INDEX[method]
+    st.feedback = FEEDBACK_INDEX[fb]
+    st.iter = int(iteration)
+    st.fixed_phase = int(bool(flags.get("fixed_phase", False)))
+    st.fix_phase_iteration = int(flags.get("fix_phase_iteration", 10) or 0)
+    st.false_run = int(false_run)
+    st.mraf_enabled = int(bool(mraf_enabled))
+    st.has_mraf_factor = int(mf is not None)
+    st.zero_mode = int(bool(mraf_enabled) and ("zero_factor" in flags) and zf != 0)
+    st.spot_window = int(spot_window)
+    st.feedback_exponent = float(flags.get("feedback_exponent", 1.0) or 0.0)
+    st.feedback_factor = float(flags.get("feedback_factor", 1.0) or 0.0)
+    st.mraf_factor = float(mf) if mf is not None else float("nan")
+    st.zero_factor = float(zf if zf is not None else 0.0)
+    return st

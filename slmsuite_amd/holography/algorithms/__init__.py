@@ -1,0 +1,816 @@
+"""
+MI355X-native hologram optimisation: the class surface of ``slmsuite.holography.algorithms``
+(``Hologram``, ``FeedbackHologram``, ``SpotHologram``) over the HIP engine in ``libhgs.so``.
+
+Same constructors, ``optimize(method=...)`` signature, ``flags`` / ``stats`` dictionaries and
+persistent-state semantics as the reference (slmsuite 0.4.1; citations are relative to its
+checkout).  Everything per-iteration -- nearfield build, padded 2-D FFT, farfield constraint and
+weight update, inverse FFT, phase extraction, statistics reductions -- runs on the GPU; this file only
+keeps the host-side bookkeeping (flag parsing, WGS-Kim history, stats lists).  There is no CPU
+fallback: without the built library or a gfx950 device ``optimize()`` raises.
+"""
+import warnings
+
+import numpy as np
+
+from slmsuite_amd import _lib as L
+from slmsuite_amd.engine import Engine, make_step
+from slmsuite_amd.holography import toolbox
+
+try:  # progress bars are optional
+    from tqdm.auto import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+# _header.py:53-81
+ALGORITHM_DEFAULTS = {
+    "GS": {"feedback": "computational"},
+    "WGS-Leonardo": {"feedback": "computational", "feedback_exponent": 0.8},
+    "WGS-Kim": {
+        "feedback": "computational",
+        "fix_phase_efficiency": None,
+        "fix_phase_iteration": 10,
+        "feedback_exponent": 0.8,
+    },
+    "WGS-Nogrette": {"feedback": "computational", "feedback_factor": 0.1},
+    "WGS-Wu": {"feedback": "computational", "feedback_exponent": .5},
+    "WGS-tanh": {"feedback": "computational", "feedback_factor": .2, "feedback_exponent": .5},
+    "CG": {"feedback": "computational", "optimizer": "Adam", "optimizer_kwargs": {"lr": .1}, "loss": None},
+}
+ALGORITHM_INDEX = {key: i for i, key in enumerate(ALGORITHM_DEFAULTS.keys())}
+FEEDBACK_OPTIONS = [
+    "computational",
+    "computational_spot",
+    "experimental",
+    "experimental_spot",
+    "external_spot",
+]
+
+_DEVICE_ARRAYS = {"phase": L.PHASE, "weights": L.WEIGHTS, "amp_ff": L.AMP_FF, "phase_ff": L.PHASE_FF,
+                  "farfield": L.FARFIELD}
+
+
+def _norm(matrix):
+    """sqrt(nansum(|x|^2)).  Hologram._norm, _hologram.py:1979-2011."""
+    if np.iscomplexobj(matrix):
+        return np.sqrt(np.nansum(np.square(np.abs(matrix))))
+    return np.sqrt(np.nansum(np.square(matrix)))
+
+
+class Hologram:
+    """
+    Phase-retrieval hologram on a padded DFT grid (reference: ``Hologram``, _hologram.py:26-2011).
+
+    State arrays (``phase``, ``weights``, ``amp_ff``, ``phase_ff``, ``farfield``) live on the GPU
+    once optimisation has started; the attributes of the same name download them on access and
+    upload on assignment, so user code written against the reference keeps working.
+    """
+
+    # ---- construction (_hologram.py:196-439) -------------------------------------------------------
+    def __init__(self, target, amp=None, phase=None, slm_shape=None, dtype=np.float32,
+                 propagation_kernel=None, **kwargs):
+        amp_shape = (np.nan, np.nan) if amp is None else np.shape(amp)
+        phase_shape = (np.nan, np.nan) if phase is None else np.shape(phase)
+        if slm_shape is None:
+            slm_shape = (np.nan, np.nan)
+        else:
+            if hasattr(slm_shape, "slm") and hasattr(slm_shape.slm, "shape"):      # FourierSLM
+                if amp is None:
+                    amp = slm_shape.slm._get_source_amplitude()
+                    amp_shape = np.shape(amp)
+                slm_shape = slm_shape.slm.shape
+            elif hasattr(slm_shape, "_get_source_amplitude"):                        # SLM
+                if amp is None:
+                    amp = slm_shape._get_source_amplitude()
+                    amp_shape = np.shape(amp)
+                slm_shape = slm_shape.shape
+            if len(slm_shape) != 2:
+                slm_shape = (np.nan, np.nan)
+
+        stack = np.vstack((amp_shape, phase_shape, slm_shape)).astype(float)
+        if np.all(np.isnan(stack)):
+            self.slm_shape = None
+        else:
+            self.slm_shape = tuple(int(x) for x in np.rint(np.nanmean(stack, axis=0)))
+            for shp, what in ((amp_shape, "amplitude (via `amp` or SLM)"),
+                              (phase_shape, "initial phase (`phase`)"),
+                              (slm_shape, "SLM (via `target` or `slm_shape`)")):
+                if not np.isnan(shp[0]) and tuple(int(s) for s in shp) != self.slm_shape:
+                    raise ValueError(f"The shape of the {what} is not equal to the other provided SLM shapes")
+
+        if target is None:
+            if self.slm_shape is None:
+                raise ValueError("SLM shape must be provided through cameraslm=")
+            self.shape = self.slm_shape
+            target = []
+        else:
+            if len(target) == 2 and np.ndim(target) == 1:
+                self.shape = (int(target[0]), int(target[1]))
+                target = None
+            elif np.ndim(target) == 2:
+                self.shape = tuple(int(s) for s in np.shape(target))
+            else:
+                raise ValueError(f"Unexpected target {target}.")
+            if any(np.log2(self.shape) != np.round(np.log2(self.shape))):
+                warnings.warn(
+                    f"Hologram target shape {self.shape} is not a power of 2; consider using "
+                    ".get_padded_shape() to pad to powers of 2 and speed up FFT computation.")
+        if self.slm_shape is None:
+            self.slm_shape = self.shape
+
+        if np.dtype(dtype).itemsize == 4:
+            self.dtype, self.dtype_complex = np.float32, np.complex64
+        elif np.dtype(dtype).itemsize == 8:
+            self.dtype, self.dtype_complex = np.float64, np.complex128
+        else:
+            raise ValueError(f"Data type {dtype} not supported.")
+
+        self._engine = None
+        self._host = {}        # name -> host copy
+        self._stale = set()    # names whose device copy is newer than the host copy
+        self._upload = set()   # names whose host copy must reach the device before the next op
+        self._n_spots_engine = 0
+
+        if amp is None:
+            self.amp = 1 / np.sqrt(np.prod(self.slm_shape))              # scalar (:401-402)
+        else:
+            self.amp = np.array(amp, dtype=self.dtype)
+            self.amp *= 1 / _norm(self.amp)                                # (:404-405)
+
+        if propagation_kernel is None:
+            self.propagation_kernel = None
+        elif isinstance(propagation_kernel, toolbox.REAL_TYPES):
+            raise ValueError("propagation_kernel must be an array of slm_shape (scalars are rejected)")
+        else:
+            self.propagation_kernel = np.array(propagation_kernel, dtype=self.dtype)
+            if self.propagation_kernel.shape != self.slm_shape:
+                raise ValueError("Expected the propagation kernel to be the same shape as the SLM.")
+
+        self.flags = kwargs
+        self._set_target(target, reset_weights=False)
+        self._host["phase"] = None
+        self.reset_phase(phase)
+        self.reset(reset_phase=False, reset_flags=False)
+
+    # ---- device-backed attributes -----------------------------------------------------------------
+    def _get_dev(self, name):
+        if name in self._stale and self._engine is not None:
+            arr = self._engine.get(_DEVICE_ARRAYS[name])[0]
+            self._host[name] = arr
+            self._stale.discard(name)
+        return self._host.get(name)
+
+    def _set_dev(self, name, value):
+        self._host[name] = value
+        self._stale.discard(name)
+        if value is not None and name in ("phase", "weights", "phase_ff"):
+            self._upload.add(name)
+
+    phase = property(lambda s: s._get_dev("phase"), lambda s, v: s._set_dev("phase", v))
+    weights = property(lambda s: s._get_dev("weights"), lambda s, v: s._set_dev("weights", v))
+    amp_ff = property(lambda s: s._get_dev("amp_ff"), lambda s, v: s._set_dev("amp_ff", v))
+    phase_ff = property(lambda s: s._get_dev("phase_ff"), lambda s, v: s._set_dev("phase_ff", v))
+    farfield = property(lambda s: s._get_dev("farfield"), lambda s, v: s._set_dev("farfield", v))
+
+    @property
+    def nearfield(self):
+        """Padded complex nearfield amp*exp(i*phase) (the reference's buffer of _build_nearfield)."""
+        nf = np.zeros(self.shape, dtype=self.dtype_complex)
+        i0, i1, i2, i3 = toolbox.unpad(self.shape, self.slm_shape)
+        ph = self.phase if self.propagation_kernel is None else self.phase + self.propagation_kernel
+        nf[i0:i1, i2:i3] = self.amp * np.exp(1j * ph)
+        return nf
+
+    def _n_spots(self):
+        return 0
+
+    def _get_engine(self):
+        """Create the engine on first use and push every pending host array."""
+        e = self._engine
+        if e is None:
+            e = self._engine = Engine(self.shape, self.slm_shape, self.dtype, batch=1, n_spots=self._n_spots())
+            if np.isscalar(self.amp):
+                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
+            else:
+                e.set(L.AMP, self.amp)
+            if self.propagation_kernel is not None:
+                e.set(L.PROP_KERNEL, self.propagation_kernel)
+            e.set(L.TARGET, self.target)
+            self._upload |= {"phase", "weights"}
+            if self._host.get("phase_ff") is not None:
+                self._upload.add("phase_ff")
+            self._engine_setup(e)
+        for name in list(self._upload):
+            if self._host.get(name) is not None:
+                e.set(_DEVICE_ARRAYS[name], self._host[name])
+            self._upload.discard(name)
+        return e
+
+    def _engine_setup(self, e):
+        pass
+
+    # ---- reset helpers (_hologram.py:442-614) -----------------------------------------------------------
+    def reset(self, reset_phase=True, reset_flags=False):
+        if self._host.get("phase") is None or reset_phase:
+            self.reset_phase()
+        self.reset_weights()
+        self.iter = 0
+        self.stats = {"method": [], "flags": {}, "stats": {}}
+        if reset_flags:
+            self.flags = {"method": ""}
+        self._host["amp_ff"] = None
+        self._host["phase_ff"] = None
+        self._host["farfield"] = np.zeros(self.shape, dtype=self.dtype_complex)
+        self._stale -= {"amp_ff", "phase_ff", "farfield"}
+        self._upload.discard("phase_ff")
+        if self._engine is not None:
+            # phase_ff "None" on the device side: a fresh engine is the simplest faithful reset
+            self._engine.close()
+            self._engine = None
+
+    def _get_random_phase(self):
+        rng = np.random.default_rng()
+        return rng.uniform(-np.pi, np.pi, self.slm_shape).astype(self.dtype)
+
+    def reset_phase(self, custom_phase=None, random_phase=None, quadratic_phase=None):
+        if custom_phase is not None:
+            custom_phase = np.array(custom_phase, dtype=self.dtype)
+            if tuple(custom_phase.shape) != tuple(self.slm_shape):
+                raise ValueError(f"Reset phase of shape {custom_phase.shape} is not of slm_shape {self.slm_shape}")
+            self.phase = custom_phase.copy()
+            return
+        if quadratic_phase is None:
+            quadratic_phase = self.flags.get("quadratic_phase", False)
+        if random_phase is None:
+            random_phase = self.flags.get("random_phase", 1)
+        ph = np.zeros(self.slm_shape, dtype=self.dtype)
+        if quadratic_phase:
+            raise NotImplementedError("quadratic_phase preconditioning is outside the optimize() path of this build")
+        if random_phase:
+            ph += random_phase * self._get_random_phase()
+        self.phase = ph
+
+    def reset_weights(self):
+        w = np.array(self.target, copy=True)
+        np.nan_to_num(w, copy=False, nan=0)
+        self.weights = w
+        if self._engine is not None:
+            self._engine.reset_weights()
+            self._upload.discard("weights")
+
+    # ---- padding rule (_hologram.py:616-725) -----------------------------------------------------------
+    @staticmethod
+    def get_padded_shape(slm_shape, padding_order=1, square_padding=True, precision=np.inf,
+                         precision_basis="kxy"):
+        cameraslm = None
+        if hasattr(slm_shape, "slm") and hasattr(slm_shape, "cam"):
+            cameraslm = slm_shape
+            slm_shape = cameraslm.slm.shape
+        elif hasattr(slm_shape, "shape"):
+            class _Fake:
+                pass
+            cameraslm = _Fake()
+            cameraslm.slm = slm_shape
+            slm_shape = cameraslm.slm.shape
+            if precision_basis == "ij":
+                raise ValueError("Must pass a CameraSLM object under slm_shape to use the 'ij' precision_basis!")
+        if np.isfinite(precision) and cameraslm is not None:
+            if precision <= 0:
+                raise ValueError("Precision passed to get_padded_shape() must be positive.")
+            fs = 1 / np.amin(cameraslm.slm.pitch)
+            if precision_basis == "ij":
+                pixels = np.amax(cameraslm.kxyslm_to_ijcam([fs, fs])) / precision
+            else:
+                pixels = fs / precision
+            pixels = int(np.power(2, int(np.ceil(np.log2(pixels)))))
+            precision_shape = (pixels, pixels)
+        elif np.isfinite(precision):
+            raise ValueError("Must pass a CameraSLM object under slm_shape to implement precision calculations!")
+        else:
+            precision_shape = slm_shape
+        if padding_order > 0:
+            padding_shape = np.power(2, np.ceil(np.log2(slm_shape)) + padding_order - 1).astype(int)
+        else:
+            padding_shape = slm_shape
+        shape = tuple(int(s) for s in np.amax(np.vstack((precision_shape, padding_shape)), axis=0))
+        if square_padding:
+            shape = (max(shape), max(shape))
+        return shape
+
+    # ---- target / accessors (_hologram.py:741-931) ---------------------------------------------------------
+    def _set_target(self, new_target, reset_weights=False):
+        if new_target is None or (hasattr(new_target, "__len__") and len(new_target) == 0):
+            self.target = np.zeros(self.shape, dtype=self.dtype)
+        else:
+            self.target = np.array(new_target, dtype=self.dtype)
+            np.abs(self.target, out=self.target)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.target *= 1 / _norm(self.target)
+        if self._engine is not None:
+            self._engine.set(L.TARGET, self.target)
+        if reset_weights:
+            self.reset_weights()
+
+    def set_target(self, new_target, reset_weights=False):
+        self._set_target(new_target=new_target, reset_weights=reset_weights)
+
+    def get_phase(self, include_propagation=False):
+        if include_propagation and self.propagation_kernel is not None:
+            return self.phase + self.propagation_kernel
+        return self.phase + np.pi
+
+    def get_amp(self):
+        return self.amp
+
+    def set_weights(self, new_weights):
+        if tuple(np.shape(new_weights)) != tuple(self.target.shape):
+            raise ValueError(f"New weights {np.shape(new_weights)} do not match target shape {self.target.shape}")
+        self.weights = np.array(new_weights, dtype=self.dtype)
+
+    def get_weights(self):
+        return self.weights
+
+    def get_farfield(self, shape=None, propagation_kernel=None, affine=None, get=True):
+        """
+        Complex DFT farfield of the current phase at an arbitrary power-of-two ``shape``
+        (_hologram.py:853-931).  Computed by a transient engine of that shape.
+        """
+        if affine is not None:
+            raise NotImplementedError("affine resampling of the farfield is outside the optimize() path of this build")
+        if shape is None:
+            shape = self.shape
+        if len(shape) == 1:
+            shape = self.slm_shape
+        shape = (int(shape[0]), int(shape[1]))
+        if propagation_kernel is None:
+            propagation_kernel = self.propagation_kernel
+        e = Engine(shape, self.slm_shape, self.dtype, batch=1)
+        try:
+            if np.isscalar(self.amp):
+                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
+            else:
+                e.set(L.AMP, self.amp)
+            if propagation_kernel is not None and not np.isscalar(propagation_kernel):
+                e.set(L.PROP_KERNEL, np.array(propagation_kernel, dtype=self.dtype))
+            elif propagation_kernel is not None and propagation_kernel != 0:
+                e.set(L.PROP_KERNEL, np.full(self.slm_shape, propagation_kernel, dtype=self.dtype))
+            e.set(L.PHASE, self.phase)
+            e.nearfield2farfield(store_phase_ff=True)
+            ff = e.get(L.FARFIELD)[0]
+            if shape == tuple(self.shape) and self._host.get("amp_ff") is not None:
+                self.amp_ff = e.get(L.AMP_FF)[0]
+                self.phase_ff = e.get(L.PHASE_FF)[0]
+        finally:
+            e.close()
+        return ff
+
+    # ---- statistics bookkeeping (_stats.py:118-223) ---------------------------------------------------------
+    def _calculate_stats_computational(self, stats, stat_groups=[]):
+        if "computational" in stat_groups:
+            stats["computational"] = self._get_engine().stats(0)[0]
+
+    def _update_stats_dictionary(self, stats):
+        it = self.iter
+        M = len(self.stats["method"])
+        if it + 1 - M > 0:
+            self.stats["method"].extend(["" for _ in range(it + 1 - M)])
+            M = it + 1
+        self.stats["method"][it] = self.flags["method"]
+        for flag in set(self.flags.keys()).union(set(self.stats["flags"].keys())):
+            if flag not in self.stats["flags"]:
+                self.stats["flags"][flag] = [np.nan for _ in range(M)]
+            else:
+                diff = it + 1 - len(self.stats["flags"][flag])
+                if diff > 0:
+                    self.stats["flags"][flag].extend([np.nan for _ in range(diff)])
+            if flag in self.flags:
+                self.stats["flags"][flag][it] = self.flags[flag]
+        grouplist = set(stats.keys()).union(set(self.stats["stats"].keys()))
+        if len(grouplist) > 0:
+            statlists = [set(stats[group].keys()) for group in stats.keys()]
+            if len(self.stats["stats"].keys()) > 0:
+                key = next(iter(self.stats["stats"]))
+                statlists.append(set(self.stats["stats"][key].keys()))
+            statlist = set.union(*statlists)
+            for group in grouplist:
+                if group not in self.stats["stats"]:
+                    self.stats["stats"][group] = {}
+                for stat in statlist:
+                    if stat not in self.stats["stats"][group]:
+                        self.stats["stats"][group][stat] = [np.nan for _ in range(M)]
+                    else:
+                        diff = it + 1 - len(self.stats["stats"][group][stat])
+                        if diff > 0:
+                            self.stats["stats"][group][stat].extend([np.nan for _ in range(diff)])
+                    if group in stats.keys() and stat in stats[group].keys():
+                        self.stats["stats"][group][stat][it] = stats[group][stat]
+        if self.flags.get("raw_stats", False):
+            if "raw_farfield" not in self.stats:
+                self.stats["raw_farfield"] = []
+            diff = it + 1 - len(self.stats["raw_farfield"])
+            if diff > 0:
+                self.stats["raw_farfield"].extend([np.nan for _ in range(diff)])
+            self.stats["raw_farfield"][it] = np.array(self.farfield, copy=True)
+
+    def _update_stats(self, stat_groups=[]):
+        stats = {}
+        self._calculate_stats_computational(stats, stat_groups)
+        self._update_stats_dictionary(stats)
+
+    # ---- optimize (_hologram.py:1076-1424) --------------------------------------------------------------------
+    def optimize(self, method="GS", maxiter=20, verbose=True, callback=None, feedback=None,
+                 stat_groups=[], **kwargs):
+        name = kwargs.pop("name", None)
+        self._update_flags(method, verbose, feedback, stat_groups, **kwargs)
+        iterations = range(maxiter)
+        if verbose and maxiter > 1 and tqdm is not None:
+            iterations = tqdm(iterations, desc=name)
+        if "GS" in method:
+            self.optimize_gs(iterations, callback)
+        elif "CG" in method:
+            raise NotImplementedError(
+                "'CG' (torch autograd, experimental in the reference) is outside the GS/WGS hot path of this build")
+        else:
+            raise ValueError(f"Unsupported optimization method '{method}'")
+
+    def _update_flags(self, method, verbose, feedback, stat_groups, **kwargs):
+        methods = list(ALGORITHM_DEFAULTS.keys())
+        if method not in methods:
+            raise ValueError("Unrecognized method '{}'.\nValid methods include {}".format(method, methods))
+        self.flags["method"] = method
+        for flag, value in ALGORITHM_DEFAULTS[method].items():
+            if flag not in self.flags:
+                self.flags[flag] = value
+        if "fixed_phase" not in self.flags:
+            self.flags["fixed_phase"] = False
+        for flag in kwargs:
+            self.flags[flag] = kwargs[flag]
+        for group in stat_groups:
+            if group not in FEEDBACK_OPTIONS:
+                raise ValueError("Statistics group '{}' not recognized as a feedback option.\n"
+                                 "Valid options: {}".format(group, FEEDBACK_OPTIONS))
+        self.flags["stat_groups"] = stat_groups
+        if feedback is not None:
+            if feedback not in FEEDBACK_OPTIONS:
+                raise ValueError("Feedback '{}' not recognized as a feedback option.\n"
+                                 "Valid options: {}".format(feedback, FEEDBACK_OPTIONS))
+            self.flags["feedback"] = feedback
+
+    # ---- the loop (_hologram.py:1427-1493) ------------------------------------------------------------------------
+    def _false_run(self, skip_last=False):
+        """
+        Trailing run of recorded False entries of stats["flags"]["fixed_phase"] (:1574-1577).
+        NaN placeholders (iterations recorded before the flag existed) end the run: `not nan` is False.
+        """
+        hist = self.stats["flags"].get("fixed_phase", [])
+        if skip_last:
+            hist = hist[:-1]
+        run = 0
+        for v in reversed(hist):
+            if isinstance(v, float) and np.isnan(v):
+                break
+            if v:
+                break
+            run += 1
+        return run
+
+    def _mraf_enabled(self):
+        return bool(np.isnan(np.sum(self.target)))          # _mraf_helper_routines :1498
+
+    def _spot_window(self):
+        return 3
+
+    def _make_step(self, skip_last=False):
+        return make_step(self.flags, self.iter, false_run=self._false_run(skip_last),
+                         mraf_enabled=self._mraf_enabled(), spot_window=self._spot_window())
+
+    def _needs_stepwise(self, callback):
+        fl = self.flags
+        return (callback is not None or len(fl["stat_groups"]) > 0 or fl.get("raw_stats", False)
+                or ("Kim" in fl["method"] and fl.get("fix_phase_efficiency", None) is not None))
+
+    def _mark_device_fresh(self, names):
+        for n in names:
+            self._stale.add(n)
+            self._upload.discard(n)
+
+    def optimize_gs(self, iterations, callback):
+        e = self._get_engine()
+        self._pre_loop_checks()
+        n_total = len(iterations)
+        if not self._needs_stepwise(callback):
+            # fused fast path: the whole loop runs on the device; flags history is replayed on the host
+            bar = iterations if (tqdm is not None and not isinstance(iterations, range)) else None
+            done = 0
+            chunk = n_total if bar is None else max(1, n_total // 20)
+            while done < n_total:
+                n = min(chunk, n_total - done)
+                st = self._make_step()
+                hist = e.iterate(st, n)
+                for k in range(n):
+                    self.flags["fixed_phase"] = hist[k]
+                    self._update_stats_dictionary({})
+                    self.iter += 1
+                self.flags["fixed_phase"] = bool(st.fixed_phase)
+                done += n
+                if bar is not None:
+                    bar.update(n)
+            if bar is not None:
+                bar.close()
+            self._mark_device_fresh(["phase", "weights"])
+        else:
+            for _ in iterations:
+                self._get_engine()                       # push user edits made inside callbacks
+                e.nearfield2farfield(store_phase_ff=False)
+                self._mark_device_fresh(["farfield", "amp_ff"])
+                if callback is not None:
+                    if callback(self):
+                        break
+                    self._get_engine()
+                self._update_stats(self.flags["stat_groups"])
+                # the engine re-counts the history entry _update_stats just appended
+                st = self._make_step(skip_last=True)
+                if self._kim_efficiency_gate():
+                    # fix_phase_efficiency reached (:1560-1569): fix (and store the phase) right now
+                    st.fix_phase_iteration = 1
+                    st.false_run = 0
+                e.farfield_constraint(st)
+                self.flags["fixed_phase"] = bool(st.fixed_phase)
+                self._mark_device_fresh(["weights", "phase_ff", "farfield"])
+                e.farfield2nearfield()
+                self._mark_device_fresh(["phase"])
+                self.iter += 1
+        self._populate_results()
+
+    def _pre_loop_checks(self):
+        fb = self.flags.get("feedback", "computational")
+        if fb in ("experimental", "experimental_spot"):
+            raise NotImplementedError(f"Feedback '{fb}' needs camera hardware and is outside this build")
+        if fb in ("computational_spot", "external_spot") and self._n_spots() == 0 and "WGS" in self.flags["method"]:
+            raise ValueError(f"Feedback '{fb}' is specific to SpotHologram")
+
+    def _kim_efficiency_gate(self):
+        """fix_phase_efficiency branch of _gs_farfield_routines (:1560-1569), evaluated on the host."""
+        fl = self.flags
+        if not ("WGS" in fl["method"] and self.iter > 0 and "Kim" in fl["method"]):
+            return False
+        if fl.get("fix_phase_efficiency", None) is None or fl["fixed_phase"]:
+            return False
+        stats = self.stats["stats"]
+        if len(stats) == 0:
+            raise ValueError("Must track statistics to fix phase based on efficiency!")
+        eff = stats[tuple(stats.keys())[-1]]["efficiency"][self.iter]
+        return bool(eff > fl["fix_phase_efficiency"])
+
+    def _populate_results(self):
+        """_hologram.py:934-949: one more forward transform, amp_ff and phase_ff of the final phase."""
+        e = self._get_engine()
+        e.nearfield2farfield(store_phase_ff=True)
+        self._mark_device_fresh(["farfield", "amp_ff", "phase_ff"])
+
+    # mempool helpers of the reference have no meaning here
+    @staticmethod
+    def set_mempool_limit(device=0, size=None, fraction=None):
+        raise ValueError("Cannot set mempool: the HIP engine owns its device memory explicitly.")
+
+    @staticmethod
+    def get_mempool_limit(device=0):
+        raise ValueError("Cannot get mempool: the HIP engine owns its device memory explicitly.")
+
+    _norm = staticmethod(_norm)
+
+
+class FeedbackHologram(Hologram):
+    """
+    Reference: ``FeedbackHologram`` (_feedback.py:5-411).  Only the constructor plumbing
+    (shape/amp from a cameraslm or SLM, :75-100) and the "computational" weight update are on the
+    optimize() path; camera feedback (``measure``, ``ijcam_to_knmslm``) needs hardware and raises.
+    """
+
+    def __init__(self, shape, target_ij=None, cameraslm=None, null_region=None,
+                 null_region_radius_frac=None, **kwargs):
+        self.cameraslm = cameraslm
+        if self.cameraslm is not None:
+            if hasattr(self.cameraslm, "slm") and hasattr(self.cameraslm.slm, "_get_source_amplitude"):
+                amp = self.cameraslm.slm._get_source_amplitude()
+                slm_shape = self.cameraslm.slm.shape
+            elif hasattr(self.cameraslm, "_get_source_amplitude"):
+                amp = self.cameraslm._get_source_amplitude()
+                slm_shape = self.cameraslm.shape
+                self.cameraslm = None
+            else:
+                raise ValueError("Expected a CameraSLM or SLM to be passed to cameraslm.")
+        else:
+            amp = kwargs.pop("amp", None)
+            slm_shape = None
+        if "slm_shape" not in kwargs:
+            kwargs["slm_shape"] = slm_shape
+        super().__init__(target=shape, amp=amp, **kwargs)
+        self.img_ij = None
+        self.img_knm = None
+        if target_ij is not None:
+            raise NotImplementedError("camera-basis targets (target_ij) need Fourier calibration hardware")
+        self.target_ij = None
+        self._cam_points = None
+
+    def measure(self, basis="ij"):
+        raise NotImplementedError("measure() needs camera hardware and is outside this build")
+
+
+class SpotHologram(FeedbackHologram):
+    """
+    Optical focus arrays, one DFT pixel per spot (reference: ``SpotHologram``,
+    _spots.py:1020-1697).  Feedback modes on the GPU: "computational" (pixel-wise),
+    "computational_spot" (w x w window integration around each spot) and "external_spot".
+    """
+
+    def __init__(self, shape, spot_vectors, basis="kxy", spot_amp=None, cameraslm=None,
+                 null_vectors=None, null_radius=None, null_region=None,
+                 null_region_radius_frac=None, **kwargs):
+        vectors = toolbox.format_2vectors(spot_vectors)
+        N = vectors.shape[1]
+        if spot_amp is not None:
+            self.spot_amp = np.ravel(spot_amp)
+            if len(self.spot_amp) != N:
+                raise ValueError("spot_amp must have the same length as the provided spots.")
+        else:
+            self.spot_amp = np.full(N, 1.0 / np.sqrt(N))
+        self.external_spot_amp = np.copy(self.spot_amp)
+
+        if null_vectors is not None:
+            null_vectors = toolbox.format_2vectors(null_vectors)
+        self.null_knm = None
+        self.null_radius_knm = None
+        self.null_region_knm = None
+
+        if basis is None or basis == "knm":
+            self.spot_knm = vectors
+            if cameraslm is not None:
+                self.spot_kxy = toolbox.convert_vector(self.spot_knm, "knm", "kxy", cameraslm, shape)
+                if "fourier" in getattr(cameraslm, "calibrations", {}):
+                    self.spot_ij = cameraslm.kxyslm_to_ijcam(self.spot_kxy)
+                else:
+                    self.spot_ij = None
+            else:
+                self.spot_kxy = None
+                self.spot_ij = None
+            self.null_knm = null_vectors
+            self.null_radius_knm = null_radius
+            self.null_region_knm = null_region
+        elif basis == "kxy":
+            assert cameraslm is not None, "We need a cameraslm to interpret kxy."
+            self.spot_kxy = vectors
+            self.spot_ij = None
+            if "fourier" in getattr(cameraslm, "calibrations", {}):
+                self.spot_ij = cameraslm.kxyslm_to_ijcam(vectors)
+            self.spot_knm = toolbox.convert_vector(self.spot_kxy, "kxy", "knm", cameraslm, shape)
+        elif basis == "ij":
+            assert cameraslm is not None, "We need an cameraslm to interpret ij."
+            assert "fourier" in cameraslm.calibrations, "We need a fourier-calibrated cameraslm to interpret ij."
+            self.spot_ij = vectors
+            self.spot_kxy = cameraslm.ijcam_to_kxyslm(vectors)
+            self.spot_knm = toolbox.convert_vector(vectors, "ij", "knm", cameraslm, shape)
+        else:
+            raise Exception("Unrecognized basis for spots '{}'.".format(basis))
+
+        if basis in ("ij", "kxy"):
+            if null_vectors is not None:
+                self.null_knm = toolbox.convert_vector(null_vectors, basis, "knm", cameraslm, shape)
+                self.null_radius_knm = None if null_radius is None else \
+                    toolbox.convert_radius(null_radius, basis, "knm", cameraslm, shape)
+            self.null_region_knm = null_region
+
+        # integration width (_spots.py:1270-1306)
+        psf_knm = 0
+        if cameraslm is not None and hasattr(getattr(cameraslm, "slm", cameraslm), "get_spot_radius_kxy"):
+            slm = getattr(cameraslm, "slm", cameraslm)
+            psf_kxy = np.mean(slm.get_spot_radius_kxy())
+            psf_knm = toolbox.convert_radius(psf_kxy, "kxy", "knm", slm, shape)
+            if np.isnan(psf_knm):
+                psf_knm = 0
+        min_psf = 3
+        dist_knm = np.max([toolbox.smallest_distance(self.spot_knm) / 1.5, min_psf])
+        width = np.clip(10 * psf_knm, min_psf, dist_knm)
+        self.spot_integration_width_knm = int(2 * np.floor(width / 2) + 1)
+        self.spot_integration_width_ij = None
+
+        if (np.any(self.spot_knm[0] < 0) or np.any(self.spot_knm[1] < 0)
+                or np.any(self.spot_knm[0] >= shape[1]) or np.any(self.spot_knm[1] >= shape[0])):
+            raise ValueError("Spots outside SLM computational space bounds!\nSpots:\n{}\nBounds: {}".format(
+                self.spot_knm, shape))
+
+        if self.null_knm is not None:
+            if self.null_radius_knm is None:
+                all_spots = np.hstack((self.null_knm, self.spot_knm))
+                self.null_radius_knm = toolbox.smallest_distance(all_spots) / 4
+            self.null_radius_knm = int(np.ceil(self.null_radius_knm))
+
+        super().__init__(shape, target_ij=None, cameraslm=cameraslm, **kwargs)
+
+        if null_region_radius_frac is not None:
+            if self.null_region_knm is None:
+                self.null_region_knm = np.zeros(self.shape, dtype=bool)
+            xl = np.linspace(-1, 1, self.null_region_knm.shape[0])
+            yl = np.linspace(-1, 1, self.null_region_knm.shape[1])
+            xg, yg = np.meshgrid(xl, yl)
+            self.null_region_knm[np.square(xg) + np.square(yg) > null_region_radius_frac ** 2] = True
+
+        self.set_target(reset_weights=True)
+
+    def __len__(self):
+        return self.spot_knm.shape[1]
+
+    def _n_spots(self):
+        return self.spot_knm.shape[1]
+
+    @staticmethod
+    def make_rectangular_array(shape, array_shape, array_pitch, array_center=None, basis="knm",
+                               orientation_check=False, **kwargs):
+        """_spots.py:1387-1488."""
+        if isinstance(array_shape, toolbox.REAL_TYPES):
+            array_shape = (int(array_shape), int(array_shape))
+        if isinstance(array_pitch, toolbox.REAL_TYPES):
+            array_pitch = (array_pitch, array_pitch)
+        if array_center is None:
+            if basis == "knm":
+                array_center = (shape[1] / 2.0, shape[0] / 2.0)
+            elif basis == "kxy":
+                array_center = (0, 0)
+            elif basis == "ij":
+                cameraslm = kwargs.get("cameraslm", None)
+                assert cameraslm is not None, "We need an cameraslm to interpret ij."
+                array_center = toolbox.convert_vector((0, 0), "kxy", "ij", cameraslm)
+        x_edge = (np.arange(array_shape[0]) - (array_shape[0] - 1) / 2.0) * array_pitch[0] + array_center[0]
+        y_edge = (np.arange(array_shape[1]) - (array_shape[1] - 1) / 2.0) * array_pitch[1] + array_center[1]
+        x_grid, y_grid = np.meshgrid(x_edge, y_edge, sparse=False, indexing="xy")
+        x_list, y_list = x_grid.ravel(), y_grid.ravel()
+        if orientation_check and len(x_list) > 2:
+            x_list, y_list = x_list[:-2], y_list[:-2]
+        return SpotHologram(shape, np.vstack((x_list, y_list)), basis=basis, spot_amp=None, **kwargs)
+
+    def _set_target_spots(self, reset_weights=False):
+        """_spots.py:1490-1546."""
+        self.spot_knm_rounded = np.rint(self.spot_knm).astype(int)
+        self.spot_kxy_rounded = None
+        self.spot_ij_rounded = None
+        if self.cameraslm is not None:
+            self.spot_kxy_rounded = toolbox.convert_vector(
+                self.spot_knm_rounded, "knm", "kxy", self.cameraslm.slm, self.shape)
+            if "fourier" in getattr(self.cameraslm, "calibrations", {}):
+                self.spot_ij_rounded = self.cameraslm.kxyslm_to_ijcam(self.spot_kxy_rounded)
+        target = np.zeros(self.shape, dtype=self.dtype)
+        if self.null_knm is not None:
+            target.fill(np.nan)
+            if self.null_region_knm is not None:
+                target[np.asarray(self.null_region_knm, dtype=bool)] = 0
+            all_spots = np.hstack((self.null_knm, self.spot_knm))
+            w = int(2 * self.null_radius_knm + 1)
+            for ii in range(all_spots.shape[1]):
+                toolbox.imprint_disk_zero(target, np.rint(all_spots[0, ii]), np.rint(all_spots[1, ii]), w)
+        target[self.spot_knm_rounded[1, :], self.spot_knm_rounded[0, :]] = self.spot_amp
+        target /= _norm(target)
+        self.target = target
+        if self._engine is not None:
+            self._engine.set(L.TARGET, self.target)
+            self._engine_setup(self._engine)
+        if reset_weights:
+            self.reset_weights()
+
+    def set_target(self, reset_weights=False, plot=False):
+        self._set_target_spots(reset_weights=reset_weights)
+
+    def _engine_setup(self, e):
+        e.set(L.SPOT_INDEX, self.spot_knm_rounded)
+        e.set(L.SPOT_AMP, self.spot_amp)
+        e.set(L.EXTERNAL_AMP, self.external_spot_amp)
+
+    def _spot_window(self):
+        return self.spot_integration_width_knm
+
+    def _pre_loop_checks(self):
+        if self.flags.get("feedback") == "experimental":
+            warnings.warn("SpotHologram feedback 'experimental' is interpreted as 'experimental_spot'")
+            self.flags["feedback"] = "experimental_spot"
+        super()._pre_loop_checks()
+        if self.flags.get("feedback") == "external_spot":
+            self._engine.set(L.EXTERNAL_AMP, self.external_spot_amp)
+
+    def _calculate_stats_computational_spot(self, stats, stat_groups=[]):
+        """_spots.py:1626-1679."""
+        if "computational_spot" in stat_groups:
+            e = self._get_engine()
+            if tuple(self.shape) == tuple(self.slm_shape):
+                stats["computational_spot"] = e.stats(1, 1, self.spot_knm_rounded)[0]
+            else:
+                stats["computational_spot"] = e.stats(1, self.spot_integration_width_knm, self.spot_knm)[0]
+
+    def _update_stats(self, stat_groups=[]):
+        stats = {}
+        self._calculate_stats_computational(stats, stat_groups)
+        self._calculate_stats_computational_spot(stats, stat_groups)
+        self._update_stats_dictionary(stats)
+
+
+__all__ = ["Hologram", "FeedbackHologram", "SpotHologram", "ALGORITHM_DEFAULTS", "ALGORITHM_INDEX",
+           "FEEDBACK_OPTIONS"]

@@ -28,8 +28,9 @@ def golden_names(prefix):
 
 
 def rel_l2(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    cplx = np.iscomplexobj(a) or np.iscomplexobj(b)
+    a = np.asarray(a, dtype=np.complex128 if cplx else np.float64)
+    b = np.asarray(b, dtype=np.complex128 if cplx else np.float64)
     d = np.sqrt(np.nansum(np.abs(a - b) ** 2))
     n = np.sqrt(np.nansum(np.abs(b) ** 2))
     return float(d / n) if n > 0 else float(d)

@@ -1,0 +1,170 @@
+"""
+CPU tests of the product's host side: the C-ABI library loads and exports what include/hgs.h
+declares, the class surface builds the same host state as the reference (checked against the
+golden fixtures), flag / history logic, and the loud failure without a GPU.  No compute calls.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, load_golden
+from golden_cases import hologram_inputs
+from slmsuite_amd import _lib as L
+from slmsuite_amd import synth
+from slmsuite_amd.engine import make_step
+from slmsuite_amd.holography import toolbox
+from slmsuite_amd.holography.algorithms import ALGORITHM_DEFAULTS, ALGORITHM_INDEX, Hologram, SpotHologram
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hgs.h")).read()
+    declared = set(re.findall(r"\b(hgs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hgs_engine", "hgs_config", "hgs_step", "hgs_status"}
+    assert declared, "no declarations parsed"
+    lib = L.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hgs.h but not exported"
+    assert set(L.EXPORTS) == declared
+    assert lib.hgs_version().startswith(b"hgs ")
+
+
+def test_struct_layouts_match_header():
+    # field order is part of the ABI: keep ctypes and the header in lock-step
+    hdr = open(os.path.join(ROOT, "include", "hgs.h")).read()
+    cfg = re.search(r"typedef struct \{([^{}]*)\} hgs_config;", hdr, re.S).group(1)
+    names = re.findall(r"\b([a-z_]+)\s*[;,]", re.sub(r"/\*.*?\*/", "", cfg, flags=re.S))
+    assert [n for n, _ in L.hgs_config._fields_] == names
+    st = re.search(r"typedef struct \{([^{}]*)\} hgs_step;", hdr, re.S).group(1)
+    names = re.findall(r"\b([a-z_]+)\s*[;,]", re.sub(r"/\*.*?\*/", "", st, flags=re.S))
+    assert [n for n, _ in L.hgs_step._fields_] == names
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = Hologram(synth.random_target(1, (64, 64)), phase=synth.seed_phase(1, (64, 64)))
+    with pytest.raises(L.HgsError):
+        h.optimize("GS", maxiter=1, verbose=False)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "slmsuite_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/", "").lower() or f == "_lib.py" or "import oracle" not in src, f
+                assert "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_constants_follow_reference_order():
+    assert list(ALGORITHM_INDEX) == ["GS", "WGS-Leonardo", "WGS-Kim", "WGS-Nogrette", "WGS-Wu", "WGS-tanh", "CG"]
+    assert ALGORITHM_DEFAULTS["WGS-Kim"]["fix_phase_iteration"] == 10
+
+
+def test_helpers_match_reference():
+    meta, gold = load_golden("helpers")
+    for row, out in zip(gold["unpad_in"], gold["unpad_out"]):
+        assert toolbox.unpad((int(row[0]), int(row[1])), (int(row[2]), int(row[3]))) == tuple(out)
+    for row, out in zip(gold["padshape_in"], gold["padshape_out"]):
+        assert Hologram.get_padded_shape((int(row[0]), int(row[1])), int(row[2]), bool(row[3])) == tuple(out)
+    m = np.arange(12.0).reshape(3, 4)
+    p = toolbox.pad(m, (8, 9))
+    assert p.shape == (8, 9) and np.array_equal(toolbox.unpad(p, (3, 4)), m)
+
+
+@pytest.mark.parametrize("name", golden_names("holo_")[:4] + golden_names("mraf_")[:1])
+def test_constructor_state_matches_reference(name):
+    """target normalisation, weights = target (NaN -> 0), scalar/array amp: compare with weights_0-like data."""
+    meta, gold = load_golden(name)
+    kw = hologram_inputs(meta)
+    h = Hologram(**kw)
+    assert h.shape == tuple(meta["shape"]) and h.slm_shape == tuple(meta["slm_shape"])
+    t = np.array(kw["target"], dtype=h.dtype)
+    t = np.abs(t)
+    t *= 1 / np.sqrt(np.nansum(np.square(t)))
+    np.testing.assert_array_equal(np.nan_to_num(h.target, nan=-1), np.nan_to_num(t, nan=-1))
+    np.testing.assert_array_equal(h.weights, np.nan_to_num(t, nan=0))
+    if kw["amp"] is None:
+        assert np.isscalar(h.amp) and abs(h.amp - 1 / np.sqrt(np.prod(h.slm_shape))) < 1e-15
+    else:
+        assert abs(float(np.sum(h.amp.astype(float) ** 2)) - 1) < 1e-5
+    assert h.iter == 0 and h.stats == {"method": [], "flags": {}, "stats": {}}
+    assert h.amp_ff is None and h.phase_ff is None
+    np.testing.assert_allclose(h.get_phase(), kw["phase"] + np.pi)
+
+
+def test_spot_hologram_host_state_matches_reference():
+    meta, gold = load_golden("spot_WGSLeonardo_computational_spot")
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    h = SpotHologram.make_rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]),
+                                            basis="knm", slm_shape=slm, phase=synth.seed_phase(meta["seed"], slm))
+    np.testing.assert_array_equal(h.spot_knm, gold["spot_knm"])
+    np.testing.assert_array_equal(h.spot_knm_rounded, gold["spot_knm_rounded"])
+    np.testing.assert_allclose(h.spot_amp, gold["spot_amp"])
+    assert h.spot_integration_width_knm == meta["width"] and len(h) == 64
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    np.testing.assert_allclose(h.target[ky, kx], gold["target_spots"], rtol=1e-6)
+    assert np.count_nonzero(h.target) == 64
+    with pytest.raises(ValueError):
+        SpotHologram((64, 64), [[70], [10]], basis="knm", slm_shape=(64, 64))
+
+
+def test_flag_parsing_and_errors():
+    h = Hologram(synth.random_target(1, (64, 64)), phase=synth.seed_phase(1, (64, 64)), my_flag=3)
+    with pytest.raises(ValueError):
+        h._update_flags("nope", False, None, [])
+    with pytest.raises(ValueError):
+        h._update_flags("GS", False, "bogus", [])
+    with pytest.raises(ValueError):
+        h._update_flags("GS", False, None, ["bogus"])
+    h._update_flags("WGS-Kim", False, None, [], feedback_exponent=0.7)
+    assert h.flags["feedback_exponent"] == 0.7 and h.flags["fix_phase_iteration"] == 10
+    assert h.flags["fixed_phase"] is False and h.flags["my_flag"] == 3 and h.flags["feedback"] == "computational"
+    st = make_step(h.flags, 4, false_run=2)
+    assert (st.method, st.feedback, st.iter, st.false_run, st.fix_phase_iteration) == (2, 0, 4, 2, 10)
+    assert abs(st.feedback_exponent - 0.7) < 1e-15 and st.mraf_enabled == 0
+    h.flags["feedback"] = "experimental"
+    with pytest.raises(NotImplementedError):
+        make_step(h.flags, 0)
+    with pytest.raises(ValueError):
+        Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((32, 32)), amp=np.ones((16, 16)))
+    with pytest.raises(ValueError):
+        Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64)), dtype=np.float16)
+
+
+def test_false_run_history():
+    h = Hologram(synth.random_target(1, (64, 64)), phase=synth.seed_phase(1, (64, 64)))
+    h.stats["flags"]["fixed_phase"] = [np.nan, False, False, False]
+    assert h._false_run() == 3 and h._false_run(skip_last=True) == 2
+    h.stats["flags"]["fixed_phase"] = [False, True, False]
+    assert h._false_run() == 1
+    h.stats["flags"]["fixed_phase"] = []
+    assert h._false_run() == 0
+
+
+def test_stats_dictionary_bookkeeping():
+    h = Hologram(synth.random_target(1, (64, 64)), phase=synth.seed_phase(1, (64, 64)))
+    h._update_flags("WGS-Leonardo", False, None, [])
+    h._update_stats_dictionary({})
+    h.iter = 2
+    h.flags["new_flag"] = 5
+    h._update_stats_dictionary({"computational": {"efficiency": 0.5}})
+    assert h.stats["method"] == ["WGS-Leonardo", "", "WGS-Leonardo"]
+    assert h.stats["flags"]["fixed_phase"][0] is False and np.isnan(h.stats["flags"]["fixed_phase"][1])
+    assert np.isnan(h.stats["flags"]["new_flag"][0]) and h.stats["flags"]["new_flag"][2] == 5
+    eff = h.stats["stats"]["computational"]["efficiency"]
+    assert np.isnan(eff[0]) and eff[2] == 0.5
+
+
+def test_convert_vector_knm_roundtrip():
+    class Slm:
+        shape = (1152, 1920)
+        pitch = (8 / 0.78, 8 / 0.78)
+    v = np.array([[0.01, -0.02], [0.005, 0.0]])
+    knm = toolbox.convert_vector(v, "kxy", "knm", Slm(), (4096, 4096))
+    back = toolbox.convert_vector(knm, "knm", "kxy", Slm(), (4096, 4096))
+    np.testing.assert_allclose(back, v, atol=1e-15)
+    np.testing.assert_allclose(toolbox.convert_vector((0, 0), "kxy", "knm", Slm(), (4096, 4096)).ravel(), [2048, 2048])
