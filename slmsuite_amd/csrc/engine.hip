@@ -504,6 +504,7 @@ template <typename R> struct Engine : EngineBase {
         c.p_exp = (R)st->feedback_exponent; c.p_fac = (R)st->feedback_factor;
         c.mraf_factor = (R)st->mraf_factor; c.zero_factor = (R)st->zero_factor;
         c.inv_fnorm = (R)(1.0 / std::sqrt(amp_norm2));  // Parseval: ||F|| = ||nearfield|| = ||amp||
+        c.log2_inv_fnorm = (R)(-0.5 * std::log2(amp_norm2));
         return c;
     }
 
@@ -609,7 +610,11 @@ template <typename R> struct Engine : EngineBase {
             int r = timed(HGS_K_COL_FUSED, [&]() -> int {
                 ColArgs<R> a = col_args();
                 a.cp = cparams(st, p);
-                LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
+                const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
+                if (env_int("HGS_OLD_FUSED", 0))
+                    LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
+                else
+                    LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
                 return 0;
             });
             if (r) return r;

@@ -24,6 +24,9 @@
 #ifndef HGS_COL_OCC
 #define HGS_COL_OCC 3
 #endif
+#ifndef HGS_FUSED_OCC
+#define HGS_FUSED_OCC 2
+#endif
 
 namespace hgs {
 
@@ -43,7 +46,8 @@ template <typename R> struct CParams {
     int has_mraf_factor;
     int zero_mode;    // 0: zero region := 0 ; 1: zero_weights feedback (:1613-1616)
     R p_exp, p_fac, mraf_factor, zero_factor;
-    R inv_fnorm;      // 1/||amp_ff||, used when fnorm_ptr == nullptr (Parseval constant)
+    R inv_fnorm;      // 1/||amp_ff|| (Parseval constant ||amp|| in the fused path)
+    R log2_inv_fnorm;
 };
 
 // sin/cos for the bounded arguments of this engine (|phase + kernel| of a few thousand radians at
@@ -78,6 +82,8 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
     static __device__ __forceinline__ float powneg(float x, float p) { return exp2f(-p * log2f(x)); }
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
+    static __device__ __forceinline__ float log2(float x) { return log2f(x); }
+    static __device__ __forceinline__ float exp2(float x) { return exp2f(x); }
     static __device__ __forceinline__ float tanh(float x) { return tanhf(x); }
     static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
 };
@@ -88,6 +94,8 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
     static __device__ __forceinline__ double powneg(double x, double p) { return ::pow(x, -p); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
+    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
     static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
 };
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                     ph[c] = p;
                     v[m].x = p;  // keep for the fused rebuild
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
         }
         if constexpr (MODE != 1) {
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                     nf = mk<R>(amv * co, amv * s);
                 }
                 v[m] = nf;
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
             fft.template run<-1>(v, lds, j);
             if (valid) {
@@ -427,6 +435,153 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
     if constexpr (MODE & C_STORE) {
         const double s = block_sum(acc_f, scratch);
         if (tid == 0) a.fpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// =====================================================================================================
+// FUSED column kernel (the dominant kernel of the fast path): for each column of a 4-column tile
+//     G --FFT_y--> F --constraint + weight update--> ff --IFFT_y--> H        (in place in GH)
+// i.e. the column half of fft2 (:1048), _gs_farfield_routines (:1550-1605) with
+// _update_weights_generic (:1822-1879) and the column half of ifft2 (:1070); the farfield is never
+// written to HBM.  Software pipeline: the weight/target loads and the G loads of the NEXT column
+// are issued right after the constraint of the current one, so they land under the inverse
+// transform of this column and the forward transform of the next.
+//   PHASE 0: rebuild with F/|F|            (exp(i*atan2 F), :1602-1605, without materialising it)
+//   PHASE 1: same + store phase_ff = atan2 F (WGS-Kim before/at the fixing iteration, :1583)
+//   PHASE 2: rebuild with the stored phase_ff (fixed phase, :1601)
+// Weight rule in log domain for Leonardo/Kim:
+//   (|F| * c / T)^-p = exp2(-p * (log2(|F|^2)/2 + log2 c - log2 T)),  T == 0 -> 1 (:1841)
+// =====================================================================================================
+template <typename R, int N, int PHASE>
+__global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel(ColArgs<R> a) {
+    using M = Math<R>;
+    constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo g = a.g;
+    const int tid = threadIdx.x;
+    const int cpar = tid / T, j = tid % T;
+    const int b = blockIdx.y;
+    Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
+    double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
+
+    WgFft<R, N> fft;
+    fft.init(a.tw, j);
+    const CParams<R> cp = a.cp;
+    const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const size_t P = (size_t)g.Ph * g.Pw;
+    const R wsc = a.wscale[b];
+    const R sc = sgn * a.scale;
+    const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
+    const int ntiles = g.Pw / 4;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ncols = my_tiles * PASSES;
+    R acc_w = 0;
+
+    Cx<R> v[16], gn[16];
+    R wr[16], tr[16];
+
+    auto col_of = [&](int q, int& ct, int& c4) {
+        ct = blockIdx.x + (q / PASSES) * gridDim.x;
+        c4 = (q % PASSES) * CPAR + cpar;
+    };
+    auto issue_wt = [&](int q) {
+        int ct, c4;
+        col_of(q, ct, c4);
+        const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
+        const R* wc = a.w + cb;
+        const R* tc = a.t + cb;
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = m_;
+            wr[m] = wc[(unsigned)(j + m * T)];
+            if (cp.do_update) tr[m] = tc[(unsigned)(j + m * T)];
+        });
+    };
+    auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
+        int ct, c4;
+        col_of(q, ct, c4);
+        const Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = m_;
+            const int r = r_lane + m * T;
+            dst[m] = mk<R>(0, 0);
+            if (r >= 0 && r < g.Sh) dst[m] = gh[(unsigned)r * 4u];
+        });
+    };
+
+    if (ncols > 0) {
+        issue_g(0, v);
+        issue_wt(0);
+    }
+#pragma unroll 1
+    for (int q = 0; q < ncols; ++q) {
+        int ct, c4;
+        col_of(q, ct, c4);
+        const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
+        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgn; });
+        fft.template run<-1>(v, lds, j);
+
+        // ---- constraint + weight update on F = sc * v ----
+        R* wc = a.w + cb;
+        R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = m_;
+            const unsigned idx = (unsigned)(j + m * T);
+            const Cx<R> F = v[m] * sc;
+            const R p2 = F.x * F.x + F.y * F.y;
+            const R wraw = wr[m];
+            R wv = wraw * wsc;
+            if (cp.do_update) {
+                const R t = tr[m];
+                if (cp.method == M_LEONARDO || cp.method == M_KIM) {
+                    if (t != (R)0) {                       // T == 0 -> factor 1 (:1841)
+                        R fc = M::exp2(-cp.p_exp * ((R)0.5 * M::log2(p2) + cp.log2_inv_fnorm - M::log2(t)));
+                        if (!(fc < (R)INFINITY)) fc = 1;   // inf (:1840,:1867) and nan (:1843) -> 1
+                        wv *= fc;
+                    }
+                } else {
+                    wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, (R)0);
+                }
+                if (is_nan(wv)) wv = (R)0.0001;            // :1873
+                if (wv != wraw) wc[idx] = wv;              // unchanged values (zeros of a sparse target) stay put
+                acc_w += wv * wv;
+            }
+            R co, si;
+            if constexpr (PHASE == 2) {
+                M::sincos(pfc[idx], &si, &co);
+            } else {
+                if (p2 > (R)0) {                           // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
+                    const R inv = M::rsqrt(p2);
+                    co = F.x * inv;
+                    si = F.y * inv;
+                } else {
+                    co = 1;
+                    si = 0;
+                }
+                if constexpr (PHASE == 1) pfc[idx] = M::atan2(F.y, F.x);
+            }
+            v[m] = mk<R>(wv * co * sgn, wv * si * sgn);
+            if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+
+        // ---- prefetch the next column while this one is transformed back ----
+        if (q + 1 < ncols) {
+            issue_wt(q + 1);
+            issue_g(q + 1, gn);
+        }
+        fft.template run<+1>(v, lds, j);
+        {
+            Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                const int r = r_lane + m * T;
+                if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u] = v[m] * sc;
+            });
+        }
+        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
+    }
+    if (cp.do_update) {
+        const double s = block_sum((double)acc_w, scratch);
+        if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }
 }
 

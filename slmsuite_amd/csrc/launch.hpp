@@ -8,6 +8,7 @@ namespace hgs {
 // returns hipError_t as int
 template <typename R> int launch_row(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a);
 template <typename R> int launch_col(int N, int mode, dim3 grid, hipStream_t s, const ColArgs<R>& a);
+template <typename R> int launch_fused(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a);
 
 // blocks of the transform kernels resident per CU are bounded by LDS; exposed for grid sizing
 template <typename R> size_t row_lds_bytes(int N);

@@ -1,0 +1,43 @@
+// Included by launch_fused_f32.hip / launch_fused_f64.hip with HGS_REAL defined.
+#include "launch.hpp"
+
+namespace hgs {
+
+template <typename R, int N, int PHASE>
+static int launch_fused_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
+    constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + 16 * sizeof(double);
+    auto k = col_fused_kernel<R, N, PHASE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(ColCfg<N>::WG), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+template <typename R, int N>
+static int launch_fused_n(int phase, dim3 grid, hipStream_t s, const ColArgs<R>& a) {
+    switch (phase) {
+        case 0: return launch_fused_one<R, N, 0>(grid, s, a);
+        case 1: return launch_fused_one<R, N, 1>(grid, s, a);
+        case 2: return launch_fused_one<R, N, 2>(grid, s, a);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+template <> int launch_fused<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t s, const ColArgs<HGS_REAL>& a) {
+    switch (N) {
+        case 64: return launch_fused_n<HGS_REAL, 64>(phase, grid, s, a);
+        case 128: return launch_fused_n<HGS_REAL, 128>(phase, grid, s, a);
+        case 256: return launch_fused_n<HGS_REAL, 256>(phase, grid, s, a);
+        case 512: return launch_fused_n<HGS_REAL, 512>(phase, grid, s, a);
+        case 1024: return launch_fused_n<HGS_REAL, 1024>(phase, grid, s, a);
+        case 2048: return launch_fused_n<HGS_REAL, 2048>(phase, grid, s, a);
+        case 4096: return launch_fused_n<HGS_REAL, 4096>(phase, grid, s, a);
+        case 8192: return launch_fused_n<HGS_REAL, 8192>(phase, grid, s, a);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace hgs

@@ -46,3 +46,14 @@ def phase_rel_l2(a, b):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def report(name, **values):
+    """Append measured parity errors to gpurun_out/parity_report.jsonl (cited in DESIGN.md)."""
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"case": name, **{k: float(v) for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass
