@@ -98,7 +98,7 @@ template <typename R> struct Engine : EngineBase {
     bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
     bool w_pending = false;  // weights stored un-normalised, wscale holds 1/||w||
     bool has_target = false, has_spots = false;
-    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256;
+    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256, row_xcd = 0, tile_blocks = 0, wpartial_n = 0;
     // profiling
     bool prof = false;
     struct Ev { int kind; hipEvent_t a, b; };
@@ -172,18 +172,21 @@ template <typename R> struct Engine : EngineBase {
         cap = cap / B > 0 ? cap / B : 1;
         int per = (row_units + cap - 1) / cap;
         row_blocks = (row_units + per - 1) / per;
+        row_xcd = (fpw == 1 && row_blocks >= 32 && env_int("HGS_ROW_XCD", 1)) ? 1 : 0;
+        if (row_xcd) row_blocks = (row_blocks + 31) / 32 * 32;
         const int tiles = g.Pw / 4;
         cap = env_int("HGS_COL_BLOCKS", n_cu * 3);
         cap = cap / B > 0 ? cap / B : 1;
         per = (tiles + cap - 1) / cap;
         col_blocks = (tiles + per - 1) / per;
+        tile_blocks = std::max(1, std::min(tiles, env_int("HGS_TILE_BLOCKS", n_cu * 2) / B));
         ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
 
         if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
         if (dalloc(&gh, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE;
         if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
         if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
-        if (dalloc(&wpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&wpartial, (size_t)B * std::max(col_blocks, tile_blocks))) return HGS_ERR_DEVICE;
         if (dalloc(&fpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&sums, (size_t)3 * B)) return HGS_ERR_DEVICE;
@@ -421,7 +424,8 @@ template <typename R> struct Engine : EngineBase {
         RowArgs<R> a{};
         a.g = g; a.phase = phase; a.amp = has_amp ? amp : nullptr; a.kern = has_kern ? kern : nullptr;
         a.amp_scalar = (R)amp_scalar; a.gh = gh; a.tw = tw_row; a.scale = (R)(1.0 / std::sqrt((double)g.Pw));
-        a.wpartial = finalize ? wpartial : nullptr; a.n_wpartial = col_blocks; a.wscale = wscale;
+        a.wpartial = finalize ? wpartial : nullptr; a.n_wpartial = wpartial_n; a.wscale = wscale;
+        a.xcd_map = row_xcd;
         return a;
     }
     int run_row(int mode, bool finalize) {
@@ -611,10 +615,18 @@ template <typename R> struct Engine : EngineBase {
                 ColArgs<R> a = col_args();
                 a.cp = cparams(st, p);
                 const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
-                if (env_int("HGS_OLD_FUSED", 0))
+                // slots of the load layout the SLM rows occupy (tile-resident kernel needs <= 6)
+                const int Tc = g.Ph / 16;
+                const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;
+                wpartial_n = col_blocks;
+                if (env_int("HGS_OLD_FUSED", 0)) {
                     LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
-                else
+                } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
+                    wpartial_n = tile_blocks;
+                    LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                } else {
                     LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                }
                 return 0;
             });
             if (r) return r;

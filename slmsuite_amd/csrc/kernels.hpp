@@ -50,24 +50,19 @@ template <typename R> struct CParams {
     R log2_inv_fnorm;
 };
 
-// sin/cos for the bounded arguments of this engine (|phase + kernel| of a few thousand radians at
-// most): 3-term Cody-Waite reduction by pi/2 + minimax polynomials on [-pi/4, pi/4]; <= ~1.5 ulp,
-// ~25 VALU ops and no large-argument slow path (ocml's sincosf carries a Payne-Hanek branch that
-// costs >100 VGPRs when 16 of them are unrolled).  Arguments beyond 2^13 take the ocml path.
+// sin/cos in fp32 with the range reduction by pi/2 done in ONE fp64 fma (exact enough for any
+// fp32 argument up to ~1e7 rad, no large-argument slow path: ocml's sincosf carries a Payne-Hanek
+// branch that costs >100 VGPRs when unrolled 16x), then minimax polynomials on [-pi/4, pi/4];
+// max abs error 9e-8 (tools/check_sincos.py).
 __device__ __forceinline__ void sincos_bounded(float x, float* s, float* c) {
-    if (__builtin_expect(fabsf(x) > 8192.0f, 0)) {
-        sincosf(x, s, c);
-        return;
-    }
-    const float q = rintf(x * 0.63661977236758134308f);
-    float r = fmaf(-q, 1.5703125f, x);
-    r = fmaf(-q, 4.837512969970703125e-4f, r);
-    r = fmaf(-q, 7.54978995489188216e-8f, r);
+    const double xd = (double)x;
+    const double qd = rint(xd * 0.63661977236758134308);
+    const float r = (float)fma(-qd, 1.57079632679489661923, xd);
     const float z = r * r;
     const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
     const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
                           z * z, fmaf(-0.5f, z, 1.0f));
-    const int n = (int)q;
+    const int n = (int)qd;
     const float ss = (n & 1) ? pc : ps;
     const float cc = (n & 1) ? ps : pc;
     *s = (n & 2) ? -ss : ss;
@@ -180,6 +175,7 @@ template <typename R> struct RowArgs {
     const double* wpartial;
     int n_wpartial;
     R* wscale;
+    int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
 };
 
 template <typename R, int N, int MODE>
@@ -214,8 +210,16 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
     const unsigned gh_step = (unsigned)T * g.Sh;
     const int c_lane = j - g.c0;   // SLM column of element m is c_lane + m*T
 
+    // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
+    // assumption): give the four rows that share each 128-byte GH line to four blocks of the same
+    // XCD that start together, so the partial-line accesses meet in that XCD's L2.
+    int first = blockIdx.x * FPW;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        first = 4 * ((idx >> 2) * 8 + xcd) + (idx & 3);
+    }
 #pragma unroll 1
-    for (int rbase = blockIdx.x * FPW; rbase < g.Sh; rbase += gridDim.x * FPW) {
+    for (int rbase = first; rbase < g.Sh; rbase += gridDim.x * FPW) {
         const int r = rbase + f;
         const bool valid = r < g.Sh;
         const int rr = valid ? r : 0;
@@ -582,6 +586,173 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     if (cp.do_update) {
         const double s = block_sum((double)acc_w, scratch);
         if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// =====================================================================================================
+// FUSED column kernel, tile-resident form (N >= 4096, fp32): same math as col_fused_kernel, but the
+// whole 4-column tile of GH (only its NR*T candidate rows) is loaded ONCE with 32-byte-per-lane
+// accesses into registers, the four columns are transformed from/to those registers, and the tile
+// is stored back with 32-byte accesses -- every GH byte crosses the memory system once per kernel.
+//
+// The SLM rows start at r0, i.e. at register slot m0 = r0/T of the load layout.  A circular shift
+// of the transform input by s = m0*T rows makes the occupied slots 0..NR-1 for every geometry
+// (static register indices); by the shift theorem it multiplies output k by exp(-2 pi i k m0/16),
+// which is a per-lane constant (k = j mod 16 in load layout) folded into the scale multiply.
+// =====================================================================================================
+// one tile row = 4 adjacent columns = 32 bytes (fp32): two 16-byte accesses per lane
+__device__ __forceinline__ void load_row4(const Cx<float>* p, Cx<float> (&o)[4]) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1];
+    o[0] = mk<float>(a.x, a.y); o[1] = mk<float>(a.z, a.w);
+    o[2] = mk<float>(b.x, b.y); o[3] = mk<float>(b.z, b.w);
+}
+__device__ __forceinline__ void store_row4(Cx<float>* p, const Cx<float> (&o)[4]) {
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    q[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+}
+
+// issue (do not wait for) the weight / target loads of one column into registers
+template <typename R, int T>
+__device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R* __restrict__ tc, bool upd, int j,
+                                               R (&wr)[16], R (&tr)[16]) {
+    static_for<0, 16>([&](auto m_) {
+        constexpr int m = m_;
+        wr[m] = wc[(unsigned)(j + m * T)];
+        tr[m] = upd ? tc[(unsigned)(j + m * T)] : (R)0;
+    });
+}
+
+template <typename R, int N, int PHASE, int NR>
+__global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
+    using M = Math<R>;
+    constexpr int T = N / 16;
+    static_assert(T >= 256, "tile-resident kernel is for one column per workgroup pass");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo g = a.g;
+    const int j = threadIdx.x;
+    const int b = blockIdx.y;
+    Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem);
+    double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
+
+    WgFft<R, N> fft;
+    fft.init(a.tw, j);
+    const CParams<R> cp = a.cp;
+    const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const size_t P = (size_t)g.Ph * g.Pw;
+    const R wsc = a.wscale[b];
+    // shift-theorem factor of this lane, with the (-1)^k sign and the ortho scale folded in
+    Cx<R> om = a.tw[((m0 * (j & 15)) & 15) * (N / 16)];
+    om = om * (sgn * a.scale);
+    const int r_lane = j + m0 * T - g.r0;   // SLM row of slot m is r_lane + m*T
+    const int ntiles = g.Pw / 4;
+    R acc_w = 0;
+
+    Cx<R> v[16];
+    Cx<R> gt[NR][4];
+    R wr[16], tr[16];
+
+    const bool upd = cp.do_update != 0;
+    const R* wbase = a.w + (size_t)b * P;
+    const R* tbase = a.t + (size_t)b * P;
+
+#pragma unroll 1
+    for (int ct = blockIdx.x; ct < ntiles; ct += gridDim.x) {
+        Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+        static_for<0, NR>([&](auto m_) {
+            constexpr int m = m_;
+            const int r = r_lane + m * T;
+            gt[m][0] = gt[m][1] = gt[m][2] = gt[m][3] = mk<R>(0, 0);
+            if (r >= 0 && r < g.Sh) load_row4(gh + (unsigned)r * 4u, gt[m]);
+        });
+        if (ct == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
+            issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c) * g.Ph;
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                if constexpr (m < NR) {
+                    Cx<R> x = gt[m][0];
+                    x = (c == 1) ? gt[m][1] : x;
+                    x = (c == 2) ? gt[m][2] : x;
+                    x = (c == 3) ? gt[m][3] : x;
+                    v[m] = x * sgn;
+                } else {
+                    v[m] = mk<R>(0, 0);
+                }
+            });
+            fft.template run<-1>(v, lds, j);
+
+            R* wc = a.w + cb;
+            R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                const unsigned idx = (unsigned)(j + m * T);
+                const Cx<R> F = cmul(v[m], om);
+                const R p2 = F.x * F.x + F.y * F.y;
+                const R wraw = wr[m];
+                R wv = wraw * wsc;
+                if (cp.do_update) {
+                    const R t = tr[m];
+                    if (cp.method == M_LEONARDO || cp.method == M_KIM) {
+                        if (t != (R)0) {
+                            R fc = M::exp2(-cp.p_exp * ((R)0.5 * M::log2(p2) + cp.log2_inv_fnorm - M::log2(t)));
+                            if (!(fc < (R)INFINITY)) fc = 1;
+                            wv *= fc;
+                        }
+                    } else {
+                        wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, (R)0);
+                    }
+                    if (is_nan(wv)) wv = (R)0.0001;
+                    if (wv != wraw) wc[idx] = wv;
+                    acc_w += wv * wv;
+                }
+                Cx<R> ph;
+                if constexpr (PHASE == 2) {
+                    M::sincos(pfc[idx], &ph.y, &ph.x);
+                } else {
+                    if (p2 > (R)0) {
+                        const R inv = M::rsqrt(p2);
+                        ph = mk<R>(F.x * inv, F.y * inv);
+                    } else {
+                        ph = mk<R>(1, 0);
+                    }
+                    if constexpr (PHASE == 1) pfc[idx] = M::atan2(F.y, F.x);
+                }
+                // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
+                v[m] = cmulc(ph, om) * wv;
+                if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            });
+            // weights/target of the next column (or of the first column of the next tile) land
+            // under the inverse transform below and the next forward transform
+            {
+                const int nct = (c < 3) ? ct : ct + (int)gridDim.x;
+                const int ncol = nct * 4 + ((c + 1) & 3);
+                if (nct < ntiles)
+                    issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, upd, j, wr, tr);
+            }
+
+            fft.template run<+1>(v, lds, j);
+            static_for<0, NR>([&](auto m_) {
+                constexpr int m = m_;
+                const Cx<R> h = v[m] * (sgn * a.scale);
+                gt[m][0] = (c == 0) ? h : gt[m][0];
+                gt[m][1] = (c == 1) ? h : gt[m][1];
+                gt[m][2] = (c == 2) ? h : gt[m][2];
+                gt[m][3] = (c == 3) ? h : gt[m][3];
+            });
+        }
+        static_for<0, NR>([&](auto m_) {
+            constexpr int m = m_;
+            const int r = r_lane + m * T;
+            if (r >= 0 && r < g.Sh) store_row4(gh + (unsigned)r * 4u, gt[m]);
+        });
+    }
+    if (cp.do_update) {
+        const double s = block_sum((double)acc_w, scratch);
+        if (j == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }
 }
 

@@ -40,4 +40,38 @@ template <> int launch_fused<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t 
     return (int)hipErrorInvalidValue;
 }
 
+#ifdef HGS_REAL_IS_FLOAT
+template <int N, int PHASE>
+static int launch_tile_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    constexpr size_t lds = (size_t)lds_elems<N>() * sizeof(Cx<float>) + 16 * sizeof(double);
+    auto k = col_tile_kernel<float, N, PHASE, 6>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
+    return (int)hipGetLastError();
+}
+
+template <> int launch_tile<float>(int N, int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    if (N == 4096) {
+        if (phase == 0) return launch_tile_one<4096, 0>(grid, s, a, m0);
+        if (phase == 1) return launch_tile_one<4096, 1>(grid, s, a, m0);
+        return launch_tile_one<4096, 2>(grid, s, a, m0);
+    }
+    if (N == 8192) {
+        if (phase == 0) return launch_tile_one<8192, 0>(grid, s, a, m0);
+        if (phase == 1) return launch_tile_one<8192, 1>(grid, s, a, m0);
+        return launch_tile_one<8192, 2>(grid, s, a, m0);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+#else
+template <> int launch_tile<double>(int, int, dim3, hipStream_t, const ColArgs<double>&, int) {
+    return (int)hipErrorInvalidValue;   // the tile-resident kernel is fp32 only
+}
+#endif
+
 }  // namespace hgs
