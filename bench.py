@@ -156,7 +156,8 @@ def main():
                 except Exception:
                     traffic = None
             rowk = prof["row"]
-            roof = {"bound": "hbm", "kernel": "col_kernel<float,4096,FWD|CONS|INV>", "achieved": achieved / 1e9,
+            roof = {"bound": "hbm", "kernel": "fused column kernel (col_tile_kernel<float,N,PHASE,6> / col_fused_kernel)",
+                    "achieved": achieved / 1e9,
                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                     "launch_us": dur * 1e6, "launches": col["launches"],
                     "algorithmic_bytes_per_launch": alg,

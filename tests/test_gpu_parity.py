@@ -298,6 +298,25 @@ def test_cfg2_spot_4096_matches_reference():
     assert abs(float(np.sqrt(np.sum(amp_ff.astype(float) ** 2))) - float(gold["ampff_norm"])) < 1e-5
 
 
+def test_cfg2_kim_4096_matches_reference():
+    """Headline geometry with WGS-Kim (phase fixed at iteration 10), 30 it, vs the recorded reference run."""
+    meta, gold = load_golden("cfg2kim_summary")
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    h = SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm,
+                                            phase=synth.seed_phase(9, slm))
+    h.optimize("WGS-Kim", maxiter=30, verbose=False)
+    assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    errs = dict(spot_amp=rel_l2(h.amp_ff[ky, kx], gold["spot_ampff"]),
+                spot_weights=rel_l2(h.weights[ky, kx], gold["spot_weights"]),
+                amp_sub=rel_l2(h.amp_ff[::16, ::16], gold["ampff_sub"]),
+                phase_sub=phase_rel_l2(h.phase[::6, ::6], gold["phase_sub"]))
+    report("cfg2 WGS-Kim 30 it vs reference", **errs)
+    assert errs["spot_amp"] < 1e-5 and errs["amp_sub"] < 1e-4 and errs["spot_weights"] < 1e-4
+    assert errs["phase_sub"] < 3e-4
+    h.optimize("WGS-Kim", maxiter=1, verbose=False, stat_groups=["computational_spot"])
+
+
 # ---- size-independent properties at full size -------------------------------------------------------------
 def test_parseval_and_linearity_full_size():
     """||farfield|| = ||nearfield|| = 1 (ortho transforms, unit-norm amp) at 4096^2 and 8192^2 pads."""
