@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="independent holograms per GPU")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--method", default="WGS-Leonardo")
-    ap.add_argument("--cpu-iters", type=int, default=6, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=16, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     return ap.parse_args()
 

@@ -168,7 +168,7 @@ template <typename R> struct Engine : EngineBase {
         // grid sizes: enough workgroups to fill the chip a few times over, balanced over the work
         const int fpw = row_fpw(g.Pw);
         const int row_units = (g.Sh + fpw - 1) / fpw;
-        int cap = env_int("HGS_ROW_BLOCKS", n_cu * 4);
+        int cap = env_int("HGS_ROW_BLOCKS", n_cu * 8);
         cap = cap / B > 0 ? cap / B : 1;
         int per = (row_units + cap - 1) / cap;
         row_blocks = (row_units + per - 1) / per;

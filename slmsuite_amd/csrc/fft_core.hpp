@@ -186,14 +186,43 @@ template <int N> constexpr int lds_elems() { return N + N / 16; }
 // `lds` points at this transform's private region of lds_elems<N>() complex elements.
 // All T = N/16 lanes of the transform (and every other lane of the workgroup) must call run():
 // it contains __syncthreads().
-template <typename R, int N> struct WgFft {
+// RESIDENT = true : stage twiddles are fetched once (init) and stay in VGPRs -- for kernels that run
+//                   many transforms per workgroup (the column kernels).
+// RESIDENT = false: they are fetched from the (L1/L2-resident) table right before each use, which
+//                   frees ~24 VGPRs -- for kernels that are occupancy-bound (the row kernels).
+template <typename R, int N, bool RESIDENT = true> struct WgFft {
     static constexpr int E = 16;
     static constexpr int T = N / 16;
-    static constexpr int NTW = tw_count<N>() > 0 ? tw_count<N>() : 1;
+    static constexpr int NTW = RESIDENT ? (tw_count<N>() > 0 ? tw_count<N>() : 1) : 1;
     Cx<R> tw[NTW];
+    const Cx<R>* table_ = nullptr;
 
     // table[i] = exp(-2*pi*i*i/N), i < N  (forward sign)
     __device__ __forceinline__ void init(const Cx<R>* __restrict__ table, int j) {
+        table_ = table;
+        if constexpr (RESIDENT) load_stage_twiddles_all(table, j);
+    }
+
+    // twiddle q of stage s for butterfly b (same indexing as the resident array)
+    template <int s, int IDX> __device__ __forceinline__ Cx<R> twv(int j) const {
+        if constexpr (RESIDENT) {
+            return tw[tw_offset<N, s>() + IDX];
+        } else {
+            constexpr int RAD = Sched<N>::r[s];
+            constexpr int NS = sched_ns<N, s>();
+            constexpr int STEP = N / (NS * RAD);
+            if constexpr (RAD == 16) {
+                constexpr int q = IDX < 3 ? 4 * (IDX + 1) : (IDX - 3 + 1);
+                return table_[(q * (j % NS) * STEP) & (N - 1)];
+            } else {
+                constexpr int B = E / RAD;
+                constexpr int b = IDX / (RAD - 1), r = IDX % (RAD - 1) + 1;
+                return table_[(r * ((j + b * T) % NS) * STEP) & (N - 1)];
+            }
+        }
+    }
+
+    __device__ __forceinline__ void load_stage_twiddles_all(const Cx<R>* __restrict__ table, int j) {
         static_for<1, Sched<N>::S>([&](auto s_) {
             constexpr int s = s_;
             constexpr int RAD = Sched<N>::r[s];
@@ -225,7 +254,17 @@ template <typename R, int N> struct WgFft {
     // LDS position of logical element q of the current exchange, relative to a padded base:
     // pad(base + d) == pad(base) + d + d/16 whenever d % 16 == 0 or (base % 16 == 0 and d < 16),
     // which lets every ds_write/ds_read of a stage use one address VGPR + immediate offsets.
-    template <int DIR, int s> __device__ __forceinline__ void stage(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+    // PING-PONG (DB = true): consecutive exchanges alternate between two LDS images, which makes the
+    // barrier after the gather unnecessary (a lane can only overwrite image A again after it passed
+    // the barrier of the exchange on image B, which every lane reaches after finishing its reads of
+    // A).  `par` is the running exchange parity of this workgroup; LDS need is 2 * lds_elems<N>().
+    int par = 0;
+    template <int DIR, int s, bool DB = false> __device__ __forceinline__ void stage(Cx<R> (&v)[16], Cx<R>* lds0, int j) {
+        Cx<R>* lds = lds0;
+        if constexpr (DB && s != Sched<N>::S - 1) {
+            lds = lds0 + (par ? lds_elems<N>() : 0);
+            par ^= 1;
+        }
         constexpr int RAD = Sched<N>::r[s];
         constexpr int B = E / RAD;
         constexpr int NS = sched_ns<N, s>();
@@ -239,15 +278,17 @@ template <typename R, int N> struct WgFft {
                     constexpr int r2 = r2_;
                     static_for<0, 4>([&](auto r1_) {
                         constexpr int r = r1_ + 4 * r2;
-                        u[r] = DIR < 0 ? cmul(u[r], tw[OFF + r2 - 1]) : cmulc(u[r], tw[OFF + r2 - 1]);
+                        const Cx<R> w = this->template twv<s, r2 - 1>(j);
+                        u[r] = DIR < 0 ? cmul(u[r], w) : cmulc(u[r], w);
                     });
                 });
-                Dft<16, DIR, R>::template run_tw<true>(u, &tw[OFF + 3]);
+                Cx<R> bt[3] = {this->template twv<s, 3>(j), this->template twv<s, 4>(j), this->template twv<s, 5>(j)};
+                Dft<16, DIR, R>::template run_tw<true>(u, bt);
             } else {
                 if constexpr (s > 0) {
                     static_for<1, RAD>([&](auto r_) {
                         constexpr int r = r_;
-                        const Cx<R> w = tw[OFF + b * (RAD - 1) + (r - 1)];
+                        const Cx<R> w = this->template twv<s, b * (RAD - 1) + (r - 1)>(j);
                         u[r] = DIR < 0 ? cmul(u[r], w) : cmulc(u[r], w);
                     });
                 }
@@ -281,14 +322,14 @@ template <typename R, int N> struct WgFft {
             } else {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = lds[lds_pad(j + m * T)]; });
             }
-            __syncthreads();
+            if constexpr (!DB) __syncthreads();
         }
     }
 
-    template <int DIR> __device__ __forceinline__ void run(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+    template <int DIR, bool DB = false> __device__ __forceinline__ void run(Cx<R> (&v)[16], Cx<R>* lds, int j) {
         static_for<0, Sched<N>::S>([&](auto s_) {
             constexpr int s = s_;
-            this->template stage<DIR, s>(v, lds, j);
+            this->template stage<DIR, s, DB>(v, lds, j);
         });
     }
 };

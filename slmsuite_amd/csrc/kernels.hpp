@@ -24,6 +24,12 @@
 #ifndef HGS_COL_OCC
 #define HGS_COL_OCC 3
 #endif
+#ifndef HGS_ROW_TW_RESIDENT
+#define HGS_ROW_TW_RESIDENT true
+#endif
+#ifndef HGS_TILE_DB
+#define HGS_TILE_DB false
+#endif
 #ifndef HGS_FUSED_OCC
 #define HGS_FUSED_OCC 2
 #endif
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
         __syncthreads();
     }
 
-    WgFft<R, N> fft;
+    WgFft<R, N, HGS_ROW_TW_RESIDENT> fft;
     fft.init(a.tw, j);
 
     const R sgn = (j & 1) ? (R)-1 : (R)1;  // (-1)^(j + m*T), T even
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     const int j = threadIdx.x;
     const int b = blockIdx.y;
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem);
-    double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
+    double* scratch = reinterpret_cast<double*>(lds + (HGS_TILE_DB ? 2 : 1) * lds_elems<N>());
 
     WgFft<R, N> fft;
     fft.init(a.tw, j);
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     v[m] = mk<R>(0, 0);
                 }
             });
-            fft.template run<-1>(v, lds, j);
+            fft.template run<-1, HGS_TILE_DB>(v, lds, j);
 
             R* wc = a.w + cb;
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, upd, j, wr, tr);
             }
 
-            fft.template run<+1>(v, lds, j);
+            fft.template run<+1, HGS_TILE_DB>(v, lds, j);
             static_for<0, NR>([&](auto m_) {
                 constexpr int m = m_;
                 const Cx<R> h = v[m] * (sgn * a.scale);
