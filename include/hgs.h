@@ -49,6 +49,10 @@ typedef struct {
     int32_t real_bytes;  /* 4 | 8                                                       */
     int32_t batch;       /* independent holograms advanced together        */
     int32_t n_spots;     /* > 0 enables spot-window / external-spot feedback            */
+    int32_t kind;        /* 0: padded DFT grid (Hologram / SpotHologram);
+                            1: CompressedSpotHologram (_spots.py:178-1018): n_spots free-floating
+                               spots with polynomial phase kernels, no padded grid (pad_* ignored) */
+    int32_t n_monomials; /* kind 1: monomials x^px y^py of the kernel phase polynomial  */
 } hgs_config;
 
 /* ALGORITHM_INDEX (_header.py:72) */
@@ -90,7 +94,12 @@ enum {
     HGS_SPOT_INDEX = 9,   /* int32 [2][n_spots] (kx row 0, ky row 1)  spot_knm_rounded   */
     HGS_SPOT_AMP = 10,    /* double [n_spots]                SpotHologram.spot_amp       */
     HGS_EXTERNAL_AMP = 11,/* double [n_spots]                external_spot_amp           */
-    HGS_ZERO_WEIGHTS = 12 /* [batch][pad_h][pad_w] complex   dense image of zero_weights */
+    HGS_ZERO_WEIGHTS = 12,/* [batch][pad_h][pad_w] complex   dense image of zero_weights */
+    /* kind 1 (CompressedSpotHologram); TARGET/WEIGHTS/PHASE_FF/FARFIELD/AMP_FF are [batch][n_spots] */
+    HGS_XGRID = 13,       /* [slm_h][slm_w] real   slm.grid[0] * zernike scaling (_spots.py:614-618) */
+    HGS_YGRID = 14,       /* [slm_h][slm_w] real   slm.grid[1] * zernike scaling                     */
+    HGS_MONOMIALS = 15,   /* int32 [n_monomials][2] (px, py)   phase._zernike_get_cantor terms       */
+    HGS_SPOT_COEFF = 16   /* real [n_monomials][n_spots]       ... and weights (phase.py:850-920)    */
 };
 
 int hgs_create(const hgs_config* cfg, hgs_engine** out);

@@ -535,3 +535,165 @@ def rectangular_array(shape, array_shape, array_pitch, array_center=None):
     ye = (np.arange(array_shape[1]) - (array_shape[1] - 1) / 2.0) * array_pitch[1] + array_center[1]
     xg, yg = np.meshgrid(xe, ye, sparse=False, indexing="xy")
     return np.vstack((xg.ravel(), yg.ravel()))
+
+
+# ======================================================================================
+# CompressedSpotHologram path: non-uniform DFT with per-spot Zernike kernels
+# ======================================================================================
+def ansi_to_radial(j):
+    """ANSI single index -> (n, l).  phase.zernike_convert_index (phase.py:570-680)."""
+    j = int(j)
+    n = int(np.ceil((-3 + np.sqrt(9 + 8 * j)) / 2))
+    return n, 2 * j - n * (n + 2)
+
+
+def zernike_cartesian(j):
+    """
+    Integer coefficients {(px, py): c} of the un-normalised real Zernike polynomial of ANSI index j
+    (value +-1 at the pupil edge; Z1 = y, Z2 = x, Z4 = 2x^2 + 2y^2 - 1), as produced by
+    phase._zernike_coefficients (phase.py:1357-1442).  Independent derivation:
+    R_n^|l|(r) = sum_s (-1)^s (n-s)! / (s! ((n+|l|)/2-s)! ((n-|l|)/2-s)!) r^(n-2s), times
+    Re/Im (x+iy)^|l| for l >= 0 / l < 0, with r^2k = (x^2+y^2)^k expanded binomially.
+    """
+    from math import comb, factorial
+    n, l = ansi_to_radial(j)
+    al = abs(l)
+    out = {}
+    for s in range((n - al) // 2 + 1):
+        rc = (-1) ** s * factorial(n - s) // (factorial(s) * factorial((n + al) // 2 - s) * factorial((n - al) // 2 - s))
+        k = (n - 2 * s - al) // 2                       # r^(n-2s) = r^al * (x^2+y^2)^k
+        for t in range(k + 1):                          # (x^2+y^2)^k = sum_t C(k,t) x^(2(k-t)) y^(2t)
+            for q in range(al + 1):                     # (x+iy)^al = sum_q C(al,q) x^(al-q) (iy)^q
+                if (l >= 0 and q % 2 == 1) or (l < 0 and q % 2 == 0):
+                    continue
+                sign = (-1) ** (q // 2)                 # i^q: real part for even q, imaginary for odd q
+                key = (al - q + 2 * (k - t), q + 2 * t)
+                out[key] = out.get(key, 0) + rc * comb(k, t) * comb(al, q) * sign
+    return {k: v for k, v in out.items() if v != 0}
+
+
+def zernike_basis_default(D):
+    """phase._zernike_indices_parse(None, D) (phase.py:923-961): [2,1], [2,1,4], [2,1,4,3,5,...]."""
+    if D == 2:
+        return np.array([2, 1])
+    if D == 3:
+        return np.array([2, 1, 4])
+    if D == 4:
+        return np.array([2, 1, 4, 3])
+    return np.hstack((np.array([2, 1, 4, 3]), np.arange(5, D + 1)))
+
+
+def cantor_pairing(px, py):
+    return (px + py) * (px + py + 1) // 2 + py
+
+
+def monomial_weights(basis, spot_zernike):
+    """
+    (terms [M,2], weights [M,N]): phi_n = sum_m weights[m,n] x^terms[m,0] y^terms[m,1].
+    phase._zernike_get_cantor (phase.py:850-920): monomials in ascending Cantor order.
+    """
+    a = np.asarray(spot_zernike, dtype=float)
+    acc = {}
+    for d, idx in enumerate(np.ravel(basis)):
+        if int(idx) < 0:
+            raise NotImplementedError("vortex pseudo-index -1")
+        for key, c in zernike_cartesian(int(idx)).items():
+            acc[key] = acc.get(key, 0) + c * a[d]
+    keys = sorted(acc, key=lambda k: cantor_pairing(*k))
+    return np.array(keys, dtype=int).reshape(-1, 2), np.array([acc[k] for k in keys], dtype=float).reshape(len(keys), -1)
+
+
+def compressed_kernel(xg, yg, terms, weights, ctype):
+    """
+    K[n, p] = exp(i phi_n(p)) / sqrt(S) in the hologram's complex dtype.
+    _build_cupy_kernel_batched (_spots.py:595-636) + phase.polynomial (phase.py:1672-1795):
+    the grids are cast to the complex dtype and the monomial sum is accumulated in that precision.
+    """
+    x = np.asarray(xg).astype(ctype)
+    y = np.asarray(yg).astype(ctype)
+    N = weights.shape[1]
+    out = np.zeros((N,) + x.shape, dtype=ctype)
+    w = weights.astype(ctype)
+    for m, (px, py) in enumerate(terms):
+        mono = np.ones_like(x)
+        for _ in range(px):
+            mono *= x
+        for _ in range(py):
+            mono *= y
+        for n in range(N):
+            if w[m, n] != 0:
+                out[n] += w[m, n] * mono
+    out = out.reshape(N, -1)
+    out *= ctype(1j)
+    np.exp(out, out=out)
+    out /= np.sqrt(out.shape[1])
+    return out
+
+
+class OracleCompressedSpotHologram(OracleHologram):
+    """
+    N free-floating spots with per-spot Zernike kernels, no padded grid (CompressedSpotHologram,
+    _spots.py:178-1018).  Inputs are taken after unit conversion: ``spot_zernike`` [D,N] in Zernike
+    radians, the pupil-scaled grids ``xg``, ``yg`` [H,W] (slm.grid * zernike scaling, :614-618).
+    """
+
+    def __init__(self, spot_zernike, xg, yg, zernike_basis=None, spot_amp=None, amp=None, phase=None,
+                 dtype=np.float32, **flags):
+        self.spot_zernike = np.asarray(spot_zernike, dtype=float)
+        D, N = self.spot_zernike.shape
+        self.zernike_basis = zernike_basis_default(D) if zernike_basis is None else np.ravel(zernike_basis)
+        self.xg, self.yg = np.asarray(xg, dtype=float), np.asarray(yg, dtype=float)
+        self.spot_amp = np.full(N, 1.0 / np.sqrt(N)) if spot_amp is None else np.array(spot_amp)
+        slm_shape = self.xg.shape
+        super().__init__(slm_shape, amp=amp, phase=phase, slm_shape=slm_shape, dtype=dtype, **flags)
+        self.set_target_spots(self.spot_amp)
+        self.reset()
+        self.external_spot_amp = np.ones(self.target.shape)
+        self._kernel = None
+
+    def set_target_spots(self, new_target):       # set_target :917-947
+        self.target = np.array(new_target, dtype=self.dtype)
+        np.abs(self.target, out=self.target)
+        self.target *= 1 / l2norm(self.target)
+
+    def reset(self):
+        super().reset()
+        self.nearfield = np.zeros(self.slm_shape, dtype=self.ctype)
+        self.farfield = np.zeros(self.target.shape, dtype=self.ctype)
+
+    def kernel(self):
+        if self._kernel is None:
+            terms, weights = monomial_weights(self.zernike_basis, self.spot_zernike)
+            self._kernel = compressed_kernel(self.xg, self.yg, terms, weights, self.ctype)
+        return self._kernel
+
+    def nearfield2farfield(self):                 # _nearfield2farfield_cupy :767-824
+        nf = self.build_nearfield()
+        K = self.kernel()
+        ff = np.conj(K @ np.conj(nf).ravel())
+        ff *= 1 / l2norm(ff)
+        self.farfield = ff.astype(self.ctype)
+        self.amp_ff = np.abs(self.farfield, out=self.amp_ff)
+
+    def farfield2nearfield(self):                 # _farfield2nearfield_cupy :887-914
+        K = self.kernel()
+        self.nearfield = (self.farfield[np.newaxis, :] @ K).reshape(self.slm_shape).astype(self.ctype)
+        self.phase = np.arctan2(self.nearfield.imag, self.nearfield.real, out=self.phase)
+        if self.propagation_kernel is not None:
+            self.phase -= self.propagation_kernel
+
+    def update_weights(self):                     # _update_weights :950-989
+        fb = self.flags["feedback"]
+        if fb == "computational":
+            fb = self.flags["feedback"] = "computational_spot"
+        if fb == "computational_spot":
+            amp_fb = self.amp_ff
+        elif fb == "external_spot":
+            amp_fb = self.external_spot_amp
+        else:
+            raise ValueError(f"Feedback '{fb}' not recognized.")
+        update_weights_generic(self.weights, np.array(amp_fb, dtype=self.dtype), self.target,
+                               self.flags["method"], self.flags, self.dtype)
+
+    def compute_stats(self, stat_groups):         # _update_stats :1004-1018 ignores computational_spot
+        return {}

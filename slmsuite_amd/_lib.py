@@ -15,14 +15,14 @@ HGS_OK, HGS_ERR_ARG, HGS_ERR_DEVICE, HGS_ERR_STATE, HGS_ERR_UNSUPPORTED = 0, -1,
 
 # array selectors (include/hgs.h)
 (PHASE, AMP, AMP_SCALAR, PROP_KERNEL, TARGET, WEIGHTS, PHASE_FF, FARFIELD, AMP_FF, SPOT_INDEX,
- SPOT_AMP, EXTERNAL_AMP, ZERO_WEIGHTS) = range(13)
+ SPOT_AMP, EXTERNAL_AMP, ZERO_WEIGHTS, XGRID, YGRID, MONOMIALS, SPOT_COEFF) = range(17)
 FB_PIXEL, FB_SPOT_WINDOW, FB_EXTERNAL = 0, 1, 2
 K_NAMES = ("row", "col_fused", "col_fwd", "col_inv", "elementwise")
 
 
 class hgs_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("device", "pad_h", "pad_w", "slm_h", "slm_w", "real_bytes", "batch", "n_spots")]
+                ("device", "pad_h", "pad_w", "slm_h", "slm_w", "real_bytes", "batch", "n_spots", "kind", "n_monomials")]
 
 
 class hgs_step(C.Structure):

@@ -13,6 +13,7 @@
 
 #include "../../include/hgs.h"
 #include "launch.hpp"
+#include "compressed_kernels.hpp"
 
 namespace hgs {
 
@@ -93,6 +94,18 @@ template <typename R> struct Engine : EngineBase {
     double* spot_amp = nullptr;
     double* ext_amp = nullptr;
     R* spot_fb = nullptr;
+    // kind 1 (compressed)
+    R* xg = nullptr;
+    R* yg = nullptr;
+    int* mono = nullptr;
+    R* coeff = nullptr;
+    Cx<R>* cpartial = nullptr;
+    double* cnorm = nullptr;
+    R* ext_r = nullptr;
+    int c_nblocks = 0, c_degree = -1, c_rows = 0;
+    std::vector<int32_t> mono_host;
+    std::vector<R> coeff_host;
+    bool has_grid[2] = {false, false}, has_mono = false, has_coeff = false;
     // host state
     double amp_scalar = 0, amp_norm2 = 1.0;
     bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
@@ -109,7 +122,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -149,6 +162,8 @@ template <typename R> struct Engine : EngineBase {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, c.device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (c.kind == 1) return init_compressed(c);
+        if (c.kind != 0) return fail(HGS_ERR_ARG, "unknown engine kind %d", c.kind);
         if (!is_pow2(c.pad_h) || !is_pow2(c.pad_w) || c.pad_h < 64 || c.pad_w < 64 || c.pad_h > 8192 ||
             c.pad_w > 8192)
             return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d) must be powers of two in [64, 8192]",
@@ -189,7 +204,7 @@ template <typename R> struct Engine : EngineBase {
         if (dalloc(&wpartial, (size_t)B * std::max(col_blocks, tile_blocks))) return HGS_ERR_DEVICE;
         if (dalloc(&fpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
-        if (dalloc(&sums, (size_t)3 * B)) return HGS_ERR_DEVICE;
+        if (dalloc(&sums, (size_t)4 * B)) return HGS_ERR_DEVICE;
         if (dalloc(&wscale, (size_t)B)) return HGS_ERR_DEVICE;
         if (int e = fill_wscale_one()) return e;
         if (int e = make_twiddles(&tw_row, g.Pw)) return e;
@@ -204,6 +219,123 @@ template <typename R> struct Engine : EngineBase {
         amp_norm2 = 1.0;
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
+    }
+
+    int init_compressed(const hgs_config& c) {
+        if (c.n_spots < 1 || c.n_monomials < 1 || c.slm_h < 1 || c.slm_w < 1 || c.batch < 1)
+            return fail(HGS_ERR_ARG, "compressed engine needs n_spots, n_monomials, slm shape and batch >= 1");
+        g.Sh = c.slm_h; g.Sw = c.slm_w; g.r0 = g.c0 = 0;
+        g.Ph = c.n_spots; g.Pw = 1;      // farfield-sized arrays are N-vectors; the transposes degenerate
+        g.batch = B = c.batch;
+        S = (size_t)g.Sh * g.Sw;
+        P = (size_t)c.n_spots;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        c_nblocks = (int)((S + (size_t)C_WG * C_PT - 1) / ((size_t)C_WG * C_PT));
+        col_blocks = 1; tile_blocks = 1; row_blocks = 1;
+        ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
+        c_rows = std::max(6, c.n_monomials);
+        if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
+        if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&xg, S)) return HGS_ERR_DEVICE;
+        if (dalloc(&yg, S)) return HGS_ERR_DEVICE;
+        if (dalloc(&mono, (size_t)2 * c.n_monomials)) return HGS_ERR_DEVICE;
+        if (dalloc(&coeff, (size_t)c_rows * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&cpartial, (size_t)B * c_nblocks * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&cnorm, (size_t)B * ((P + 255) / 256))) return HGS_ERR_DEVICE;
+        if (dalloc(&ext_amp, P)) return HGS_ERR_DEVICE;
+        if (dalloc(&ext_r, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&wpartial, (size_t)B)) return HGS_ERR_DEVICE;
+        if (dalloc(&fpartial, (size_t)B)) return HGS_ERR_DEVICE;
+        if (dalloc(&sums, (size_t)4 * B)) return HGS_ERR_DEVICE;
+        if (dalloc(&wscale, (size_t)B)) return HGS_ERR_DEVICE;
+        if (int e = fill_wscale_one()) return e;
+        amp_scalar = 1.0 / std::sqrt((double)S);
+        amp_norm2 = 1.0;
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    // repack the monomial weights for the degree-specialised kernels (canonical [1,x,y,x2,xy,y2])
+    int pack_coeff() {
+        if (!has_mono || !has_coeff) return 0;
+        const int M = cfg.n_monomials, N = cfg.n_spots;
+        c_degree = 0;
+        for (int m = 0; m < M; ++m) c_degree = std::max(c_degree, mono_host[2 * m] + mono_host[2 * m + 1]);
+        for (int m = 0; m < M; ++m)
+            if (mono_host[2 * m] < 0 || mono_host[2 * m + 1] < 0)
+                return fail(HGS_ERR_UNSUPPORTED, "negative monomial powers (vortex pseudo-term) are not supported");
+        if (c_degree <= 2) {
+            std::vector<R> c6((size_t)6 * N, (R)0);
+            for (int m = 0; m < M; ++m) {
+                const int px = mono_host[2 * m], py = mono_host[2 * m + 1];
+                const int slot = (px == 0 && py == 0) ? 0 : (px == 1 && py == 0) ? 1 : (px == 0 && py == 1) ? 2
+                                 : (px == 2) ? 3 : (px == 1) ? 4 : 5;
+                for (int n = 0; n < N; ++n) c6[(size_t)slot * N + n] += coeff_host[(size_t)m * N + n];
+            }
+            HIPCHK(hipMemcpy(coeff, c6.data(), c6.size() * sizeof(R), hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(hipMemcpy(coeff, coeff_host.data(), (size_t)M * N * sizeof(R), hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+
+    CArgs<R> cargs() {
+        CArgs<R> a{};
+        a.S = (int)S; a.N = cfg.n_spots; a.M = cfg.n_monomials; a.batch = B; a.xg = xg; a.yg = yg; a.mono = mono;
+        a.coeff = coeff; a.phase = phase; a.amp = has_amp ? amp : nullptr; a.kern = has_kern ? kern : nullptr;
+        a.amp_scalar = (R)amp_scalar; a.ff = ff; a.amp_ff = aff; a.partial = cpartial; a.nblocks = c_nblocks;
+        a.fsum = sums + 0 * B; a.degree = c_degree;
+        return a;
+    }
+    int compressed_ready() {
+        if (!has_grid[0] || !has_grid[1] || !has_mono || !has_coeff)
+            return fail(HGS_ERR_STATE, "compressed engine needs HGS_XGRID, HGS_YGRID, HGS_MONOMIALS and HGS_SPOT_COEFF");
+        return 0;
+    }
+    int n2f_compressed(int store_pff) {
+        if (int e = compressed_ready()) return e;
+        if (int e = need_ff()) return e;
+        if (store_pff) { if (int e = need_pff()) return e; }
+        const int nred = (int)((P + 255) / 256);
+        int r = timed(HGS_K_COL_FWD, [&]() -> int {
+            CArgs<R> a = cargs();
+            const dim3 grid(c_nblocks, B);
+            if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a);
+            else if (c_degree == 2) hipLaunchKernelGGL((c_n2f_partial<R, 2>), grid, dim3(C_WG), 0, stream, a);
+            else hipLaunchKernelGGL((c_n2f_partial<R, 0>), grid, dim3(C_WG), 0, stream, a);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(c_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, a, cnorm);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(256), 0, stream, a, (const double*)cnorm, nred);
+            HIPCHK(hipGetLastError());
+            return 0;
+        });
+        if (r) return r;
+        if (store_pff) {
+            EwArgs<R> a{};
+            a.P = P; a.batch = B; a.ff = ff; a.pff = pff;
+            hipLaunchKernelGGL(ew_store_phase<R>, dim3(ew_blocks, B), dim3(256), 0, stream, a);
+            HIPCHK(hipGetLastError());
+            have_pff = true;
+        }
+        farfield_valid = true;
+        return 0;
+    }
+    int f2n_compressed() {
+        if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
+        int r = timed(HGS_K_COL_INV, [&]() -> int {
+            CArgs<R> a = cargs();
+            const dim3 grid(c_nblocks, B);
+            if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
+            else if (c_degree == 2) hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a);
+            else hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a);
+            HIPCHK(hipGetLastError());
+            return 0;
+        });
+        farfield_valid = false;
+        return r;
     }
 
     int fill_wscale_one() {
@@ -354,6 +486,34 @@ template <typename R> struct Engine : EngineBase {
                 if (int e = need_zw()) return e;
                 return upload_T<C>(zw, host, nbytes);
             }
+            case HGS_XGRID:
+            case HGS_YGRID: {
+                if (cfg.kind != 1) return fail(HGS_ERR_STATE, "grids belong to the compressed engine");
+                if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "grid: bad size %zu", nbytes);
+                HIPCHK(hipMemcpy(which == HGS_XGRID ? xg : yg, host, nbytes, hipMemcpyHostToDevice));
+                has_grid[which == HGS_XGRID ? 0 : 1] = true;
+                farfield_valid = false;
+                return 0;
+            }
+            case HGS_MONOMIALS: {
+                if (cfg.kind != 1) return fail(HGS_ERR_STATE, "monomials belong to the compressed engine");
+                if (nbytes != (size_t)2 * cfg.n_monomials * sizeof(int32_t)) return fail(HGS_ERR_ARG, "monomials: bad size");
+                const int32_t* h = (const int32_t*)host;
+                mono_host.assign(h, h + 2 * cfg.n_monomials);
+                HIPCHK(hipMemcpy(mono, host, nbytes, hipMemcpyHostToDevice));
+                has_mono = true;
+                farfield_valid = false;
+                return pack_coeff();
+            }
+            case HGS_SPOT_COEFF: {
+                if (cfg.kind != 1) return fail(HGS_ERR_STATE, "spot coefficients belong to the compressed engine");
+                if (nbytes != (size_t)cfg.n_monomials * cfg.n_spots * sizeof(R)) return fail(HGS_ERR_ARG, "spot coefficients: bad size");
+                const R* h = (const R*)host;
+                coeff_host.assign(h, h + (size_t)cfg.n_monomials * cfg.n_spots);
+                has_coeff = true;
+                farfield_valid = false;
+                return pack_coeff();
+            }
             case HGS_SPOT_INDEX: {
                 if (cfg.n_spots <= 0) return fail(HGS_ERR_STATE, "engine was created with n_spots = 0");
                 if (nbytes != (size_t)2 * cfg.n_spots * sizeof(int32_t)) return fail(HGS_ERR_ARG, "spot index: bad size");
@@ -369,6 +529,7 @@ template <typename R> struct Engine : EngineBase {
             }
             case HGS_SPOT_AMP:
             case HGS_EXTERNAL_AMP: {
+                if (cfg.kind == 1 && which == HGS_SPOT_AMP) return fail(HGS_ERR_ARG, "compressed targets are set with HGS_TARGET");
                 if (cfg.n_spots <= 0) return fail(HGS_ERR_STATE, "engine was created with n_spots = 0");
                 if (nbytes != (size_t)cfg.n_spots * sizeof(double)) return fail(HGS_ERR_ARG, "spot amplitudes: bad size");
                 HIPCHK(hipMemcpy(which == HGS_SPOT_AMP ? spot_amp : ext_amp, host, nbytes, hipMemcpyHostToDevice));
@@ -447,6 +608,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int n2f(int store_pff) override {
+        if (cfg.kind == 1) return n2f_compressed(store_pff);
         if (int e = need_ff()) return e;
         if (store_pff) { if (int e = need_pff()) return e; }
         if (int e = run_row(0, false)) return e;
@@ -464,6 +626,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int f2n() override {
+        if (cfg.kind == 1) return f2n_compressed();
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
         int r = timed(HGS_K_COL_INV, [&]() -> int {
             LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(col_blocks, B), stream, col_args()));
@@ -516,7 +679,7 @@ template <typename R> struct Engine : EngineBase {
         if (st->method < HGS_GS || st->method > HGS_WGS_TANH) return fail(HGS_ERR_ARG, "unknown method %d", st->method);
         if (st->feedback < HGS_FB_PIXEL || st->feedback > HGS_FB_EXTERNAL) return fail(HGS_ERR_ARG, "unknown feedback %d", st->feedback);
         if (!has_target) return fail(HGS_ERR_STATE, "target has not been set");
-        if (st->feedback != HGS_FB_PIXEL && st->method != HGS_GS) {
+        if (cfg.kind == 0 && st->feedback != HGS_FB_PIXEL && st->method != HGS_GS) {
             if (!has_spots) return fail(HGS_ERR_STATE, "spot feedback needs HGS_SPOT_INDEX / HGS_SPOT_AMP");
             if (st->feedback == HGS_FB_SPOT_WINDOW) {
                 if (st->spot_window < 1) return fail(HGS_ERR_ARG, "spot_window must be >= 1");
@@ -548,8 +711,20 @@ template <typename R> struct Engine : EngineBase {
         const dim3 eg(ew_blocks, B), eb(256);
         return timed(HGS_K_ELEMENTWISE, [&]() -> int {
             bool pixel_update = false;
+            if (p.do_update && cfg.kind == 1 && st->feedback == HGS_FB_EXTERNAL) {
+                // CompressedSpotHologram "external_spot" (_spots.py:978-989): the N-vector rule with
+                // external_spot_amp as the feedback amplitude
+                hipLaunchKernelGGL(convert_d2r<R>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream,
+                                   (const double*)ext_amp, ext_r, (int)P, B);
+                HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL(ew_sumsq<R>, eg, eb, 0, stream, (const R*)ext_r, P, epartial);
+                HIPCHK(hipGetLastError());
+                if (int e = reduce(epartial, ew_blocks, sums + 3 * B)) return e;
+                a.amp_ff = ext_r;
+                a.fsum = sums + 3 * B;
+            }
             if (p.do_update) {
-                if (st->feedback == HGS_FB_PIXEL) {
+                if (st->feedback == HGS_FB_PIXEL || cfg.kind == 1) {
                     if (st->method == HGS_WGS_NOGRETTE) {
                         hipLaunchKernelGGL(ew_nogrette_sum<R>, eg, eb, 0, stream, a);
                         HIPCHK(hipGetLastError());
@@ -588,7 +763,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     bool fused_ok(const hgs_step* st) const {
-        return !st->mraf_enabled && st->feedback == HGS_FB_PIXEL && st->method != HGS_WGS_NOGRETTE;
+        return cfg.kind == 0 && !st->mraf_enabled && st->feedback == HGS_FB_PIXEL && st->method != HGS_WGS_NOGRETTE;
     }
 
     int iterate(hgs_step* st, int n, uint8_t* hist) override {

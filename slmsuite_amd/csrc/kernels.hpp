@@ -871,6 +871,19 @@ template <typename R> __global__ void ew_rebuild(EwArgs<R> a) {
     }
 }
 
+// partial sums of x^2 (nansum) for an arbitrary real array
+template <typename R> __global__ void ew_sumsq(const R* x, size_t P, double* partial) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.y;
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = (double)x[(size_t)b * P + i];
+        if (v == v) acc += v * v;
+    }
+    const double s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+}
+
 // phase_ff = atan2(F) only (Kim transition with MRAF-free stepwise mode, :1583)
 template <typename R> __global__ void ew_store_phase(EwArgs<R> a) {
     using M = Math<R>;

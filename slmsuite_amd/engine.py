@@ -14,19 +14,26 @@ FEEDBACK_INDEX = {"computational": L.FB_PIXEL, "computational_spot": L.FB_SPOT_W
 
 
 class Engine:
-    def __init__(self, shape, slm_shape, dtype=np.float32, batch=1, n_spots=0, device=0):
+    def __init__(self, shape, slm_shape, dtype=np.float32, batch=1, n_spots=0, device=0, kind=0, n_monomials=0):
         self.lib = L.load()
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise ValueError(f"Data type {dtype} not supported.")
         self.ctype = np.dtype(np.complex64 if self.dtype == np.float32 else np.complex128)
-        self.shape = (int(shape[0]), int(shape[1]))
+        self.kind = int(kind)
         self.slm_shape = (int(slm_shape[0]), int(slm_shape[1]))
         self.batch = int(batch)
         self.n_spots = int(n_spots)
-        cfg = L.hgs_config(device=int(device), pad_h=self.shape[0], pad_w=self.shape[1],
+        self.n_monomials = int(n_monomials)
+        if self.kind == 1:      # CompressedSpotHologram: farfield-sized arrays are N-vectors
+            self.shape = (self.n_spots,)
+            pad = self.slm_shape
+        else:
+            self.shape = pad = (int(shape[0]), int(shape[1]))
+        cfg = L.hgs_config(device=int(device), pad_h=pad[0], pad_w=pad[1],
                            slm_h=self.slm_shape[0], slm_w=self.slm_shape[1],
-                           real_bytes=self.dtype.itemsize, batch=self.batch, n_spots=self.n_spots)
+                           real_bytes=self.dtype.itemsize, batch=self.batch, n_spots=self.n_spots,
+                           kind=self.kind, n_monomials=self.n_monomials)
         self._h = C.c_void_p()
         L.check(self.lib.hgs_create(C.byref(cfg), C.byref(self._h)))
 
@@ -43,7 +50,7 @@ class Engine:
 
     # -- arrays ----------------------------------------------------------------------------
     def _np(self, which, arr):
-        if which in (L.SPOT_INDEX,):
+        if which in (L.SPOT_INDEX, L.MONOMIALS):
             return np.ascontiguousarray(arr, dtype=np.int32)
         if which in (L.SPOT_AMP, L.EXTERNAL_AMP):
             return np.ascontiguousarray(arr, dtype=np.float64)

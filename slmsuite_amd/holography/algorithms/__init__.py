@@ -814,3 +814,194 @@ class SpotHologram(FeedbackHologram):
 
 __all__ = ["Hologram", "FeedbackHologram", "SpotHologram", "ALGORITHM_DEFAULTS", "ALGORITHM_INDEX",
            "FEEDBACK_OPTIONS"]
+
+
+class CompressedSpotHologram(FeedbackHologram):
+    """
+    Kernel-based focal arrays: N free-floating spots, each with its own Zernike phase kernel, no
+    padded DFT grid (reference: ``CompressedSpotHologram``, _spots.py:178-1018).  The farfield is the
+    N-vector of spot amplitudes; both directions of the non-uniform DFT are regenerated on the fly on
+    the GPU (no kernel cache, no 256-spot batching).
+
+    ``cameraslm`` is duck-typed: it needs ``.slm`` with ``shape``, ``grid`` (x/lambda meshgrids),
+    ``pitch``, ``get_source_zernike_scaling()`` and ``_get_source_amplitude()``
+    (``slmsuite_amd.hardware.SimpleFourierSLM`` is a minimal stand-in).
+    """
+
+    def __init__(self, spot_vectors, basis="kxy", spot_amp=None, cameraslm=None, cuda=False, **kwargs):
+        if cameraslm is None:
+            raise ValueError("cameraslm must be passed.")
+        spot_vectors = toolbox.format_vectors(spot_vectors)
+        D, N = spot_vectors.shape
+        if spot_amp is not None:
+            self.spot_amp = np.array(spot_amp)
+            if self.spot_amp.size != N:
+                raise ValueError(f"spot_amp (length {self.spot_amp.size}) must have the same length as the provided spots ({N}).")
+        else:
+            self.spot_amp = np.full(N, 1.0 / np.sqrt(N))
+
+        if isinstance(basis, str):
+            self.zernike_basis = toolbox.zernike_indices_parse(None, D)
+        else:
+            self.zernike_basis = np.ravel(basis)
+            basis = "zernike"
+            if len(self.zernike_basis) != D:
+                raise ValueError(f"zernike_basis (length {len(self.zernike_basis)}) must have the same "
+                                 f"dimension as the provided spots ({D}).")
+            if 0 in self.zernike_basis:
+                warnings.warn("Found ANSI index '0' (Zernike piston) in the zernike_basis; this is not necessary.")
+        if not np.any(self.zernike_basis == 2) or not np.any(self.zernike_basis == 1):
+            raise ValueError("Compressed basis must include x, y (Zernike ANSI indices 2, 1)")
+        cart = [int(np.argwhere(self.zernike_basis == 2)[0][0]), int(np.argwhere(self.zernike_basis == 1)[0][0])]
+        if np.any(self.zernike_basis == 4):
+            cart.append(int(np.argwhere(self.zernike_basis == 4)[0][0]))
+        self.zernike_basis_cartesian = np.array(cart)
+
+        if basis == "zernike":
+            self.spot_zernike = np.array(spot_vectors, dtype=float)
+            _, self.spot_kxy = toolbox.convert_vector_zernike(spot_vectors[self.zernike_basis_cartesian, :],
+                                                              "zernike", cameraslm)
+        elif basis in ("kxy", "norm"):
+            self.spot_zernike, self.spot_kxy = toolbox.convert_vector_zernike(spot_vectors, "kxy", cameraslm)
+        else:
+            raise NotImplementedError(f"basis '{basis}' needs a Fourier-calibrated camera and is outside this build")
+        self.spot_ij = None
+        self.spot_integration_width_ij = None
+
+        slm = cameraslm.slm if hasattr(cameraslm, "slm") else cameraslm
+        kmax = 1. / np.min(slm.pitch) / 2.
+        if np.any(np.abs(self.spot_kxy[:2, :]) > 1.1 * kmax):
+            raise ValueError("Spots laterally outside the bounds of the farfield")
+
+        self._compressed_ready = False
+        super().__init__(shape=None, target_ij=None, cameraslm=cameraslm, **kwargs)
+        self.shape = self.slm_shape
+        self.set_target(new_target=self.spot_amp, reset_weights=True)
+        # quirk: the reference ends its constructor with reset() (_spots.py:495), which replaces any
+        # phase passed by the caller with a fresh random one; reproduce, then honour reset_phase().
+        self.reset()
+        self.external_spot_amp = np.ones(self.target.shape)
+        self.cuda = False
+        xg, yg = toolbox.process_grid(slm)
+        scale = slm.get_source_zernike_scaling()
+        sx, sy = (scale, scale) if np.isscalar(scale) else (scale[0], scale[1])
+        self._xg = np.asarray(xg, dtype=float) * sx
+        self._yg = np.asarray(yg, dtype=float) * sy
+        self._spot_zernike_cached = None
+        self._compressed_ready = True
+
+    def __len__(self):
+        return self.spot_amp.size
+
+    def _n_spots(self):
+        return len(self)
+
+    def get_padded_shape(self, *args, **kwargs):
+        raise NameError("CompressedSpotHologram does not use a DFT grid and does not need padding.")
+
+    # the base-class target plumbing works on the padded grid; here the target is the N-vector
+    def _set_target(self, new_target, reset_weights=False):
+        if not getattr(self, "_compressed_ready", False) and (new_target is None or np.size(new_target) == 0
+                                                               or np.ndim(new_target) != 1):
+            self.target = np.zeros((len(self),), dtype=self.dtype)   # placeholder during base construction
+            return
+        self.set_target(new_target, reset_weights)
+
+    def set_target(self, new_target=None, reset_weights=False):
+        """_spots.py:917-947."""
+        if new_target is None:
+            target = np.array(self.spot_amp, dtype=self.dtype)
+        else:
+            new_target = np.squeeze(np.ravel(new_target))
+            if new_target.shape != (len(self),):
+                raise ValueError("Target must be of appropriate shape. Initialize a new Hologram if a "
+                                 "different shape is desired.")
+            target = np.array(new_target, dtype=self.dtype)
+            self.spot_amp = np.array(new_target, dtype=self.dtype)
+        np.abs(target, out=target)
+        target *= 1 / _norm(target)
+        self.target = target
+        if self._engine is not None:
+            self._engine.set(L.TARGET, self.target)
+        if reset_weights:
+            self.reset_weights()
+
+    def reset(self, reset_phase=True, reset_flags=False):
+        super().reset(reset_phase=reset_phase, reset_flags=reset_flags)
+        self._host["farfield"] = np.zeros(self.target.shape, dtype=self.dtype_complex)
+
+    @property
+    def nearfield(self):
+        ph = self.phase if self.propagation_kernel is None else self.phase + self.propagation_kernel
+        return (self.amp * np.exp(1j * ph)).astype(self.dtype_complex)
+
+    def _check_spot_zernike_change(self):
+        """_spots.py:638-650: whole-array comparison against the cached copy."""
+        changed = self._spot_zernike_cached is None or np.any(self._spot_zernike_cached != self.spot_zernike)
+        if changed:
+            self._spot_zernike_cached = self.spot_zernike.copy()
+        return changed
+
+    def _push_kernels(self, e):
+        terms, w = toolbox.zernike_monomial_weights(self.zernike_basis, self.spot_zernike)
+        if terms.shape[0] != e.n_monomials:
+            raise ValueError("the monomial set of the kernels changed; build a new hologram")
+        e.set(L.MONOMIALS, terms)
+        e.set(L.SPOT_COEFF, w)
+
+    def _get_engine(self):
+        e = self._engine
+        if e is None:
+            terms, _ = toolbox.zernike_monomial_weights(self.zernike_basis, self.spot_zernike)
+            e = self._engine = Engine(self.slm_shape, self.slm_shape, self.dtype, batch=1, n_spots=len(self),
+                                      kind=1, n_monomials=terms.shape[0])
+            if np.isscalar(self.amp):
+                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
+            else:
+                e.set(L.AMP, self.amp)
+            if self.propagation_kernel is not None:
+                e.set(L.PROP_KERNEL, self.propagation_kernel)
+            e.set(L.XGRID, self._xg)
+            e.set(L.YGRID, self._yg)
+            e.set(L.TARGET, self.target)
+            self._spot_zernike_cached = None
+            self._upload |= {"phase", "weights"}
+            if self._host.get("phase_ff") is not None:
+                self._upload.add("phase_ff")
+        if self._check_spot_zernike_change():
+            self._push_kernels(e)
+        for name in list(self._upload):
+            if self._host.get(name) is not None:
+                e.set(_DEVICE_ARRAYS[name], self._host[name])
+            self._upload.discard(name)
+        return e
+
+    def _make_step(self, skip_last=False):
+        fl = dict(self.flags)
+        if fl.get("feedback") in ("computational", "computational_spot"):
+            fl["feedback"] = "computational"          # the N-vector rule on amp_ff
+        return make_step(fl, self.iter, false_run=self._false_run(skip_last),
+                         mraf_enabled=self._mraf_enabled(), spot_window=1)
+
+    def _pre_loop_checks(self):
+        fb = self.flags.get("feedback", "computational")
+        if fb == "computational":                      # _spots.py:957-959
+            self.flags["feedback"] = "computational_spot"
+        if fb == "experimental":
+            warnings.warn("CompressedSpotHologram feedback 'experimental' is interpreted as 'experimental_spot'")
+            self.flags["feedback"] = "experimental_spot"
+        if self.flags["feedback"] in ("experimental", "experimental_spot"):
+            raise NotImplementedError("experimental feedback needs camera hardware and is outside this build")
+        if self.flags["feedback"] == "external_spot":
+            self._engine.set(L.EXTERNAL_AMP, np.asarray(self.external_spot_amp, dtype=float))
+
+    def _needs_stepwise(self, callback):
+        # no fused kernel for this path yet: the engine loops the three operators on the device
+        return super()._needs_stepwise(callback)
+
+    def _update_stats(self, stat_groups=[]):
+        """_spots.py:1004-1018: the computational_spot group is disabled in the reference."""
+        self._update_stats_dictionary({})
+
+    def get_farfield(self, *args, **kwargs):
+        raise NotImplementedError("CompressedSpotHologram has no DFT-grid farfield; see .farfield for the spots")

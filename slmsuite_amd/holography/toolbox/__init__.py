@@ -174,3 +174,117 @@ def imprint_disk_zero(matrix, cx, cy, w):
             if (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r:
                 matrix[yy, xx] = 0
     return matrix
+
+
+# ---- Zernike machinery used by CompressedSpotHologram (toolbox/phase.py) -------------------------------
+def zernike_ansi_to_radial(j):
+    """ANSI index -> (n, l)  (phase.zernike_convert_index, phase.py:570-680)."""
+    j = int(j)
+    n = int(np.ceil((-3 + np.sqrt(9 + 8 * j)) / 2))
+    return n, 2 * j - n * (n + 2)
+
+
+def zernike_cartesian(j):
+    """
+    {(px, py): integer coefficient} of the real Zernike polynomial of ANSI index j, normalised to
+    +-1 at the pupil edge (Z1 = y, Z2 = x, Z4 = 2x^2 + 2y^2 - 1), as phase._zernike_coefficients
+    (phase.py:1357-1442) caches them.  R_n^|l|(r) expanded with (x+iy)^|l| and (x^2+y^2)^k.
+    """
+    from math import comb, factorial
+    n, l = zernike_ansi_to_radial(j)
+    al = abs(l)
+    out = {}
+    for s in range((n - al) // 2 + 1):
+        rc = (-1) ** s * factorial(n - s) // (factorial(s) * factorial((n + al) // 2 - s) * factorial((n - al) // 2 - s))
+        k = (n - 2 * s - al) // 2
+        for t in range(k + 1):
+            for q in range(al + 1):
+                if (l >= 0 and q % 2 == 1) or (l < 0 and q % 2 == 0):
+                    continue
+                key = (al - q + 2 * (k - t), q + 2 * t)
+                out[key] = out.get(key, 0) + rc * comb(k, t) * comb(al, q) * (-1) ** (q // 2)
+    return {k: v for k, v in out.items() if v != 0}
+
+
+def zernike_indices_parse(indices=None, D=None):
+    """Default bases [2,1], [2,1,4], [2,1,4,3,5,...]  (phase._zernike_indices_parse, phase.py:923-961)."""
+    if indices is None:
+        if D is None:
+            raise ValueError("Either dimension or indices must be defined.")
+        if D == 2:
+            indices = np.array([2, 1])
+        elif D == 3:
+            indices = np.array([2, 1, 4])
+        elif D == 4:
+            indices = np.array([2, 1, 4, 3])
+        else:
+            indices = np.hstack((np.array([2, 1, 4, 3]), np.arange(5, D + 1)))
+    indices = np.ravel(indices)
+    if D is not None and len(indices) != D:
+        raise ValueError(f"Expected data (dimension {D}) to have common size with indices (length {len(indices)}).")
+    return indices
+
+
+def zernike_monomial_weights(indices, weights):
+    """
+    (terms [M,2] int, monomial weights [M,N]) such that sum_d weights[d,n] Z_indices[d](x, y) =
+    sum_m out[m,n] x^terms[m,0] y^terms[m,1]; monomials in ascending Cantor order
+    (phase._zernike_get_cantor, phase.py:850-920).
+    """
+    a = np.asarray(weights, dtype=float)
+    acc = {}
+    for d, idx in enumerate(np.ravel(indices)):
+        if int(idx) < 0:
+            raise NotImplementedError("the vortex pseudo-index -1 is outside this build")
+        for key, c in zernike_cartesian(int(idx)).items():
+            acc[key] = acc.get(key, 0) + c * a[d]
+    keys = sorted(acc, key=lambda k: (k[0] + k[1]) * (k[0] + k[1] + 1) // 2 + k[1])
+    return (np.array(keys, dtype=np.int32).reshape(-1, 2),
+            np.array([acc[k] for k in keys], dtype=float).reshape(len(keys), -1))
+
+
+def process_grid(grid):
+    """(x_grid, y_grid) from a cameraslm, an SLM or a pair of arrays (toolbox._process_grid)."""
+    if hasattr(grid, "slm") and hasattr(grid, "cam"):
+        grid = grid.slm
+    if hasattr(grid, "grid"):
+        grid = grid.grid
+    return grid[0], grid[1]
+
+
+def format_vectors(vectors, expected_dimension=None):
+    """(D, N) float array from tuples / row vectors (toolbox.format_vectors with handle_dimension='pass')."""
+    v = np.array(vectors, dtype=float, copy=True)
+    if v.ndim == 1:
+        v = v.reshape(-1, 1)
+    if v.ndim != 2:
+        raise ValueError(f"Expected a (D, N) array of vectors, got shape {np.shape(vectors)}")
+    if expected_dimension is not None and v.shape[0] != expected_dimension:
+        raise ValueError(f"Expected vectors of dimension {expected_dimension}")
+    return v
+
+
+def convert_vector_zernike(vector, from_units, hardware):
+    """
+    ("zernike" coefficients [D,N], "kxy" [D,N]) of 2- or 3-vectors given in "kxy"/"norm" or "zernike"
+    units: xy scale 2*pi / slm.get_source_zernike_scaling(), depth (8 pi)/scale^2
+    (toolbox.convert_vector, toolbox/__init__.py:318-392).
+    """
+    slm = hardware.slm if hasattr(hardware, "slm") else hardware
+    v = format_vectors(vector)
+    zs = 2 * np.pi * np.reciprocal(slm.get_source_zernike_scaling())
+    if from_units in ("kxy", "norm", "rad"):
+        kxy = v.copy()
+        zern = v.copy()
+        zern[:2] = v[:2] * zs
+        if v.shape[0] > 2:
+            zern[2] = v[2] * ((zs * zs) / (8 * np.pi))
+    elif from_units == "zernike":
+        zern = v.copy()
+        kxy = v.copy()
+        kxy[:2] = v[:2] / zs
+        if v.shape[0] > 2:
+            kxy[2] = v[2] * ((8 * np.pi) / (zs * zs))
+    else:
+        raise NotImplementedError(f"unit '{from_units}' needs camera calibration hardware")
+    return zern, kxy

@@ -284,6 +284,81 @@ def gen_cfg2(alg):
                               method="WGS-Leonardo", sub_ampff=16, sub_phase=6, wall_s=dt), out)
 
 
+def make_fourier_slm(res_wh=(64, 48)):
+    """SimulatedSLM + SimulatedCamera + analytic Fourier calibration (SURVEY 8c recipe)."""
+    from slmsuite.hardware.slms.simulated import SimulatedSLM
+    from slmsuite.hardware.cameras.simulated import SimulatedCamera
+    from slmsuite.hardware.cameraslms import FourierSLM
+    slm = SimulatedSLM(res_wh, pitch_um=(8, 8), wav_um=0.78)
+    cam = SimulatedCamera(slm, resolution=(256, 256), pitch_um=(4, 4))
+    fs = FourierSLM(cam, slm)
+    fs.fourier_calibrate_analytic(np.array([[6000., 0], [0, 6000.]]), np.array([128., 128.]))
+    return fs
+
+
+def gen_compressed_cases(alg):
+    """F5: CompressedSpotHologram on a 48x64 SLM: N=50 (2-D), N=50 (3-D), N=300 (> N_BATCH_MAX), custom basis."""
+    from slmsuite.holography.toolbox import phase as tphase
+    fs = make_fourier_slm()
+    slm = fs.slm
+    scale = slm.get_source_zernike_scaling()
+    xg, yg = slm.grid[0] * scale, slm.grid[1] * scale
+    out = {"zernike_coeff_json": np.array(json.dumps(
+        {str(j): {f"{k[0]},{k[1]}": int(v) for k, v in tphase._zernike_coefficients(j).items()} for j in range(45)}))}
+    save("compressed_helpers", dict(kind="compressed_helpers", scale=float(scale), pitch=[float(p) for p in slm.pitch],
+                                    shape=[int(x) for x in slm.shape]), out)
+    cases = [("2d50", 2, 50, "kxy", None, "WGS-Kim", dict(fix_phase_iteration=4)),
+             ("3d50", 3, 50, "kxy", None, "WGS-Leonardo", {}),
+             ("2d300", 2, 300, "kxy", None, "WGS-Kim", dict(fix_phase_iteration=4)),
+             ("zern5", 5, 24, [2, 1, 4, 3, 5], None, "WGS-Nogrette", {}),
+             ("mraf2d", 2, 40, "kxy", "mraf", "WGS-Leonardo", dict(mraf_factor=0.5))]
+    for tag, D, N, basis, special, method, kw in cases:
+        seed = 500 + N + D
+        v = (synth.uniform01(seed, (D, N), 7) * 2 - 1)
+        if basis == "kxy":
+            v[:2] *= 0.012
+            if D == 3:
+                v[2] *= 2e-6
+        else:
+            v *= np.array([12, 12, 2, 1.5, 1.5])[:, None]
+        spot_amp = None
+        if special == "mraf":
+            spot_amp = np.full(N, 1.0)
+            spot_amp[::5] = np.nan
+            spot_amp[3::7] = 0
+        phase0 = synth.seed_phase(seed, tuple(int(x) for x in slm.shape))
+        h = alg.CompressedSpotHologram(v.copy(), basis=basis, spot_amp=None if spot_amp is None else spot_amp.copy(),
+                                       cameraslm=fs, phase=phase0.copy())
+        # CompressedSpotHologram.__init__ ends with self.reset() (_spots.py:495), which re-randomises
+        # the phase it was given; put the seed phase back so the run is reproducible.
+        h.reset_phase(phase0.copy())
+        rec = {}
+
+        def snap(hh):
+            k = hh.iter
+            rec[f"ff_{k}"] = np.array(hh.farfield, copy=True)
+            rec[f"weights_{k}"] = np.array(hh.weights, copy=True)
+            if k in (1, 2, 5, 6):
+                rec[f"phase_{k}"] = np.array(hh.phase, copy=True)
+            rec[f"fixed_{k}"] = np.array(bool(hh.flags.get("fixed_phase", False)))
+            return False
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            h.optimize(method, maxiter=8, verbose=False, callback=snap, **kw)
+        rec.update(final_phase=np.array(h.phase), final_weights=np.array(h.weights), final_ff=np.array(h.farfield),
+                   final_ampff=np.array(h.amp_ff), spot_zernike=np.array(h.spot_zernike),
+                   zernike_basis=np.array(h.zernike_basis), spot_vectors=v, target=np.array(h.target),
+                   xg=np.array(xg), yg=np.array(yg), spot_kxy=np.array(h.spot_kxy),
+                   fixed_history=np.array([bool(x) for x in h.stats["flags"]["fixed_phase"]]))
+        if spot_amp is not None:
+            rec["spot_amp_in"] = spot_amp
+        meta = dict(kind="compressed", tag=tag, D=D, N=N, basis=basis if isinstance(basis, str) else list(basis),
+                    method=method, kwargs=kw, seed=seed, maxiter=8, slm_shape=[int(x) for x in slm.shape],
+                    scale=float(scale), feedback=h.flags["feedback"])
+        save(f"compressed_{tag}", meta, rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg2", action="store_true")
@@ -297,6 +372,7 @@ def main():
         "spot": lambda: gen_spot_cases(alg),
         "helpers": lambda: gen_helper_cases(alg, toolbox, analysis),
         "cfg1": lambda: gen_cfg1(alg),
+        "compressed": lambda: gen_compressed_cases(alg),
     }
     if args.cfg2:
         steps["cfg2"] = lambda: gen_cfg2(alg)
