@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--method", default="WGS-Leonardo")
     ap.add_argument("--cpu-iters", type=int, default=16, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (self-test)")
     return ap.parse_args()
 
 
@@ -84,7 +85,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
