@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhgs.so")
+LIB_PATH = os.environ.get("HGS_LIB", os.path.join(_HERE, "libhgs.so"))   # HGS_LIB: A/B builds only
 
 HGS_OK, HGS_ERR_ARG, HGS_ERR_DEVICE, HGS_ERR_STATE, HGS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 

@@ -22,20 +22,62 @@
 #include <type_traits>
 #include <utility>
 
+// Ablation hooks for tools/microbench/ablate.hip (all 0 in the product build).
+#ifndef HGS_ABL_XCHG
+#define HGS_ABL_XCHG 0
+#endif
+#ifndef HGS_ABL_BFLY
+#define HGS_ABL_BFLY 0
+#endif
+#ifndef HGS_ABL_TRANS
+#define HGS_ABL_TRANS 0
+#endif
+
 namespace hgs {
 
-template <typename R> struct Cx { R x, y; };
+// Complex numbers are 2-vectors (x = re, y = im) held in an aligned VGPR pair, so that complex
+// add/sub are ONE packed instruction (v_pk_add_f32) and a complex multiply is two (v_pk_mul_f32 +
+// v_pk_fma_f32 with op_sel/neg modifiers).  Measured on MI355X (tools/microbench/valu_rate.hip): a
+// wave64 scalar fp32 VALU op occupies its SIMD for ~4.2 cycles, v_pk_fma_f32 for ~4.45 while doing
+// twice the work -- the transform kernels are VALU-issue bound, so packed math is the lever.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <typename R> struct CxSel;
+template <> struct CxSel<float> { using type = v2f; };
+template <> struct CxSel<double> { using type = v2d; };
+template <typename R> using Cx = typename CxSel<R>::type;
+template <typename V> struct RealOf;
+template <> struct RealOf<v2f> { using type = float; };
+template <> struct RealOf<v2d> { using type = double; };
 
-template <typename R> __device__ __forceinline__ Cx<R> mk(R x, R y) { Cx<R> c; c.x = x; c.y = y; return c; }
-template <typename R> __device__ __forceinline__ Cx<R> operator+(Cx<R> a, Cx<R> b) { return mk<R>(a.x + b.x, a.y + b.y); }
-template <typename R> __device__ __forceinline__ Cx<R> operator-(Cx<R> a, Cx<R> b) { return mk<R>(a.x - b.x, a.y - b.y); }
-template <typename R> __device__ __forceinline__ Cx<R> operator*(Cx<R> a, R s) { return mk<R>(a.x * s, a.y * s); }
-template <typename R> __device__ __forceinline__ Cx<R> cmul(Cx<R> a, Cx<R> b) {
-    return mk<R>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+template <typename R> __device__ __forceinline__ Cx<R> mk(R x, R y) { return (Cx<R>){x, y}; }
+template <typename V> __device__ __forceinline__ V cswap(V a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// a * b
+template <typename V> __device__ __forceinline__ V cmul(V a, V b) {
+    if constexpr (std::is_same<V, v2f>::value) {
+        v2f t, r;
+        // t = a.xx * b ; r = a.yy * (-b.y, b.x) + t
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+            : "=v"(r) : "v"(a), "v"(b), "v"(t));
+        return r;
+    } else {
+        return (V){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    }
 }
 // a * conj(b)
-template <typename R> __device__ __forceinline__ Cx<R> cmulc(Cx<R> a, Cx<R> b) {
-    return mk<R>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+template <typename V> __device__ __forceinline__ V cmulc(V a, V b) {
+    if constexpr (std::is_same<V, v2f>::value) {
+        v2f t, r;
+        // t = a.xx * (b.x, -b.y) ; r = a.yy * (b.y, b.x) + t
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+            : "=v"(r) : "v"(a), "v"(b), "v"(t));
+        return r;
+    } else {
+        return (V){a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+    }
 }
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -46,45 +88,50 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 }
 
 // DIR = -1 forward (e^{-i...}), +1 inverse.
-// multiply by e^{DIR * 2*pi*i * Q / 16}, Q compile-time.
-template <int Q, int DIR, typename R> __device__ __forceinline__ Cx<R> rot16(Cx<R> a) {
+// a + e^{DIR*i*pi/2} b  and  a - e^{DIR*i*pi/2} b : one packed fma each (swap folds into op_sel,
+// the (+-1, -+1) pair is a scalar-register constant)
+template <int DIR, typename V> __device__ __forceinline__ V cadd_rot4(V a, V b) {
+    using R = typename RealOf<V>::type;
+    constexpr R s = DIR < 0 ? (R)1 : (R)-1;     // forward: a + (-i) b = (a.x + b.y, a.y - b.x)
+    return __builtin_elementwise_fma(cswap(b), (V){s, -s}, a);
+}
+template <int DIR, typename V> __device__ __forceinline__ V csub_rot4(V a, V b) {
+    using R = typename RealOf<V>::type;
+    constexpr R s = DIR < 0 ? (R)1 : (R)-1;
+    return __builtin_elementwise_fma(cswap(b), (V){-s, s}, a);
+}
+
+// multiply by e^{DIR * 2*pi*i * Q / 16}, Q compile-time:  a*(c,c) + swap(a)*(-s,s)
+template <int Q, int DIR, typename V> __device__ __forceinline__ V rot16(V a) {
+    using R = typename RealOf<V>::type;
     constexpr int q = ((Q % 16) + 16) % 16;
     constexpr R C1 = (R)0.92387953251128675613;  // cos(pi/8)
     constexpr R S1 = (R)0.38268343236508977173;  // sin(pi/8)
     constexpr R H = (R)0.70710678118654752440;   // sqrt(1/2)
+    constexpr R cs[16] = {1, C1, H, S1, 0, -S1, -H, -C1, -1, -C1, -H, -S1, 0, S1, H, C1};
+    constexpr R sn[16] = {0, S1, H, C1, 1, C1, H, S1, 0, -S1, -H, -C1, -1, -C1, -H, -S1};
+    constexpr R c = cs[q];
+    constexpr R s = DIR < 0 ? -sn[q] : sn[q];
     if constexpr (q == 0) return a;
-    else if constexpr (q == 8) return mk<R>(-a.x, -a.y);
-    else if constexpr (q == 4) return DIR < 0 ? mk<R>(a.y, -a.x) : mk<R>(-a.y, a.x);
-    else if constexpr (q == 12) return DIR < 0 ? mk<R>(-a.y, a.x) : mk<R>(a.y, -a.x);
-    else if constexpr (q % 2 == 0) {
-        // odd multiples of pi/4: (cos, sin) = (+-H, +-H)
-        constexpr R c = (q == 2 || q == 14) ? H : -H;
-        constexpr R s0 = (q == 2 || q == 6) ? H : -H;  // sin(2*pi*q/16)
-        constexpr R s = DIR < 0 ? -s0 : s0;
-        return mk<R>(a.x * c - a.y * s, a.x * s + a.y * c);
-    } else {
-        constexpr R cs[16] = {1, C1, H, S1, 0, -S1, -H, -C1, -1, -C1, -H, -S1, 0, S1, H, C1};
-        constexpr R sn[16] = {0, S1, H, C1, 1, C1, H, S1, 0, -S1, -H, -C1, -1, -C1, -H, -S1};
-        constexpr R c = cs[q];
-        constexpr R s = DIR < 0 ? -sn[q] : sn[q];
-        return mk<R>(a.x * c - a.y * s, a.x * s + a.y * c);
-    }
+    else if constexpr (q == 8) return -a;
+    else if constexpr (q == 4 || q == 12) return cswap(a) * (V){-s, s};
+    else return __builtin_elementwise_fma(cswap(a), (V){-s, s}, a * (V){c, c});
 }
 
-template <int DIR, typename R> __device__ __forceinline__ void dft2(Cx<R>& a, Cx<R>& b) {
-    Cx<R> t = a - b;
+template <int DIR, typename V> __device__ __forceinline__ void dft2(V& a, V& b) {
+    V t = a - b;
     a = a + b;
     b = t;
 }
 
-// 4-point DFT on (v0,v1,v2,v3), natural order in and out.
-template <int DIR, typename R>
-__device__ __forceinline__ void dft4(Cx<R>& v0, Cx<R>& v1, Cx<R>& v2, Cx<R>& v3) {
-    Cx<R> a0 = v0 + v2, a1 = v0 - v2, a2 = v1 + v3, a3 = rot16<4, DIR>(v1 - v3);
+// 4-point DFT on (v0,v1,v2,v3), natural order in and out: 8 packed ops
+template <int DIR, typename V>
+__device__ __forceinline__ void dft4(V& v0, V& v1, V& v2, V& v3) {
+    V a0 = v0 + v2, a1 = v0 - v2, a2 = v1 + v3, d = v1 - v3;
     v0 = a0 + a2;
-    v1 = a1 + a3;
     v2 = a0 - a2;
-    v3 = a1 - a3;
+    v1 = cadd_rot4<DIR>(a1, d);
+    v3 = csub_rot4<DIR>(a1, d);
 }
 
 // R-point DFT, v[r] natural order in, V[p] natural order out (in place).
@@ -116,19 +163,18 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
     // the caller pre-multiplies v[r1+4r2] by W^(4 r2 k); the common factor W^(r1 k) = bt[r1-1]
     // of each inner 4-point transform is applied here to its outputs.
     template <bool TW>
-    static __device__ __forceinline__ void run_tw(Cx<R> (&v)[16], const Cx<R>* bt) {
+    static __device__ __forceinline__ void run_tw(Cx<R> (&v)[16], Cx<R> bt1, Cx<R> bt2, Cx<R> bt3) {
         // step 1: DFT4 over r2 for each r1 -> t[r1][p2] stored at v[r1 + 4*p2]
         dft4<DIR>(v[0], v[4], v[8], v[12]);
         dft4<DIR>(v[1], v[5], v[9], v[13]);
         dft4<DIR>(v[2], v[6], v[10], v[14]);
         dft4<DIR>(v[3], v[7], v[11], v[15]);
         if constexpr (TW) {
-            static_for<1, 4>([&](auto r1_) {
-                constexpr int r1 = r1_;
-                static_for<0, 4>([&](auto p2_) {
-                    constexpr int p2 = p2_;
-                    v[r1 + 4 * p2] = DIR < 0 ? cmul(v[r1 + 4 * p2], bt[r1 - 1]) : cmulc(v[r1 + 4 * p2], bt[r1 - 1]);
-                });
+            static_for<0, 4>([&](auto p2_) {
+                constexpr int p2 = p2_;
+                v[1 + 4 * p2] = DIR < 0 ? cmul(v[1 + 4 * p2], bt1) : cmulc(v[1 + 4 * p2], bt1);
+                v[2 + 4 * p2] = DIR < 0 ? cmul(v[2 + 4 * p2], bt2) : cmulc(v[2 + 4 * p2], bt2);
+                v[3 + 4 * p2] = DIR < 0 ? cmul(v[3 + 4 * p2], bt3) : cmulc(v[3 + 4 * p2], bt3);
             });
         }
         // step 2: twiddle t[r1][p2] *= w16^(r1*p2)
@@ -149,7 +195,10 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
         t = v[7]; v[7] = v[13]; v[13] = t;
         t = v[11]; v[11] = v[14]; v[14] = t;
     }
-    static __device__ __forceinline__ void run(Cx<R> (&v)[16]) { run_tw<false>(v, nullptr); }
+    static __device__ __forceinline__ void run(Cx<R> (&v)[16]) {
+        const Cx<R> z = mk<R>(0, 0);
+        run_tw<false>(v, z, z, z);
+    }
 };
 
 // ---- radix schedules ---------------------------------------------------------------------------
@@ -282,8 +331,9 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
                         u[r] = DIR < 0 ? cmul(u[r], w) : cmulc(u[r], w);
                     });
                 });
-                Cx<R> bt[3] = {this->template twv<s, 3>(j), this->template twv<s, 4>(j), this->template twv<s, 5>(j)};
-                Dft<16, DIR, R>::template run_tw<true>(u, bt);
+                if (!HGS_ABL_BFLY)
+                    Dft<16, DIR, R>::template run_tw<true>(u, this->template twv<s, 3>(j), this->template twv<s, 4>(j),
+                                                           this->template twv<s, 5>(j));
             } else {
                 if constexpr (s > 0) {
                     static_for<1, RAD>([&](auto r_) {
@@ -292,8 +342,11 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
                         u[r] = DIR < 0 ? cmul(u[r], w) : cmulc(u[r], w);
                     });
                 }
-                Dft<RAD, DIR, R>::run(u);
+                if (!HGS_ABL_BFLY) Dft<RAD, DIR, R>::run(u);
             }
+            if constexpr (HGS_ABL_XCHG && s != Sched<N>::S - 1) {
+                static_for<0, RAD>([&](auto r_) { constexpr int r = r_; v[b + r * B] = u[r]; });
+            } else
             if constexpr (s == Sched<N>::S - 1) {
                 static_for<0, RAD>([&](auto r_) { constexpr int r = r_; v[b + r * B] = u[r]; });
             } else {
@@ -314,7 +367,7 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
                 }
             }
         });
-        if constexpr (s != Sched<N>::S - 1) {
+        if constexpr (s != Sched<N>::S - 1 && !HGS_ABL_XCHG) {
             __syncthreads();
             if constexpr (T % 16 == 0) {
                 const Cx<R>* p = lds + lds_pad(j);

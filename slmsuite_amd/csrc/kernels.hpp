@@ -251,7 +251,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                 const int c = c_lane + m * T;
                 if (valid && c >= 0 && c < g.Sw) {
                     // nf = sgn * scale * v;  _nearfield_extract :1030, :1036
-                    R p = M::atan2(v[m].y * sc, v[m].x * sc);
+                    R p = HGS_ABL_TRANS ? (v[m].y * sc + v[m].x) : M::atan2(v[m].y * sc, v[m].x * sc);
                     if (kn != nullptr) p -= kn[c];
                     ph[c] = p;
                     v[m].x = p;  // keep for the fused rebuild
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                     R p = (MODE == 2) ? v[m].x : ph[c];
                     if (kn != nullptr) p += kn[c];
                     R s, co;
-                    M::sincos(p, &s, &co);
+                    if (HGS_ABL_TRANS) { s = p; co = p + (R)1; } else M::sincos(p, &s, &co);
                     const R amv = ((am != nullptr) ? am[c] : a.amp_scalar) * sgn;
                     nf = mk<R>(amv * co, amv * s);
                 }
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     R acc_w = 0;
 
     Cx<R> v[16];
-    Cx<R> gt[NR][4];
+    R gtx[NR][4], gty[NR][4];   // the tile (scalar arrays: arrays of 2-vectors are not promoted to registers)
     R wr[16], tr[16];
 
     const bool upd = cp.do_update != 0;
@@ -666,29 +666,37 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 #pragma unroll 1
     for (int ct = blockIdx.x; ct < ntiles; ct += gridDim.x) {
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
-        static_for<0, NR>([&](auto m_) {
-            constexpr int m = m_;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
-            gt[m][0] = gt[m][1] = gt[m][2] = gt[m][3] = mk<R>(0, 0);
-            if (r >= 0 && r < g.Sh) load_row4(gh + (unsigned)r * 4u, gt[m]);
-        });
+            float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+            if (r >= 0 && r < g.Sh) {
+                const float4* q = reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
+                lo = q[0];
+                hi = q[1];
+            }
+            gtx[m][0] = lo.x; gty[m][0] = lo.y; gtx[m][1] = lo.z; gty[m][1] = lo.w;
+            gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
+        }
         if (ct == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
             issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c) * g.Ph;
-            static_for<0, 16>([&](auto m_) {
-                constexpr int m = m_;
-                if constexpr (m < NR) {
-                    Cx<R> x = gt[m][0];
-                    x = (c == 1) ? gt[m][1] : x;
-                    x = (c == 2) ? gt[m][2] : x;
-                    x = (c == 3) ? gt[m][3] : x;
-                    v[m] = x * sgn;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < NR) {
+                    R xr = gtx[m < NR ? m : 0][0], xi = gty[m < NR ? m : 0][0];
+#pragma unroll
+                    for (int cc = 1; cc < 4; ++cc) {
+                        xr = (c == cc) ? gtx[m < NR ? m : 0][cc] : xr;
+                        xi = (c == cc) ? gty[m < NR ? m : 0][cc] : xi;
+                    }
+                    v[m] = mk<R>(xr * sgn, xi * sgn);
                 } else {
                     v[m] = mk<R>(0, 0);
                 }
-            });
+            }
             fft.template run<-1, HGS_TILE_DB>(v, lds, j);
 
             R* wc = a.w + cb;
@@ -717,7 +725,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
                 Cx<R> ph;
                 if constexpr (PHASE == 2) {
-                    M::sincos(pfc[idx], &ph.y, &ph.x);
+                    R sn, cs;
+                    M::sincos(pfc[idx], &sn, &cs);
+                    ph = mk<R>(cs, sn);
                 } else {
                     if (p2 > (R)0) {
                         const R inv = M::rsqrt(p2);
@@ -741,20 +751,25 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
 
             fft.template run<+1, HGS_TILE_DB>(v, lds, j);
-            static_for<0, NR>([&](auto m_) {
-                constexpr int m = m_;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
                 const Cx<R> h = v[m] * (sgn * a.scale);
-                gt[m][0] = (c == 0) ? h : gt[m][0];
-                gt[m][1] = (c == 1) ? h : gt[m][1];
-                gt[m][2] = (c == 2) ? h : gt[m][2];
-                gt[m][3] = (c == 3) ? h : gt[m][3];
-            });
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    gtx[m][cc] = (c == cc) ? h.x : gtx[m][cc];
+                    gty[m][cc] = (c == cc) ? h.y : gty[m][cc];
+                }
+            }
         }
-        static_for<0, NR>([&](auto m_) {
-            constexpr int m = m_;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
-            if (r >= 0 && r < g.Sh) store_row4(gh + (unsigned)r * 4u, gt[m]);
-        });
+            if (r >= 0 && r < g.Sh) {
+                float4* q = reinterpret_cast<float4*>(gh + (unsigned)r * 4u);
+                q[0] = make_float4(gtx[m][0], gty[m][0], gtx[m][1], gty[m][1]);
+                q[1] = make_float4(gtx[m][2], gty[m][2], gtx[m][3], gty[m][3]);
+            }
+        }
     }
     if (cp.do_update) {
         const double s = block_sum((double)acc_w, scratch);
