@@ -410,7 +410,7 @@ template <typename R> struct Engine : EngineBase {
         }
         dim3 grid((g.Pw + 31) / 32, (g.Ph + 31) / 32, B);
         hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, (const E*)st, dst, g.Ph, g.Pw,
-                           (const R*)nullptr);
+                           (const R*)nullptr, cfg.kind == 0 ? g.Ph / 16 : 0, 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
@@ -421,7 +421,8 @@ template <typename R> struct Engine : EngineBase {
         if (int e = need_staging()) return e;
         E* st = reinterpret_cast<E*>(staging);
         dim3 grid((g.Ph + 31) / 32, (g.Pw + 31) / 32, B);
-        hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, src, st, g.Pw, g.Ph, scale);
+        hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, src, st, g.Pw, g.Ph, scale,
+                           cfg.kind == 0 ? g.Ph / 16 : 0, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(dst, st, all, dst_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));

@@ -40,6 +40,21 @@ struct Geo {
     int Ph, Pw, Sh, Sw, r0, c0, batch;
 };
 
+// Inside each column of the column-major farfield-sized arrays the Ph entries are stored
+// LANE-MAJOR: ky = j + m*T (T = Ph/16, the load layout of the column transform) sits at j*16 + m,
+// so the 16 values a lane needs are 64 contiguous bytes (4 x 16-byte loads instead of 16 scalar
+// ones, 4 KiB contiguous per wave).  Elementwise kernels are oblivious to the permutation;
+// hgs_set_array / hgs_get_array and the spot kernels apply it.
+#ifndef HGS_LANE_MAJOR
+#define HGS_LANE_MAJOR 1
+#endif
+__host__ __device__ __forceinline__ int col_pos(int ky, int T) {
+    return HGS_LANE_MAJOR ? (ky % T) * 16 + ky / T : ky;
+}
+template <int T> __device__ __forceinline__ unsigned lane_pos(int j, int m) {
+    return HGS_LANE_MAJOR ? (unsigned)(j * 16 + m) : (unsigned)(j + m * T);
+}
+
 // method codes follow ALGORITHM_INDEX (_header.py:72)
 enum { M_GS = 0, M_LEONARDO = 1, M_KIM = 2, M_NOGRETTE = 3, M_WU = 4, M_TANH = 5 };
 
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                 R* pfc = a.pff ? a.pff + cb : nullptr;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    const unsigned idx = (unsigned)(j + m * T);
+                    const unsigned idx = lane_pos<T>(j, m);
                     const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                     ffc[idx] = v[m];
                     afc[idx] = M::sqrt(p2);
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                 R* pfc = a.pff ? a.pff + cb : nullptr;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    const unsigned idx = (unsigned)(j + m * T);
+                    const unsigned idx = lane_pos<T>(j, m);
                     const Cx<R> F = v[m];
                     R wv = wc[idx] * wsc;
                     const R p2 = F.x * F.x + F.y * F.y;
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
             }
             if constexpr (MODE & C_LOAD) {
                 const Cx<R>* ffc = a.ff + cb;
-                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = ffc[(unsigned)(j + m * T)]; });
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = ffc[lane_pos<T>(j, m)]; });
             }
             if constexpr (MODE & C_INV) {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgn; });
@@ -502,8 +517,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const R* tc = a.t + cb;
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
-            wr[m] = wc[(unsigned)(j + m * T)];
-            if (cp.do_update) tr[m] = tc[(unsigned)(j + m * T)];
+            wr[m] = wc[lane_pos<T>(j, m)];
+            if (cp.do_update) tr[m] = tc[lane_pos<T>(j, m)];
         });
     };
     auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
-            const unsigned idx = (unsigned)(j + m * T);
+            const unsigned idx = lane_pos<T>(j, m);
             const Cx<R> F = v[m] * sc;
             const R p2 = F.x * F.x + F.y * F.y;
             const R wraw = wr[m];
@@ -625,8 +640,8 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
                                                R (&wr)[16], R (&tr)[16]) {
     static_for<0, 16>([&](auto m_) {
         constexpr int m = m_;
-        wr[m] = wc[(unsigned)(j + m * T)];
-        tr[m] = upd ? tc[(unsigned)(j + m * T)] : (R)0;
+        wr[m] = wc[lane_pos<T>(j, m)];
+        tr[m] = upd ? tc[lane_pos<T>(j, m)] : (R)0;
     });
 }
 
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
-                const unsigned idx = (unsigned)(j + m * T);
+                const unsigned idx = lane_pos<T>(j, m);
                 const Cx<R> F = cmul(v[m], om);
                 const R p2 = F.x * F.x + F.y * F.y;
                 const R wraw = wr[m];
@@ -934,16 +949,22 @@ template <typename R> __global__ void scale_from_sum(const double* sum, R* wscal
 
 // Tiled transpose between the host-facing natural [rows][cols] layout and the engine's
 // column-major layout, with an optional per-hologram scale (pending weight normalisation).
+// perm_T > 0: the column-major side is lane-major (col_pos) with T = perm_T; to_colmajor tells which
+// side that is (1: out is the engine layout, 0: in is the engine layout).
 template <typename E, typename R>
 __global__ void transpose_scale(const E* __restrict__ in, E* __restrict__ out, int rows, int cols,
-                                const R* scale) {
+                                const R* scale, int perm_T, int to_colmajor) {
     __shared__ E tile[32][33];
     const int b = blockIdx.z;
     const size_t off = (size_t)b * rows * cols;
     const R s = scale ? scale[b] : (R)1;
     int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
     for (int i = threadIdx.y; i < 32; i += blockDim.y)
-        if (x < cols && y0 + i < rows) tile[i][threadIdx.x] = in[off + (size_t)(y0 + i) * cols + x];
+        if (x < cols && y0 + i < rows) {
+            // reading the engine layout [cols_of_engine = rows here][Ph = cols here]: permute within the row
+            const int xs = (perm_T > 0 && !to_colmajor) ? col_pos(x, perm_T) : x;
+            tile[i][threadIdx.x] = in[off + (size_t)(y0 + i) * cols + xs];
+        }
     __syncthreads();
     x = blockIdx.y * 32 + threadIdx.x;
     y0 = blockIdx.x * 32;
@@ -951,7 +972,8 @@ __global__ void transpose_scale(const E* __restrict__ in, E* __restrict__ out, i
         if (x < rows && y0 + i < cols) {
             E v = tile[threadIdx.x][i];
             if (scale) v = v * s;
-            out[off + (size_t)(y0 + i) * rows + x] = v;
+            const int xd = (perm_T > 0 && to_colmajor) ? col_pos(x, perm_T) : x;
+            out[off + (size_t)(y0 + i) * rows + xd] = v;
         }
 }
 
@@ -980,7 +1002,7 @@ template <typename R> __global__ void spot_window(SpotArgs<R> a) {
     for (int dy = 0; dy < a.width; ++dy)
         for (int dx = 0; dx < a.width; ++dx) {
             const int x = kx + lo + dx, y = ky + lo + dy;
-            const R v = a.amp_ff[(size_t)b * P + (size_t)x * a.g.Ph + y];
+            const R v = a.amp_ff[(size_t)b * P + (size_t)x * a.g.Ph + col_pos(y, a.g.Ph / 16)];
             const R v2 = v * v;  // cp.square in working precision, then astype(float) (:1592, take :202)
             s += (double)v2;
         }
@@ -1027,7 +1049,7 @@ template <typename R> __global__ void spot_update(SpotArgs<R> a) {
     acc = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int kx = a.spot_xy[n], ky = a.spot_xy[N + n];
-        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + ky;
+        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + col_pos(ky, a.g.Ph / 16);
         const R f = (a.feedback == 2) ? (R)a.ext_amp[n] : a.fb[(size_t)b * N + n];
         const R fc = weight_factor<R>(a.cp.method, f * inv_fn, (R)a.spot_amp[n], a.cp.p_exp, a.cp.p_fac, nog);
         R wv = a.w[idx] * fc;
@@ -1041,7 +1063,7 @@ template <typename R> __global__ void spot_update(SpotArgs<R> a) {
     const R wsc = (R)1 / (R)::sqrt(bc);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int kx = a.spot_xy[n], ky = a.spot_xy[N + n];
-        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + ky;
+        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + col_pos(ky, a.g.Ph / 16);
         a.w[idx] *= wsc;
     }
 }
