@@ -151,7 +151,7 @@ def main():
             achieved = alg / dur
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and args.workload == "cfg2" and args.batch == 1 and args.method == "WGS-Leonardo":
                 try:
                     traffic = json.load(open(pmc)).get("col_fused_bytes_per_launch")
                 except Exception:
