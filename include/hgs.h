@@ -133,6 +133,16 @@ int hgs_iterate(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* fixed_phase_
  * out[batch][4] = efficiency, uniformity, pkpk_err, std_err.  Needs a materialised farfield. */
 int hgs_stats(hgs_engine* e, int group, int width, const double* spot_xy_float, double* out);
 
+/* hgs_iterate for optimize(..., stat_groups=[...]) (_hologram.py:1479): additionally returns
+ * the statistics _update_stats records in every iteration, i.e. those of the farfield the iteration
+ * starts from.  stat_groups: bit 0 "computational", bit 1 "computational_spot" (needs width and
+ * spot_xy_float as hgs_stats).  stats_out[n_iter][2][batch][4] (group slot 0 / 1; slots of groups
+ * not requested are NaN).  On the fused path the column kernel accumulates the reductions in the
+ * pass that applies the constraint (no farfield is materialised, one host read at the end);
+ * otherwise the call runs the general path with a hgs_stats per iteration. */
+int hgs_iterate_stats(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* fixed_phase_history,
+                      int stat_groups, int width, const double* spot_xy_float, double* stats_out);
+
 int hgs_sync(hgs_engine* e);
 
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */

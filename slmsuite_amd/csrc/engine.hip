@@ -57,6 +57,8 @@ struct EngineBase {
     virtual int constraint(hgs_step* st) = 0;
     virtual int f2n() = 0;
     virtual int iterate(hgs_step* st, int n, uint8_t* hist) = 0;
+    virtual int iterate_stats(hgs_step* st, int n, uint8_t* hist, int groups, int width, const double* xy,
+                              double* out) = 0;
     virtual int stats(int group, int width, const double* xy, double* out) = 0;
     virtual int sync() = 0;
     virtual int profile_enable(int on) = 0;
@@ -94,6 +96,11 @@ template <typename R> struct Engine : EngineBase {
     double* spot_amp = nullptr;
     double* ext_amp = nullptr;
     R* spot_fb = nullptr;
+    // statistics of the fused path (hgs_iterate_stats)
+    double* stat_partial = nullptr;   // [B][blocks][STAT_WAVES][STAT_N]
+    double* stat_tsum = nullptr;      // [B] sum T^2
+    struct StatCtx { int groups = 0, width = 1; double* dev_out = nullptr; int* dxy = nullptr; };
+    StatCtx* stat_ctx = nullptr;      // non-null while hgs_iterate_stats drives the fused loop
     // kind 1 (compressed)
     R* xg = nullptr;
     R* yg = nullptr;
@@ -122,7 +129,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -348,6 +355,10 @@ template <typename R> struct Engine : EngineBase {
     // ---- lazily allocated farfield-sized buffers ----
     int need_ff() {
         if (!ff) { if (dalloc(&ff, B * P)) return HGS_ERR_DEVICE; }
+        if (!aff) { if (dalloc(&aff, B * P)) return HGS_ERR_DEVICE; }
+        return 0;
+    }
+    int need_aff() {
         if (!aff) { if (dalloc(&aff, B * P)) return HGS_ERR_DEVICE; }
         return 0;
     }
@@ -790,6 +801,12 @@ template <typename R> struct Engine : EngineBase {
             int r = timed(HGS_K_COL_FUSED, [&]() -> int {
                 ColArgs<R> a = col_args();
                 a.cp = cparams(st, p);
+                if (stat_ctx) {
+                    a.do_stats = stat_ctx->groups;
+                    a.spartial = stat_partial;
+                    a.tsum = stat_tsum;
+                    a.inv_fsum = 1.0 / amp_norm2;
+                }
                 const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
                 // slots of the load layout the SLM rows occupy (tile-resident kernel needs <= 6)
                 const int Tc = g.Ph / 16;
@@ -799,13 +816,16 @@ template <typename R> struct Engine : EngineBase {
                     LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
                 } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
                     wpartial_n = tile_blocks;
-                    LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                    if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                    else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
                 } else {
-                    LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                    if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                    else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
                 }
                 return 0;
             });
             if (r) return r;
+            if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
             if (p.do_update) w_pending = true;
             // the row kernel that follows folds the weight-norm partials into wscale
@@ -813,6 +833,107 @@ template <typename R> struct Engine : EngineBase {
             st->iter++;
         }
         return 0;
+    }
+
+    // ---- hgs_iterate_stats: the loop of optimize_gs with stat_groups (_hologram.py:1465-1490) -------------
+    // Fused path: the column kernel accumulates the "computational" statistics of the field it
+    // constrains (StatAcc) and, for the spot group, stores amp_ff for the window sums; one tiny
+    // finalize launch per iteration; the host reads all n_iter results once at the end.
+    int fused_stats_finish(int i) {
+        StatCtx& c = *stat_ctx;
+        const int nparts = wpartial_n * STAT_WAVES;
+        if (c.groups & 1) {
+            hipLaunchKernelGGL(stat_finalize, dim3(B), dim3(256), 0, stream, (const double*)stat_partial, nparts,
+                               (const double*)stat_tsum, 1.0 / amp_norm2, c.dev_out + ((size_t)i * 2 + 0) * B * 4);
+            HIPCHK(hipGetLastError());
+        }
+        if (c.groups & 2) {
+            SpotArgs<R> sa{};
+            sa.g = g; sa.n_spots = cfg.n_spots; sa.width = c.width; sa.feedback = 1; sa.spot_xy = c.dxy; sa.amp_ff = aff;
+            sa.fb = spot_fb;
+            hipLaunchKernelGGL(spot_window<R>, dim3((cfg.n_spots + 127) / 128, B), dim3(128), 0, stream, sa);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(spot_stat_finalize<R>, dim3(B), dim3(256), 0, stream, (const R*)spot_fb,
+                               (const double*)spot_amp, cfg.n_spots, amp_norm2, c.dev_out + ((size_t)i * 2 + 1) * B * 4);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
+
+    int iterate_stats(hgs_step* st, int n, uint8_t* hist, int groups, int width, const double* xy,
+                      double* out) override {
+        if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
+        if (groups & ~3) return fail(HGS_ERR_ARG, "unknown statistics group mask %d", groups);
+        if (groups == 0) return iterate(st, n, hist);
+        if (!out) return fail(HGS_ERR_ARG, "statistics requested without an output buffer");
+        if (n == 0) return 0;
+        if (cfg.kind != 0) return fail(HGS_ERR_UNSUPPORTED, "hgs_iterate_stats is for the padded-grid holograms");
+        if (int e = check_step(st)) return e;
+        std::vector<int32_t> ixy;
+        if (groups & 2) {
+            if (cfg.n_spots <= 0 || !xy || !has_spots) return fail(HGS_ERR_STATE, "spot statistics need spots");
+            const int N = cfg.n_spots;
+            ixy.resize(2 * N);
+            const int flo = (int)std::floor(-(width - 1) / 2.0), fhi = flo + width - 1;
+            for (int k = 0; k < N; ++k) {
+                ixy[k] = (int32_t)std::floor(xy[k]);
+                ixy[N + k] = (int32_t)std::floor(xy[N + k]);
+                if (ixy[k] + flo < 0 || ixy[N + k] + flo < 0 || ixy[k] + fhi >= g.Pw || ixy[N + k] + fhi >= g.Ph)
+                    return fail(HGS_ERR_ARG, "integration window of spot %d leaves the grid", k);
+            }
+        }
+        for (size_t k = 0; k < (size_t)n * 2 * B * 4; ++k) out[k] = NAN;
+        const bool fused = fused_ok(st) && !env_int("HGS_FORCE_STEPWISE", 0) && !env_int("HGS_OLD_FUSED", 0);
+        if (!fused) {
+            // general path: materialise, reduce, constrain -- one host read of a few doubles per iteration
+            for (int i = 0; i < n; ++i) {
+                if (int e = n2f(0)) return e;
+                if (groups & 1) { if (int e = stats(0, 1, nullptr, out + ((size_t)i * 2 + 0) * B * 4)) return e; }
+                if (groups & 2) { if (int e = stats(1, width, xy, out + ((size_t)i * 2 + 1) * B * 4)) return e; }
+                Plan p = plan_iteration(st, hist ? hist + i : nullptr);
+                if (int e = constraint_planned(st, p)) return e;
+                if (int e = f2n()) return e;
+                st->iter++;
+            }
+            return 0;
+        }
+        StatCtx c;
+        c.groups = groups;
+        c.width = width;
+        const int max_blocks = std::max(tile_blocks, col_blocks);
+        const size_t nslots = (size_t)B * max_blocks * STAT_WAVES;
+        if (!stat_partial) { if (dalloc(&stat_partial, nslots * STAT_N)) return HGS_ERR_DEVICE; }
+        if (!stat_tsum) { if (dalloc(&stat_tsum, (size_t)B)) return HGS_ERR_DEVICE; }
+        if (groups & 2) { if (int e = need_aff()) return e; }
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c.dev_out), (size_t)n * 2 * B * 4 * sizeof(double)));
+        int r = 0;
+        do {
+            if (groups & 2) {
+                if (hipMalloc(reinterpret_cast<void**>(&c.dxy), ixy.size() * sizeof(int)) != hipSuccess) { r = fail(HGS_ERR_DEVICE, "hipMalloc"); break; }
+                if (hipMemcpyAsync(c.dxy, ixy.data(), ixy.size() * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) { r = fail(HGS_ERR_DEVICE, "hipMemcpy"); break; }
+            }
+            hipLaunchKernelGGL(stat_fill_neutral, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, stat_partial, nslots);
+            // sum T^2 (the fused path has no NaN targets)
+            hipLaunchKernelGGL(ew_sumsq<R>, dim3(ew_blocks, B), dim3(256), 0, stream, (const R*)t, P, epartial);
+            if (hipGetLastError() != hipSuccess) { r = fail(HGS_ERR_DEVICE, "statistics setup launch failed"); break; }
+            if ((r = reduce(epartial, ew_blocks, stat_tsum))) break;
+            stat_ctx = &c;
+            r = iterate(st, n, hist);
+            stat_ctx = nullptr;
+            if (r) break;
+            std::vector<double> h((size_t)n * 2 * B * 4);
+            if (hipMemcpyAsync(h.data(), c.dev_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess) { r = fail(HGS_ERR_DEVICE, "statistics read-back failed"); break; }
+            for (int i = 0; i < n; ++i)
+                for (int gidx = 0; gidx < 2; ++gidx)
+                    if (groups & (1 << gidx))
+                        std::memcpy(out + ((size_t)i * 2 + gidx) * B * 4, h.data() + ((size_t)i * 2 + gidx) * B * 4, (size_t)B * 4 * sizeof(double));
+        } while (0);
+        stat_ctx = nullptr;
+        hipStreamSynchronize(stream);
+        if (c.dev_out) hipFree(c.dev_out);
+        if (c.dxy) hipFree(c.dxy);
+        return r;
     }
 
     int iterate_timed(hgs_step* st, int n, double* ms) override {
@@ -1003,6 +1124,12 @@ int hgs_iterate(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* hist) {
     ENG(e)
     if (!step) return hgs::fail(HGS_ERR_ARG, "null step");
     return e->impl->iterate(step, n_iter, hist);
+}
+int hgs_iterate_stats(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* hist, int stat_groups, int width,
+                      const double* spot_xy_float, double* stats_out) {
+    ENG(e)
+    if (!step) return hgs::fail(HGS_ERR_ARG, "null step");
+    return e->impl->iterate_stats(step, n_iter, hist, stat_groups, width, spot_xy_float, stats_out);
 }
 int hgs_stats(hgs_engine* e, int group, int width, const double* xy, double* out) {
     ENG(e)

@@ -140,6 +140,83 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     return t;  // valid in thread 0
 }
 
+// ---- in-kernel "computational" statistics (_stats.py:7-116) for the fused column kernels -------------
+// The fused kernels see every farfield pixel F and its target T in registers, so the statistics the
+// reference computes from amp_ff / target in _update_stats are folded into the same pass:
+//   f_pwr = |F|^2 / s (s = sum |F|^2 = ||amp||^2 by Parseval),  t_pwr = T^2 / sum T^2,
+//   over T != 0:  ratio = f_pwr / t_pwr (min, max), err = t_pwr - f_pwr (min, max, sum, sum^2, count),
+//   sum T |F| (efficiency).  Per-lane accumulation over one column, wave reduction, then lane 0 of
+// each wave folds into that wave's private LDS slots (no barrier); slots go to global at kernel end.
+constexpr int STAT_N = 8;            // tf, es, es2, cnt, rmin, rmax, emin, emax
+constexpr int STAT_WAVES = 16;       // slots per workgroup in the partial buffer (max 1024 lanes)
+constexpr int SCRATCH_DOUBLES = 16 + STAT_WAVES * STAT_N;
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+template <typename R> struct StatAcc {
+    double tf, es, es2;
+    float cnt;
+    R rmin, rmax, emin, emax;            // extrema in the working precision
+    __device__ __forceinline__ void clear() {
+        tf = es = es2 = 0;
+        cnt = 0;
+        rmin = emin = INFINITY;
+        rmax = emax = -INFINITY;
+    }
+    // one pixel with T != 0 (the fused path never sees NaN targets)
+    __device__ __forceinline__ void add(R p2, R absF, R t, double at, double bf) {
+        if (t != (R)0) {
+            const double tp = (double)t * (double)t * at, fp = (double)p2 * bf;
+            if (tp != 0.0) {
+                const double ratio = fp / tp, err = tp - fp;
+                tf += (double)t * (double)absF;
+                es += err;
+                es2 += err * err;
+                cnt += 1.0f;
+                rmin = (R)fmin((double)rmin, ratio);
+                rmax = (R)fmax((double)rmax, ratio);
+                emin = (R)fmin((double)emin, err);
+                emax = (R)fmax((double)emax, err);
+            }
+        }
+    }
+    static __device__ __forceinline__ void slot_init(double* slot) {
+        if ((threadIdx.x & 63) == 0) {
+            slot[0] = slot[1] = slot[2] = slot[3] = 0;
+            slot[4] = slot[6] = INFINITY;
+            slot[5] = slot[7] = -INFINITY;
+        }
+    }
+    // all lanes of the wave call; `slot` = this wave's STAT_N doubles of LDS
+    __device__ __forceinline__ void flush(double* slot) {
+        const double a0 = wave_sum(tf), a1 = wave_sum(es), a2 = wave_sum(es2), a3 = wave_sum((double)cnt);
+        const double a4 = wave_min((double)rmin), a5 = wave_max((double)rmax), a6 = wave_min((double)emin),
+                     a7 = wave_max((double)emax);
+        if ((threadIdx.x & 63) == 0) {
+            slot[0] += a0; slot[1] += a1; slot[2] += a2; slot[3] += a3;
+            slot[4] = fmin(slot[4], a4); slot[5] = fmax(slot[5], a5);
+            slot[6] = fmin(slot[6], a6); slot[7] = fmax(slot[7], a7);
+        }
+        clear();
+    }
+    static __device__ __forceinline__ void slot_store(const double* slot, double* spartial, int b) {
+        if ((threadIdx.x & 63) == 0) {
+            double* o = spartial + (((size_t)b * gridDim.x + blockIdx.x) * STAT_WAVES + (threadIdx.x >> 6)) * STAT_N;
+#pragma unroll
+            for (int k = 0; k < STAT_N; ++k) o[k] = slot[k];
+        }
+    }
+};
+
 // ---- the WGS weight rule for one element (rows 9-10; _hologram.py:1830-1873) -------------------------
 //   fb  : feedback amplitude already divided by its L2 norm
 //   returns the multiplicative factor fc
@@ -339,6 +416,11 @@ template <typename R> struct ColArgs {
     R scale;          // 1/sqrt(Ph)
     int store_pff;    // STORE: also write phase_ff
     CParams<R> cp;
+    // fused kernels only: statistics of this iteration (hgs_iterate_stats)
+    int do_stats;          // bit 0: accumulate the "computational" statistics; bit 1: store amp_ff
+    double* spartial;      // [batch][gridDim.x][STAT_WAVES][STAT_N]
+    const double* tsum;    // [batch] sum T^2
+    double inv_fsum;       // 1 / sum |F|^2
 };
 
 template <typename R, int N, int MODE>
@@ -477,7 +559,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
 // Weight rule in log domain for Leonardo/Kim:
 //   (|F| * c / T)^-p = exp2(-p * (log2(|F|^2)/2 + log2 c - log2 T)),  T == 0 -> 1 (:1841)
 // =====================================================================================================
-template <typename R, int N, int PHASE>
+template <typename R, int N, int PHASE, bool STATS = false>
 __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel(ColArgs<R> a) {
     using M = Math<R>;
     constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
@@ -501,6 +583,14 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int ncols = my_tiles * PASSES;
     R acc_w = 0;
+    double* stat_slot = scratch + 16 + (tid >> 6) * STAT_N;
+    StatAcc<R> sacc;
+    double stat_at = 0;
+    if constexpr (STATS) {
+        sacc.clear();
+        stat_at = 1.0 / a.tsum[b];
+        StatAcc<R>::slot_init(stat_slot);
+    }
 
     Cx<R> v[16], gn[16];
     R wr[16], tr[16];
@@ -518,7 +608,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
             wr[m] = wc[lane_pos<T>(j, m)];
-            if (cp.do_update) tr[m] = tc[lane_pos<T>(j, m)];
+            if (cp.do_update || STATS) tr[m] = tc[lane_pos<T>(j, m)];
         });
     };
     auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
@@ -570,6 +660,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if (wv != wraw) wc[idx] = wv;              // unchanged values (zeros of a sparse target) stay put
                 acc_w += wv * wv;
             }
+            if constexpr (STATS) {
+                const R af = M::sqrt(p2);
+                if (a.do_stats & 2) a.amp_ff[cb + idx] = af;
+                sacc.add(p2, af, tr[m], stat_at, a.inv_fsum);
+            }
             R co, si;
             if constexpr (PHASE == 2) {
                 M::sincos(pfc[idx], &si, &co);
@@ -588,6 +683,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
 
+        if constexpr (STATS) sacc.flush(stat_slot);
         // ---- prefetch the next column while this one is transformed back ----
         if (q + 1 < ncols) {
             issue_wt(q + 1);
@@ -604,6 +700,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         }
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
     }
+    if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
     if (cp.do_update) {
         const double s = block_sum((double)acc_w, scratch);
         if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
@@ -645,7 +742,7 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
     });
 }
 
-template <typename R, int N, int PHASE, int NR>
+template <typename R, int N, int PHASE, int NR, bool STATS = false>
 __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
     using M = Math<R>;
     constexpr int T = N / 16;
@@ -674,7 +771,15 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     R gtx[NR][4], gty[NR][4];   // the tile (scalar arrays: arrays of 2-vectors are not promoted to registers)
     R wr[16], tr[16];
 
-    const bool upd = cp.do_update != 0;
+    const bool upd = cp.do_update != 0 || STATS;   // target needed by the update and by the statistics
+    double* stat_slot = scratch + 16 + (j >> 6) * STAT_N;
+    StatAcc<R> sacc;
+    double stat_at = 0;
+    if constexpr (STATS) {
+        sacc.clear();
+        stat_at = 1.0 / a.tsum[b];
+        StatAcc<R>::slot_init(stat_slot);
+    }
     const R* wbase = a.w + (size_t)b * P;
     const R* tbase = a.t + (size_t)b * P;
 
@@ -738,6 +843,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     if (wv != wraw) wc[idx] = wv;
                     acc_w += wv * wv;
                 }
+                if constexpr (STATS) {
+                    const R af = M::sqrt(p2);
+                    if (a.do_stats & 2) a.amp_ff[cb + idx] = af;
+                    sacc.add(p2, af, tr[m], stat_at, a.inv_fsum);
+                }
                 Cx<R> ph;
                 if constexpr (PHASE == 2) {
                     R sn, cs;
@@ -756,6 +866,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 v[m] = cmulc(ph, om) * wv;
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (STATS) sacc.flush(stat_slot);
             // weights/target of the next column (or of the first column of the next tile) land
             // under the inverse transform below and the next forward transform
             {
@@ -786,6 +897,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
         }
     }
+    if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
     if (cp.do_update) {
         const double s = block_sum((double)acc_w, scratch);
         if (j == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
@@ -1150,6 +1262,99 @@ __global__ void stats_pass2(const R* f, const R* t, size_t n, const double* sf_s
                 v = (k == 0 || k == 2) ? fmin(v, red[k][i]) : (k == 1 || k == 3) ? fmax(v, red[k][i]) : v + red[k][i];
             o[k] = v;
         }
+    }
+}
+
+// ---- statistics of the fused path (hgs_iterate_stats) --------------------------------------------------
+// neutral element of every slot of the per-wave partial buffer
+static __global__ void stat_fill_neutral(double* spartial, size_t nslots) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    double* o = spartial + i * STAT_N;
+    o[0] = o[1] = o[2] = o[3] = 0;
+    o[4] = o[6] = INFINITY;
+    o[5] = o[7] = -INFINITY;
+}
+
+// combine 8-slot records (sum x4, min, max, min, max) held one per thread; result valid in thread 0
+__device__ __forceinline__ void stat_block_combine(double (&v)[STAT_N], double (*red)[16]) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < STAT_N; ++k) {
+        double x = v[k];
+        if (k < 4) x = wave_sum(x);
+        else if (k == 4 || k == 6) x = wave_min(x);
+        else x = wave_max(x);
+        if (lane == 0) red[k][wid] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < STAT_N; ++k) {
+            double x = red[k][0];
+            for (int i = 1; i < nw; ++i)
+                x = (k < 4) ? x + red[k][i] : (k == 4 || k == 6) ? fmin(x, red[k][i]) : fmax(x, red[k][i]);
+            v[k] = x;
+        }
+    }
+    __syncthreads();
+}
+
+// out[b][4] = efficiency, uniformity, pkpk_err, std_err from the per-wave partials of one column launch
+static __global__ void stat_finalize(const double* spartial, int nparts, const double* tsum, double inv_fsum,
+                                     double* out) {
+    __shared__ double red[STAT_N][16];
+    const int b = blockIdx.x;
+    double v[STAT_N] = {0, 0, 0, 0, INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        const double* o = spartial + ((size_t)b * nparts + i) * STAT_N;
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        v[4] = fmin(v[4], o[4]); v[5] = fmax(v[5], o[5]); v[6] = fmin(v[6], o[6]); v[7] = fmax(v[7], o[7]);
+    }
+    stat_block_combine(v, red);
+    if (threadIdx.x == 0) {
+        const double cnt = v[3], mean = v[1] / cnt, var = fmax(0.0, v[2] / cnt - mean * mean);
+        out[4 * b + 0] = v[0] * v[0] * inv_fsum / tsum[b];           // (sum t_amp f_amp)^2
+        out[4 * b + 1] = 1 - (v[5] - v[4]) / (v[5] + v[4]);
+        out[4 * b + 2] = cnt * (v[7] - v[6]);
+        out[4 * b + 3] = cnt * ::sqrt(var);
+    }
+}
+
+// "computational_spot" group (_spots.py:1626-1679) from the window feedback of spot_window:
+// feedback = fb[n], target = spot_amp[n], efficiency = sum fb^2 / total.  One block per hologram.
+template <typename R>
+__global__ void spot_stat_finalize(const R* fb, const double* spot_amp, int n_spots, double total, double* out) {
+    __shared__ double red[STAT_N][16];
+    __shared__ double bc[2];
+    const int b = blockIdx.x;
+    double v[STAT_N] = {0, 0, 0, 0, INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int n = threadIdx.x; n < n_spots; n += blockDim.x) {
+        const double f = (double)fb[(size_t)b * n_spots + n], t = spot_amp[n];
+        v[0] += f * f;
+        if (t == t) v[1] += t * t;
+    }
+    stat_block_combine(v, red);
+    if (threadIdx.x == 0) { bc[0] = v[0]; bc[1] = v[1]; }
+    __syncthreads();
+    const double sf = bc[0], st = bc[1];
+    double u[STAT_N] = {0, 0, 0, 0, INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int n = threadIdx.x; n < n_spots; n += blockDim.x) {
+        const double f = (double)fb[(size_t)b * n_spots + n], t = spot_amp[n];
+        const double tp = t * t / st, fp = f * f / sf;
+        if (tp != 0 && tp == tp) {
+            const double ratio = fp / tp, err = tp - fp;
+            u[1] += err; u[2] += err * err; u[3] += 1;
+            u[4] = fmin(u[4], ratio); u[5] = fmax(u[5], ratio); u[6] = fmin(u[6], err); u[7] = fmax(u[7], err);
+        }
+    }
+    stat_block_combine(u, red);
+    if (threadIdx.x == 0) {
+        const double cnt = u[3], mean = u[1] / cnt, var = fmax(0.0, u[2] / cnt - mean * mean);
+        out[4 * b + 0] = sf / total;
+        out[4 * b + 1] = 1 - (u[5] - u[4]) / (u[5] + u[4]);
+        out[4 * b + 2] = cnt * (u[7] - u[6]);
+        out[4 * b + 3] = cnt * ::sqrt(var);
     }
 }
 

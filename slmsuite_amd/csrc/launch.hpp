@@ -11,6 +11,9 @@ template <typename R> int launch_col(int N, int mode, dim3 grid, hipStream_t s, 
 template <typename R> int launch_fused(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a);
 // tile-resident fused kernel: fp32, N in {4096, 8192}, at most 6 occupied load-layout slots
 template <typename R> int launch_tile(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
+// the same two kernels with the in-pass statistics compiled in (ColArgs::do_stats, hgs_iterate_stats)
+template <typename R> int launch_fused_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a);
+template <typename R> int launch_tile_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
 
 // blocks of the transform kernels resident per CU are bounded by LDS; exposed for grid sizing
 template <typename R> size_t row_lds_bytes(int N);

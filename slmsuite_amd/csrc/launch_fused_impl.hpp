@@ -1,12 +1,25 @@
-// Included by launch_fused_f32.hip / launch_fused_f64.hip with HGS_REAL defined.
+// Included by launch_fused_{,stats_}f32.hip / launch_fused_{,stats_}f64.hip with HGS_REAL defined.
+// HGS_STATS_TU = 1 builds the variants that also accumulate the statistics (hgs_iterate_stats).
 #include "launch.hpp"
 
+#ifndef HGS_STATS_TU
+#define HGS_STATS_TU 0
+#endif
+#if HGS_STATS_TU
+#define LAUNCH_FUSED launch_fused_stats
+#define LAUNCH_TILE launch_tile_stats
+#else
+#define LAUNCH_FUSED launch_fused
+#define LAUNCH_TILE launch_tile
+#endif
+
 namespace hgs {
+constexpr bool kStats = HGS_STATS_TU != 0;
 
 template <typename R, int N, int PHASE>
 static int launch_fused_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
-    constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + 16 * sizeof(double);
-    auto k = col_fused_kernel<R, N, PHASE>;
+    constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
+    auto k = col_fused_kernel<R, N, PHASE, kStats>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -26,7 +39,7 @@ static int launch_fused_n(int phase, dim3 grid, hipStream_t s, const ColArgs<R>&
     return (int)hipErrorInvalidValue;
 }
 
-template <> int launch_fused<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t s, const ColArgs<HGS_REAL>& a) {
+template <> int LAUNCH_FUSED<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t s, const ColArgs<HGS_REAL>& a) {
     switch (N) {
         case 64: return launch_fused_n<HGS_REAL, 64>(phase, grid, s, a);
         case 128: return launch_fused_n<HGS_REAL, 128>(phase, grid, s, a);
@@ -43,8 +56,8 @@ template <> int launch_fused<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t 
 #ifdef HGS_REAL_IS_FLOAT
 template <int N, int PHASE>
 static int launch_tile_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-    constexpr size_t lds = (size_t)(HGS_TILE_DB ? 2 : 1) * lds_elems<N>() * sizeof(Cx<float>) + 16 * sizeof(double);
-    auto k = col_tile_kernel<float, N, PHASE, 6>;
+    constexpr size_t lds = (size_t)(HGS_TILE_DB ? 2 : 1) * lds_elems<N>() * sizeof(Cx<float>) + SCRATCH_DOUBLES * sizeof(double);
+    auto k = col_tile_kernel<float, N, PHASE, 6, kStats>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -54,7 +67,7 @@ static int launch_tile_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, in
     return (int)hipGetLastError();
 }
 
-template <> int launch_tile<float>(int N, int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+template <> int LAUNCH_TILE<float>(int N, int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
     if (N == 4096) {
         if (phase == 0) return launch_tile_one<4096, 0>(grid, s, a, m0);
         if (phase == 1) return launch_tile_one<4096, 1>(grid, s, a, m0);
@@ -69,7 +82,7 @@ template <> int launch_tile<float>(int N, int phase, dim3 grid, hipStream_t s, c
 }
 
 #else
-template <> int launch_tile<double>(int, int, dim3, hipStream_t, const ColArgs<double>&, int) {
+template <> int LAUNCH_TILE<double>(int, int, dim3, hipStream_t, const ColArgs<double>&, int) {
     return (int)hipErrorInvalidValue;   // the tile-resident kernel is fp32 only
 }
 #endif

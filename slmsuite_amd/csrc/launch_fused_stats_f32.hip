@@ -1,0 +1,4 @@
+#define HGS_REAL float
+#define HGS_REAL_IS_FLOAT 1
+#define HGS_STATS_TU 1
+#include "launch_fused_impl.hpp"

@@ -93,6 +93,33 @@ class Engine:
         L.check(self.lib.hgs_iterate(self._h, C.byref(step), int(n_iter), hist))
         return [bool(hist[i]) for i in range(n_iter)]
 
+    STAT_GROUPS = ("computational", "computational_spot")
+
+    def iterate_stats(self, step, n_iter, groups, width=1, spot_xy=None):
+        """
+        hgs_iterate_stats: n_iter loop bodies plus the statistics recorded in each of them.
+        ``groups``: iterable of "computational" / "computational_spot".  Returns
+        (fixed_phase history, [per iteration {group: [per hologram stats dict]}]).
+        """
+        mask = sum(1 << self.STAT_GROUPS.index(g) for g in groups)
+        hist = (C.c_uint8 * max(1, n_iter))()
+        out = (C.c_double * max(1, n_iter * 2 * self.batch * 4))()
+        xy = None
+        if spot_xy is not None:
+            xy_np = np.ascontiguousarray(spot_xy, dtype=np.float64)
+            xy = xy_np.ctypes.data_as(C.POINTER(C.c_double))
+        L.check(self.lib.hgs_iterate_stats(self._h, C.byref(step), int(n_iter), hist, int(mask), int(width), xy, out))
+        res = np.array(out[:]).reshape(max(1, n_iter), 2, self.batch, 4)
+        per_iter = []
+        for i in range(n_iter):
+            d = {}
+            for gi, g in enumerate(self.STAT_GROUPS):
+                if mask & (1 << gi):
+                    d[g] = [dict(efficiency=float(r[0]), uniformity=float(r[1]), pkpk_err=float(r[2]),
+                                 std_err=float(r[3])) for r in res[i, gi]]
+            per_iter.append(d)
+        return [bool(hist[i]) for i in range(n_iter)], per_iter
+
     def iterate_timed(self, step, n_iter):
         ms = C.c_double()
         L.check(self.lib.hgs_iterate_timed(self._h, C.byref(step), int(n_iter), C.byref(ms)))

@@ -485,32 +485,46 @@ class Hologram:
         return make_step(self.flags, self.iter, false_run=self._false_run(skip_last),
                          mraf_enabled=self._mraf_enabled(), spot_window=self._spot_window())
 
-    def _needs_stepwise(self, callback):
-        fl = self.flags
-        return (callback is not None or len(fl["stat_groups"]) > 0 or fl.get("raw_stats", False)
-                or ("Kim" in fl["method"] and fl.get("fix_phase_efficiency", None) is not None))
-
     def _mark_device_fresh(self, names):
         for n in names:
             self._stale.add(n)
             self._upload.discard(n)
 
+    def _device_stat_groups(self):
+        """(groups, width, spot_xy) for Engine.iterate_stats: the groups _update_stats computes on the device."""
+        return [g for g in ("computational",) if g in self.flags["stat_groups"]], 1, None
+
+    def _device_loop_ok(self, callback):
+        """
+        True when the whole loop can run inside one engine call: no callback, no raw farfield
+        capture, no efficiency-gated Kim fixing (that decision needs this iteration's statistics on
+        the host before the constraint, :1560-1569).  Requested statistics are computed on the device
+        in the same pass (hgs_iterate_stats).
+        """
+        fl = self.flags
+        return not (callback is not None or fl.get("raw_stats", False)
+                    or ("Kim" in fl["method"] and fl.get("fix_phase_efficiency", None) is not None))
+
     def optimize_gs(self, iterations, callback):
         e = self._get_engine()
         self._pre_loop_checks()
         n_total = len(iterations)
-        if not self._needs_stepwise(callback):
-            # fused fast path: the whole loop runs on the device; flags history is replayed on the host
+        if self._device_loop_ok(callback):
+            # device-resident loop: flags history (and statistics) are replayed on the host afterwards
             bar = iterations if (tqdm is not None and not isinstance(iterations, range)) else None
             done = 0
             chunk = n_total if bar is None else max(1, n_total // 20)
+            groups, width, xy = self._device_stat_groups() if len(self.flags["stat_groups"]) > 0 else ([], 1, None)
             while done < n_total:
                 n = min(chunk, n_total - done)
                 st = self._make_step()
-                hist = e.iterate(st, n)
+                if groups:
+                    hist, per_iter = e.iterate_stats(st, n, groups, width, xy)
+                else:
+                    hist, per_iter = e.iterate(st, n), None
                 for k in range(n):
                     self.flags["fixed_phase"] = hist[k]
-                    self._update_stats_dictionary({})
+                    self._update_stats_dictionary({} if per_iter is None else {g: per_iter[k][g][0] for g in groups})
                     self.iter += 1
                 self.flags["fixed_phase"] = bool(st.fixed_phase)
                 done += n
@@ -796,6 +810,12 @@ class SpotHologram(FeedbackHologram):
         if self.flags.get("feedback") == "external_spot":
             self._engine.set(L.EXTERNAL_AMP, self.external_spot_amp)
 
+    def _device_stat_groups(self):
+        groups = [g for g in ("computational", "computational_spot") if g in self.flags["stat_groups"]]
+        if tuple(self.shape) == tuple(self.slm_shape):
+            return groups, 1, self.spot_knm_rounded
+        return groups, self.spot_integration_width_knm, self.spot_knm
+
     def _calculate_stats_computational_spot(self, stats, stat_groups=[]):
         """_spots.py:1626-1679."""
         if "computational_spot" in stat_groups:
@@ -995,9 +1015,9 @@ class CompressedSpotHologram(FeedbackHologram):
         if self.flags["feedback"] == "external_spot":
             self._engine.set(L.EXTERNAL_AMP, np.asarray(self.external_spot_amp, dtype=float))
 
-    def _needs_stepwise(self, callback):
-        # no fused kernel for this path yet: the engine loops the three operators on the device
-        return super()._needs_stepwise(callback)
+    def _device_stat_groups(self):
+        # the reference records no computational statistics for this class (_spots.py:1004-1018)
+        return [], 1, None
 
     def _update_stats(self, stat_groups=[]):
         """_spots.py:1004-1018: the computational_spot group is disabled in the reference."""

@@ -456,3 +456,87 @@ def test_callback_and_set_weights():
     np.testing.assert_allclose(h.weights, w, rtol=1e-6)
     with pytest.raises(ValueError):
         h.set_weights(np.zeros((3, 3)))
+
+
+# ---- statistics computed inside the fused pass (hgs_iterate_stats) ---------------------------
+STAT_NAMES = ("efficiency", "uniformity", "pkpk_err", "std_err")
+
+
+def _stats_table(h, group):
+    return np.array([h.stats["stats"][group][n] for n in STAT_NAMES], dtype=float)
+
+
+@pytest.mark.parametrize("name", ["spot_WGSLeonardo_computational", "spot_WGSLeonardo_computational_spot",
+                                  "spot_WGSKim_computational_spot"])
+def test_in_pass_statistics_match_general_path_and_reference(name):
+    """
+    optimize(stat_groups=[...]) without a callback keeps the loop on the device: the fused column
+    kernel accumulates the "computational" reductions and the spot windows read the amp_ff it
+    stores.  Must agree with (i) the general path (callback forces it) and (ii) the statistics the
+    reference recorded, and walk to the same end state.
+    """
+    meta, gold = load_golden(name)
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+
+    def make():
+        return SpotHologram.make_rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]),
+                                                   basis="knm", slm_shape=slm,
+                                                   phase=synth.seed_phase(meta["seed"], slm))
+    groups = ["computational", "computational_spot"]
+    h_dev, h_gen = make(), make()
+    h_dev.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, feedback=meta["feedback"],
+                   stat_groups=groups, **meta["kwargs"])
+    h_gen.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, feedback=meta["feedback"],
+                   stat_groups=groups, callback=lambda hh: False, **meta["kwargs"])
+    worst = 0.0
+    for grp in groups:
+        a, b = _stats_table(h_dev, grp), _stats_table(h_gen, grp)
+        assert a.shape == b.shape == (4, meta["maxiter"])
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-7, err_msg=grp)
+        worst = max(worst, float(np.max(np.abs(a - b) / (np.abs(b) + 1e-7))))
+        for i, n in enumerate(STAT_NAMES):
+            np.testing.assert_allclose(a[i], gold[f"stats_{grp}_{n}"], rtol=2e-3, atol=2e-6, err_msg=f"{grp}.{n}")
+    report(f"in-pass statistics {name}", device_vs_general=worst,
+           phase=phase_rel_l2(h_dev.phase, h_gen.phase))
+    assert phase_rel_l2(h_dev.phase, gold["final_phase"]) < 2e-5
+    assert h_dev.stats["flags"]["fixed_phase"] == h_gen.stats["flags"]["fixed_phase"]
+    assert h_dev.stats["method"] == h_gen.stats["method"]
+
+
+@pytest.mark.parametrize("name", ["holo_GS_A_f32", "holo_WGSKim_A_f32", "holo_GS_A_f64"])
+def test_in_pass_statistics_dense_target(name):
+    """Dense image targets (every pixel in the mask), fp32 and fp64, small transforms (col_fused_kernel)."""
+    if name not in golden_names("holo_"):
+        pytest.skip("fixture not recorded")
+    meta, gold = load_golden(name)
+    h_dev, h_gen = Hologram(**hologram_inputs(meta)), Hologram(**hologram_inputs(meta))
+    n_it = 3     # dense WGS trajectories are chaotic (SURVEY 7-5): compare while they are still together
+    h_dev.optimize(meta["method"], maxiter=n_it, verbose=False, stat_groups=["computational"], **meta["kwargs"])
+    h_gen.optimize(meta["method"], maxiter=n_it, verbose=False, stat_groups=["computational"],
+                   callback=lambda hh: False, **meta["kwargs"])
+    a, b = _stats_table(h_dev, "computational"), _stats_table(h_gen, "computational")
+    tol = 1e-9 if name.endswith("f64") else 5e-4
+    np.testing.assert_allclose(a, b, rtol=tol, atol=1e-9 if name.endswith("f64") else 1e-7)
+    for i, n in enumerate(STAT_NAMES):
+        np.testing.assert_allclose(a[i], np.asarray(gold[f"stats_computational_{n}"])[:n_it],
+                                   rtol=0.3 if "WGS" in meta["method"] else 2e-3, atol=1e-6)
+
+
+def test_in_pass_statistics_full_size_and_batch():
+    """cfg 2 geometry (tile-resident kernel): in-pass statistics vs hgs_stats on the materialised farfield."""
+    shape, slm = (4096, 4096), (1152, 1920)
+    h = SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm,
+                                            phase=synth.seed_phase(2, slm))
+    h.optimize("WGS-Leonardo", maxiter=4, verbose=False, stat_groups=["computational", "computational_spot"])
+    g = SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm,
+                                            phase=synth.seed_phase(2, slm))
+    g.optimize("WGS-Leonardo", maxiter=4, verbose=False, stat_groups=["computational", "computational_spot"],
+               callback=lambda hh: False)
+    for grp in ("computational", "computational_spot"):
+        a, b = _stats_table(h, grp), _stats_table(g, grp)
+        report(f"in-pass statistics cfg2 {grp}", max_rel=float(np.max(np.abs(a - b) / (np.abs(b) + 1e-7))))
+        np.testing.assert_allclose(a, b, rtol=5e-4, atol=1e-7, err_msg=grp)
+    assert phase_rel_l2(h.phase, g.phase) < 1e-4
+    # uniformity must improve and stay in [0, 1]
+    u = h.stats["stats"]["computational_spot"]["uniformity"]
+    assert 0 < u[0] < u[-1] <= 1
