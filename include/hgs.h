@@ -143,6 +143,15 @@ int hgs_stats(hgs_engine* e, int group, int width, const double* spot_xy_float, 
 int hgs_iterate_stats(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* fixed_phase_history,
                       int stat_groups, int width, const double* spot_xy_float, double* stats_out);
 
+/* MultiplaneHologram._farfield2nearfield (_multiplane.py:255-279): every child runs
+ * _farfield2nearfield(extract=False) on its own (constrained) farfield; the children's complex
+ * nearfields over the SLM are summed on the device,
+ *     nf = sum_k weights[k] * nf_k * exp(-i propagation_kernel_k),   phase = atan2(nf),
+ * and the common phase is written into every child's HGS_PHASE (the reference's children share
+ * one phase array).  Children may differ in pad shape and kind but must agree in SLM shape,
+ * batch, precision and device; n <= 16.  Synchronous. */
+int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double* weights, int n);
+
 int hgs_sync(hgs_engine* e);
 
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */

@@ -278,6 +278,12 @@ class OracleHologram:
         if self.propagation_kernel is not None:
             self.phase -= self.propagation_kernel
 
+    def inverse_nearfield(self):
+        """_farfield2nearfield(extract=False) (:1058-1073): complex nearfield cropped to the SLM."""
+        self.nearfield = np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(self.farfield), norm="ortho"))
+        r0, r1, c0, c1 = unpad_slices(self.shape, self.slm_shape)
+        return self.nearfield[r0:r1, c0:c1]
+
     def populate_results(self):
         """_hologram.py:934-949."""
         self.nearfield2farfield()
@@ -433,6 +439,64 @@ class OracleHologram:
             self.iter += 1
         if populate:
             self.populate_results()
+
+
+class OracleMultiplaneHologram:
+    """
+    Composite of several oracle holograms sharing one phase mask (MultiplaneHologram,
+    _multiplane.py:8-289): per iteration every child transforms forward (:245-249), records its
+    own statistics (:224-226) and applies its own constraint (:281-283); the children's complex
+    nearfields over the SLM, each with its propagation kernel removed, are summed with the
+    L2-normalised weights and the common phase is the argument of the sum (:251-276).
+    """
+
+    def __init__(self, holograms, weights=None):
+        self.holograms = list(holograms)
+        h0 = self.holograms[0]
+        self.dtype, self.ctype, self.slm_shape = h0.dtype, h0.ctype, h0.slm_shape
+        self.amp = h0.amp
+        self.phase = h0.phase
+        for h in self.holograms:                       # shared data (:73-76)
+            h.amp = self.amp
+            h.phase = self.phase
+        if weights is None:
+            weights = np.ones(len(self.holograms), dtype=self.dtype)
+        self.weights = np.array(weights, dtype=self.dtype)
+        self.weights /= l2norm(self.weights)
+        self.nearfield = np.zeros(self.slm_shape, dtype=self.ctype)
+        self.flags = {}
+        self.iter = 0
+
+    def optimize(self, method="GS", maxiter=20, callback=None, feedback=None, stat_groups=(), **kwargs):
+        self.holograms[0].update_flags(method, feedback, list(stat_groups), **kwargs)
+        self.flags = dict(self.holograms[0].flags)
+        for h in self.holograms:                       # _update_flags :176-182
+            h.flags.update(self.flags)
+        masks = [h.mraf_masks() for h in self.holograms]
+        for _ in range(maxiter):
+            for h in self.holograms:
+                h.nearfield2farfield()
+                h.iter = self.iter
+            if callback is not None and callback(self):
+                break
+            for h in self.holograms:
+                h.update_stats(self.flags["stat_groups"])
+            for h, m in zip(self.holograms, masks):
+                h.gs_farfield_routines(m)
+            self.nearfield.fill(0)
+            for h, w in zip(self.holograms, self.weights):
+                nf = h.inverse_nearfield()
+                if h.propagation_kernel is None:
+                    self.nearfield += w * nf
+                else:
+                    self.nearfield += w * nf * np.exp(-1j * h.propagation_kernel)
+                h.iter = self.iter
+            # one shared array: every child sees the new phase (:1026-1036 on the parent)
+            np.arctan2(self.nearfield.imag, self.nearfield.real, out=self.phase)
+            self.iter += 1
+        for h in self.holograms:                       # _populate_results through the overload
+            h.nearfield2farfield()
+            h.iter = self.iter
 
 
 class OracleSpotHologram(OracleHologram):

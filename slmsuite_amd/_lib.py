@@ -65,6 +65,7 @@ def load():
         "hgs_farfield2nearfield": (C.c_int, [eng]),
         "hgs_iterate": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_uint8)]),
         "hgs_stats": (C.c_int, [eng, C.c_int, C.c_int, P(C.c_double), P(C.c_double)]),
+        "hgs_multiplane_farfield2nearfield": (C.c_int, [P(eng), P(C.c_double), C.c_int]),
         "hgs_iterate_stats": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_uint8), C.c_int, C.c_int,
                                         P(C.c_double), P(C.c_double)]),
         "hgs_sync": (C.c_int, [eng]),
@@ -84,7 +85,7 @@ def load():
 
 EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device",
            "hgs_reset_weights", "hgs_nearfield2farfield", "hgs_farfield_constraint",
-           "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_sync", "hgs_profile_enable",
+           "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_multiplane_farfield2nearfield", "hgs_sync", "hgs_profile_enable",
            "hgs_profile_read", "hgs_iterate_timed", "hgs_last_error", "hgs_version")
 
 

@@ -30,6 +30,7 @@ template <typename R> struct CArgs {
     int nblocks;
     double* fsum;       // [b] sum |ff|^2 after normalisation (= 1) for the constraint kernels
     int degree;         // max(px + py)
+    Cx<R>* nf_out;      // c_f2n: store the complex nearfield [b][S] (scaled 1/sqrt(S)) instead of the phase
 };
 
 template <typename R> struct Trig;
@@ -216,9 +217,14 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_f2n(CAr
     for (int i = 0; i < C_PT; ++i) {
         const int p = (blockIdx.x * C_PT + i) * C_WG + tid;
         if (p < a.S) {
-            R ph = M::atan2(im[i], re[i]);         // the 1/sqrt(S) scale does not change the phase (:1030)
-            if (a.kern) ph -= a.kern[p];
-            a.phase[(size_t)b * a.S + p] = ph;
+            if (a.nf_out != nullptr) {             // _farfield2nearfield(extract=False) (_spots.py:887-914)
+                const R sc = M::rsqrt((R)a.S);
+                a.nf_out[(size_t)b * a.S + p] = mk<R>(re[i] * sc, im[i] * sc);
+            } else {
+                R ph = M::atan2(im[i], re[i]);     // the 1/sqrt(S) scale does not change the phase (:1030)
+                if (a.kern) ph -= a.kern[p];
+                a.phase[(size_t)b * a.S + p] = ph;
+            }
         }
     }
 }

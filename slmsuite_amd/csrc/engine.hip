@@ -56,6 +56,11 @@ struct EngineBase {
     virtual int n2f(int store_pff) = 0;
     virtual int constraint(hgs_step* st) = 0;
     virtual int f2n() = 0;
+    // MultiplaneHologram support: inverse transform without phase extraction, and the cross-engine combine
+    struct MpInfo { void* nf; const void* kern; void* phase; size_t S; int B; int real_bytes; int device; hipStream_t stream; };
+    virtual int f2n_complex() = 0;
+    virtual int mp_info(MpInfo* out) = 0;
+    virtual int mp_combine(const MpInfo* infos, const double* weights, int n) = 0;
     virtual int iterate(hgs_step* st, int n, uint8_t* hist) = 0;
     virtual int iterate_stats(hgs_step* st, int n, uint8_t* hist, int groups, int width, const double* xy,
                               double* out) = 0;
@@ -96,6 +101,7 @@ template <typename R> struct Engine : EngineBase {
     double* spot_amp = nullptr;
     double* ext_amp = nullptr;
     R* spot_fb = nullptr;
+    C* nfbuf = nullptr;               // [B][Sh][Sw] complex nearfield of f2n_complex (MultiplaneHologram)
     // statistics of the fused path (hgs_iterate_stats)
     double* stat_partial = nullptr;   // [B][blocks][STAT_WAVES][STAT_N]
     double* stat_tsum = nullptr;      // [B] sum T^2
@@ -129,7 +135,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -649,6 +655,58 @@ template <typename R> struct Engine : EngineBase {
         return run_row(1, false);
     }
 
+    // Hologram._farfield2nearfield(extract=False) (:1058-1073): the complex nearfield over the SLM,
+    // kept on the device for MultiplaneHologram's weighted sum
+    int f2n_complex() override {
+        if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
+        if (!nfbuf) { if (dalloc(&nfbuf, B * S)) return HGS_ERR_DEVICE; }
+        if (cfg.kind == 1) {
+            int r = timed(HGS_K_COL_INV, [&]() -> int {
+                CArgs<R> a = cargs();
+                a.nf_out = nfbuf;
+                const dim3 grid(c_nblocks, B);
+                if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
+                else if (c_degree == 2) hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a);
+                else hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a);
+                HIPCHK(hipGetLastError());
+                return 0;
+            });
+            farfield_valid = false;
+            return r;
+        }
+        int r = timed(HGS_K_COL_INV, [&]() -> int {
+            LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(col_blocks, B), stream, col_args()));
+            return 0;
+        });
+        if (r) return r;
+        farfield_valid = false;
+        return timed(HGS_K_ROW, [&]() -> int {
+            RowArgs<R> a = row_args(false);
+            a.nf_out = nfbuf;
+            LCHK(launch_row<R>(g.Pw, 1, dim3(row_blocks, B), stream, a));
+            return 0;
+        });
+    }
+    int mp_info(MpInfo* o) override {
+        o->nf = nfbuf; o->kern = has_kern ? kern : nullptr; o->phase = phase; o->S = S; o->B = B;
+        o->real_bytes = (int)sizeof(R); o->device = cfg.device; o->stream = stream;
+        return 0;
+    }
+    int mp_combine(const MpInfo* infos, const double* weights, int n) override {
+        MpArgs<R> a{};
+        a.n = n; a.S = S; a.total = (size_t)B * S;
+        for (int k = 0; k < n; ++k) {
+            a.nf[k] = static_cast<const C*>(infos[k].nf);
+            a.kern[k] = static_cast<const R*>(infos[k].kern);
+            a.phase[k] = static_cast<R*>(infos[k].phase);
+            a.w[k] = (R)weights[k];
+        }
+        hipLaunchKernelGGL(multiplane_combine<R>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
     // flag evolution of _gs_farfield_routines (:1552-1585); returns what this iteration must do
     struct Plan { int do_update, use_fixed, store_phase; };
     Plan plan_iteration(hgs_step* st, uint8_t* hist_slot) {
@@ -1120,6 +1178,23 @@ int hgs_farfield_constraint(hgs_engine* e, hgs_step* step) {
     return e->impl->constraint(step);
 }
 int hgs_farfield2nearfield(hgs_engine* e) { ENG(e) return e->impl->f2n(); }
+int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double* weights, int n) {
+    if (!children || !weights || n < 1) return hgs::fail(HGS_ERR_ARG, "multiplane: need at least one child and its weight");
+    if (n > hgs::MP_MAX) return hgs::fail(HGS_ERR_UNSUPPORTED, "multiplane: at most %d children", hgs::MP_MAX);
+    hgs::EngineBase::MpInfo info[hgs::MP_MAX];
+    for (int k = 0; k < n; ++k) {
+        if (!children[k] || !children[k]->impl) return hgs::fail(HGS_ERR_ARG, "multiplane: null child %d", k);
+        if (int r = children[k]->impl->f2n_complex()) return r;
+        if (int r = children[k]->impl->mp_info(&info[k])) return r;
+        if (info[k].S != info[0].S || info[k].B != info[0].B || info[k].real_bytes != info[0].real_bytes ||
+            info[k].device != info[0].device)
+            return hgs::fail(HGS_ERR_ARG, "multiplane: child %d differs in SLM shape, batch, precision or device", k);
+    }
+    // every child's inverse transform must have landed before child 0's stream reads them
+    for (int k = 1; k < n; ++k)
+        if (hipStreamSynchronize(info[k].stream) != hipSuccess) return hgs::fail(HGS_ERR_DEVICE, "multiplane: stream sync failed");
+    return children[0]->impl->mp_combine(info, weights, n);
+}
 int hgs_iterate(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* hist) {
     ENG(e)
     if (!step) return hgs::fail(HGS_ERR_ARG, "null step");

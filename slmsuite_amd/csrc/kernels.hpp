@@ -274,6 +274,8 @@ template <typename R> struct RowArgs {
     int n_wpartial;
     R* wscale;
     int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
+    Cx<R>* nf_out;       // MODE 1 only: store the complex nearfield rows [b][Sh][Sw] instead of extracting
+                         // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
 };
 
 template <typename R, int N, int MODE>
@@ -343,10 +345,14 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                 const int c = c_lane + m * T;
                 if (valid && c >= 0 && c < g.Sw) {
                     // nf = sgn * scale * v;  _nearfield_extract :1030, :1036
-                    R p = HGS_ABL_TRANS ? (v[m].y * sc + v[m].x) : M::atan2(v[m].y * sc, v[m].x * sc);
-                    if (kn != nullptr) p -= kn[c];
-                    ph[c] = p;
-                    v[m].x = p;  // keep for the fused rebuild
+                    if (MODE == 1 && a.nf_out != nullptr) {
+                        (a.nf_out + (size_t)b * g.Sh * g.Sw + srow)[c] = v[m] * sc;
+                    } else {
+                        R p = HGS_ABL_TRANS ? (v[m].y * sc + v[m].x) : M::atan2(v[m].y * sc, v[m].x * sc);
+                        if (kn != nullptr) p -= kn[c];
+                        ph[c] = p;
+                        v[m].x = p;  // keep for the fused rebuild
+                    }
                 }
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
@@ -1356,6 +1362,38 @@ __global__ void spot_stat_finalize(const R* fb, const double* spot_amp, int n_sp
         out[4 * b + 2] = cnt * (u[7] - u[6]);
         out[4 * b + 3] = cnt * ::sqrt(var);
     }
+}
+
+// ---- MultiplaneHologram._farfield2nearfield (_multiplane.py:255-279) -----------------------------------
+// phase = atan2( sum_k w_k * nf_k * exp(-i kernel_k) ), written into every child's phase buffer
+// (the children share one phase array in the reference).
+constexpr int MP_MAX = 16;
+template <typename R> struct MpArgs {
+    int n;
+    size_t S;       // SLM pixels per hologram
+    size_t total;   // batch * S
+    const Cx<R>* nf[MP_MAX];
+    const R* kern[MP_MAX];   // or nullptr
+    R w[MP_MAX];
+    R* phase[MP_MAX];
+};
+template <typename R> __global__ void multiplane_combine(MpArgs<R> a) {
+    using M = Math<R>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const size_t p = i % a.S;
+    Cx<R> acc = mk<R>(0, 0);
+    for (int k = 0; k < a.n; ++k) {
+        Cx<R> v = a.nf[k][i];
+        if (a.kern[k] != nullptr) {
+            R sn, cs;
+            M::sincos(a.kern[k][p], &sn, &cs);
+            v = mk<R>(v.x * cs + v.y * sn, v.y * cs - v.x * sn);   // v * exp(-i kernel)
+        }
+        acc = acc + v * a.w[k];
+    }
+    const R ph = M::atan2(acc.y, acc.x);
+    for (int k = 0; k < a.n; ++k) a.phase[k][i] = ph;
 }
 
 }  // namespace hgs

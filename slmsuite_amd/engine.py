@@ -136,6 +136,14 @@ class Engine:
         return [dict(efficiency=float(r[0]), uniformity=float(r[1]), pkpk_err=float(r[2]), std_err=float(r[3]))
                 for r in res]
 
+    @staticmethod
+    def multiplane_farfield2nearfield(engines, weights):
+        """hgs_multiplane_farfield2nearfield: common phase of the children from their weighted complex nearfields."""
+        n = len(engines)
+        handles = (C.c_void_p * n)(*[e._h for e in engines])
+        w = (C.c_double * n)(*[float(x) for x in weights])
+        L.check(engines[0].lib.hgs_multiplane_farfield2nearfield(handles, w, n))
+
     def sync(self):
         L.check(self.lib.hgs_sync(self._h))
 

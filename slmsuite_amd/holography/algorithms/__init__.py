@@ -333,11 +333,12 @@ class Hologram:
 
     def get_farfield(self, shape=None, propagation_kernel=None, affine=None, get=True):
         """
-        Complex DFT farfield of the current phase at an arbitrary power-of-two ``shape``
-        (_hologram.py:853-931).  Computed by a transient engine of that shape.
+        Complex DFT farfield of the current phase at an arbitrary power-of-two ``shape``, optionally at
+        another depth (``propagation_kernel``) and resampled by ``affine`` (_hologram.py:853-931; the
+        call SimulatedCamera makes per frame).  One engine per requested shape is kept alive, so
+        repeated calls cost two kernels plus the read-back.  The affine step is the reference's own
+        host call (``scipy.ndimage.affine_transform``, order 3, constant 0) on the downloaded field.
         """
-        if affine is not None:
-            raise NotImplementedError("affine resampling of the farfield is outside the optimize() path of this build")
         if shape is None:
             shape = self.shape
         if len(shape) == 1:
@@ -345,24 +346,33 @@ class Hologram:
         shape = (int(shape[0]), int(shape[1]))
         if propagation_kernel is None:
             propagation_kernel = self.propagation_kernel
-        e = Engine(shape, self.slm_shape, self.dtype, batch=1)
-        try:
-            if np.isscalar(self.amp):
-                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
-            else:
-                e.set(L.AMP, self.amp)
-            if propagation_kernel is not None and not np.isscalar(propagation_kernel):
-                e.set(L.PROP_KERNEL, np.array(propagation_kernel, dtype=self.dtype))
-            elif propagation_kernel is not None and propagation_kernel != 0:
-                e.set(L.PROP_KERNEL, np.full(self.slm_shape, propagation_kernel, dtype=self.dtype))
-            e.set(L.PHASE, self.phase)
-            e.nearfield2farfield(store_phase_ff=True)
-            ff = e.get(L.FARFIELD)[0]
-            if shape == tuple(self.shape) and self._host.get("amp_ff") is not None:
-                self.amp_ff = e.get(L.AMP_FF)[0]
-                self.phase_ff = e.get(L.PHASE_FF)[0]
-        finally:
-            e.close()
+        if propagation_kernel is None:
+            propagation_kernel = 0
+        engines = self.__dict__.setdefault("_ff_engines", {})
+        e = engines.get(shape)
+        if e is None:
+            e = engines[shape] = Engine(shape, self.slm_shape, self.dtype, batch=1)
+        if np.isscalar(self.amp):
+            e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
+        else:
+            e.set(L.AMP, self.amp)
+        if np.isscalar(propagation_kernel):
+            kern = np.full(self.slm_shape, propagation_kernel, dtype=self.dtype)
+        else:
+            kern = np.ascontiguousarray(propagation_kernel, dtype=self.dtype)
+            if kern.shape != tuple(self.slm_shape):
+                raise ValueError(f"propagation_kernel must have the SLM shape {tuple(self.slm_shape)}")
+        e.set(L.PROP_KERNEL, kern)
+        e.set(L.PHASE, self.phase)
+        e.nearfield2farfield(store_phase_ff=True)
+        ff = e.get(L.FARFIELD)[0]
+        if shape == tuple(self.shape) and self._host.get("amp_ff") is not None:
+            self.amp_ff = e.get(L.AMP_FF)[0]
+            self.phase_ff = e.get(L.PHASE_FF)[0]
+        if affine is not None:
+            from scipy.ndimage import affine_transform
+            ff = affine_transform(input=ff, matrix=affine["M"], offset=affine["b"], output_shape=shape, order=3,
+                                  mode="constant", cval=0)
         return ff
 
     # ---- statistics bookkeeping (_stats.py:118-223) ---------------------------------------------------------
@@ -543,19 +553,23 @@ class Hologram:
                         break
                     self._get_engine()
                 self._update_stats(self.flags["stat_groups"])
-                # the engine re-counts the history entry _update_stats just appended
-                st = self._make_step(skip_last=True)
-                if self._kim_efficiency_gate():
-                    # fix_phase_efficiency reached (:1560-1569): fix (and store the phase) right now
-                    st.fix_phase_iteration = 1
-                    st.false_run = 0
-                e.farfield_constraint(st)
-                self.flags["fixed_phase"] = bool(st.fixed_phase)
-                self._mark_device_fresh(["weights", "phase_ff", "farfield"])
+                self._constraint_step(e)
                 e.farfield2nearfield()
                 self._mark_device_fresh(["phase"])
                 self.iter += 1
         self._populate_results()
+
+    def _constraint_step(self, e):
+        """_gs_farfield_routines (:1550-1661) of the general path, after _update_stats of this iteration."""
+        # the engine re-counts the history entry _update_stats just appended
+        st = self._make_step(skip_last=True)
+        if self._kim_efficiency_gate():
+            # fix_phase_efficiency reached (:1560-1569): fix (and store the phase) right now
+            st.fix_phase_iteration = 1
+            st.false_run = 0
+        e.farfield_constraint(st)
+        self.flags["fixed_phase"] = bool(st.fixed_phase)
+        self._mark_device_fresh(["weights", "phase_ff", "farfield"])
 
     def _pre_loop_checks(self):
         fb = self.flags.get("feedback", "computational")
@@ -1025,3 +1039,148 @@ class CompressedSpotHologram(FeedbackHologram):
 
     def get_farfield(self, *args, **kwargs):
         raise NotImplementedError("CompressedSpotHologram has no DFT-grid farfield; see .farfield for the spots")
+
+
+class MultiplaneHologram(Hologram):
+    """
+    Several holograms -- other planes of focus, other point sets -- optimised together into one
+    phase mask (reference: ``MultiplaneHologram``, _multiplane.py:8-289).  The children keep their own
+    engines, targets, weights, flags history and statistics; per iteration each child transforms the
+    shared phase forward and applies its own constraint, then the engine sums the children's
+    complex nearfields on the GPU (``hgs_multiplane_farfield2nearfield``) into the new common phase.
+
+    ``weights`` (one per child, L2-normalised) redistribute power between the children.
+    """
+
+    def __init__(self, holograms, weights=None):
+        self.holograms = list(holograms)
+        if len(self.holograms) == 0:
+            raise ValueError("Multiplane hologram must be provided child holograms")
+        for h in self.holograms:
+            if "MultiplaneHologram" in str(type(h)):
+                raise ValueError("Multiplane hologram recursion is not supported.")
+            if "Hologram" not in str(type(h)):
+                raise ValueError(f"Multiplane hologram must be provided child holograms, not {type(h)}")
+        h0 = self.holograms[0]
+        for h in self.holograms[1:]:
+            if tuple(h.slm_shape) != tuple(h0.slm_shape) or h.dtype != h0.dtype:
+                raise ValueError("All child holograms must share one SLM shape and precision")
+        self._mp_ready = False
+        # (the reference needs array-valued child amplitudes here; a scalar amp = uniform is accepted too)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")             # the fake target has the (non power-of-two) SLM shape
+            super().__init__(target=h0.slm_shape,      # the parent has a fake target (:63-70)
+                             amp=None if np.isscalar(h0.amp) else h0.amp, phase=h0.phase,
+                             slm_shape=h0.slm_shape, dtype=h0.dtype)
+        self.target = None
+        self._mp_ready = True
+        # the children point to the same data (:73-76)
+        for h in self.holograms:
+            h.amp = self.amp
+            if h._engine is not None:                   # a new amplitude needs a fresh engine
+                h._engine.close()
+                h._engine = None
+        self.phase = self._host["phase"]
+        if weights is None:
+            weights = np.ones(len(self), dtype=self.dtype)
+        self.weights = np.array(weights, dtype=self.dtype)
+        if self.weights.shape != (len(self),):
+            raise ValueError("Expected one weight per child hologram")
+        self.weights = self.weights / _norm(self.weights)
+
+    def __len__(self):
+        return len(self.holograms)
+
+    # ---- the shared phase ---------------------------------------------------------------------------
+    def _get_dev(self, name):
+        if name == "phase" and "phase" in self._stale:
+            self._host["phase"] = self.holograms[0].phase
+            self._stale.discard("phase")
+        return self._host.get(name)
+
+    def _set_dev(self, name, value):
+        self._host[name] = value
+        self._stale.discard(name)
+        if name == "phase" and value is not None and getattr(self, "_mp_ready", False):
+            for h in self.holograms:
+                h.phase = value
+
+    phase = property(lambda s: s._get_dev("phase"), lambda s, v: s._set_dev("phase", v))
+    weights = property(lambda s: s._get_dev("weights"), lambda s, v: s._set_dev("weights", v))
+
+    def _get_engine(self):
+        raise RuntimeError("MultiplaneHologram has no engine of its own; its children do")
+
+    # ---- meta functionality (_multiplane.py:174-289) -----------------------------------------------------
+    def _update_flags(self, method, verbose, feedback, stat_groups, **kwargs):
+        super()._update_flags(method, verbose, feedback, stat_groups, **kwargs)
+        for h in self.holograms:
+            h.flags.update(self.flags)
+
+    def reset(self, reset_phase=True, reset_flags=False):
+        if getattr(self, "_mp_ready", False):
+            if reset_phase or self._host.get("phase") is None:
+                self.reset_phase()
+            self.iter = 0
+            self.stats = {"method": [], "flags": {}, "stats": {}}
+            if reset_flags:
+                self.flags = {"method": ""}
+            for h in self.holograms:
+                h.reset(reset_phase=False, reset_flags=reset_flags)
+                h.phase = self._host["phase"]
+        else:
+            super().reset(reset_phase, reset_flags)
+
+    def reset_weights(self):
+        if getattr(self, "_mp_ready", False):
+            for h in self.holograms:
+                h.reset_weights()
+        else:
+            super().reset_weights()
+
+    def _update_stats(self, stat_groups=[]):
+        for h in self.holograms:
+            h._update_stats(stat_groups)
+
+    def set_target(self, *args, **kwargs):
+        raise RuntimeError("Do not use MultiplaneHologram.set_target(). "
+                           "Instead, update the targets of the children holograms directly.")
+
+    def get_farfield(self, *args, **kwargs):
+        raise NotImplementedError("MultiplaneHologram has no farfield of its own; ask a child hologram")
+
+    def optimize_gs(self, iterations, callback):
+        """The loop of optimize_gs (:1465-1490) with the overloads of _multiplane.py:245-289."""
+        for h in self.holograms:
+            h._pre_loop_checks()
+        for _ in iterations:
+            # (A) every child populates its own farfield from the shared phase (:245-249)
+            for h in self.holograms:
+                h._get_engine().nearfield2farfield(store_phase_ff=False)
+                h._mark_device_fresh(["farfield", "amp_ff"])
+                h.iter = self.iter
+            if callback is not None:
+                if callback(self):
+                    break
+            self._update_stats(self.flags["stat_groups"])
+            # (B) each child's own constraint and weight update (:281-283)
+            for h in self.holograms:
+                h._constraint_step(h._get_engine())
+            # (C) weighted sum of the complex nearfields -> common phase (:251-276)
+            Engine.multiplane_farfield2nearfield([h._get_engine() for h in self.holograms], self.weights)
+            for h in self.holograms:
+                h._mark_device_fresh(["phase"])
+                h.iter = self.iter
+            self._stale.add("phase")
+            self.iter += 1
+        self._populate_results()
+
+    def _populate_results(self):
+        """:934-949 with the overloaded _nearfield2farfield: the children's farfield and amp_ff are refreshed."""
+        for h in self.holograms:
+            h._get_engine().nearfield2farfield(store_phase_ff=False)
+            h._mark_device_fresh(["farfield", "amp_ff"])
+            h.iter = self.iter
+
+
+__all__ += ["CompressedSpotHologram", "MultiplaneHologram"]

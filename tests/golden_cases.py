@@ -32,3 +32,31 @@ def hologram_inputs(meta):
 
 def spot_external_amp(meta, spot_amp):
     return spot_amp * (1 + 0.2 * (synth.uniform01(meta["seed"], (len(spot_amp),), 5) - 0.5))
+
+
+# ---- MultiplaneHologram fixtures (tools/make_golden.py gen_multiplane_cases) -----------------------------
+MULTIPLANE_SLM = (48, 80)
+MULTIPLANE_WEIGHTS = (1.0, 2.0, 0.5)
+
+
+def multiplane_children(Hologram, SpotHologram, make_spots=None, dtype=np.float32):
+    """
+    The three children of the multiplane fixtures, built from the given classes (reference, product
+    or oracle adapters): a dense image at another depth (propagation kernel), a spot array on a larger
+    grid, a dense image on a non-square grid.  All share the 48x80 SLM and the seed phase 700.
+    """
+    slm = MULTIPLANE_SLM
+    dt = np.dtype(dtype).type
+    phase0 = synth.seed_phase(700, slm, dtype=dt)
+    amp = synth.gaussian_amp(slm, dtype=dt)
+    kern = (0.3 * synth.seed_phase(701, slm)).astype(dt)
+    h1 = Hologram(synth.random_target(702, (128, 128), dtype=dt), amp=amp.copy(), phase=phase0.copy(),
+                  slm_shape=slm, dtype=dt, propagation_kernel=kern)
+    if make_spots is None:
+        h2 = SpotHologram.make_rectangular_array((256, 256), array_shape=(6, 6), array_pitch=(20, 20), basis="knm",
+                                                 slm_shape=slm, amp=amp.copy(), phase=phase0.copy(), dtype=dt)
+    else:
+        h2 = make_spots((256, 256), (6, 6), (20, 20), slm, amp.copy(), phase0.copy(), dt)
+    h3 = Hologram(synth.random_target(703, (64, 128), dtype=dt), amp=amp.copy(), phase=phase0.copy(),
+                  slm_shape=slm, dtype=dt)
+    return [h1, h2, h3]

@@ -540,3 +540,35 @@ def test_in_pass_statistics_full_size_and_batch():
     # uniformity must improve and stay in [0, 1]
     u = h.stats["stats"]["computational_spot"]["uniformity"]
     assert 0 < u[0] < u[-1] <= 1
+
+
+def test_get_farfield_shape_kernel_affine():
+    """Hologram.get_farfield (_hologram.py:853-931): other DFT shapes, a depth kernel, the affine resample."""
+    from scipy.ndimage import affine_transform
+    from slmsuite_amd.holography import toolbox
+    slm, shape = (72, 120), (256, 256)
+    h = Hologram(synth.random_target(5, shape), phase=synth.seed_phase(5, slm), slm_shape=slm,
+                 amp=synth.gaussian_amp(slm))
+    h.optimize("GS", maxiter=3, verbose=False)
+    kern = (0.3 * synth.seed_phase(6, slm)).astype(np.float32)
+
+    def expected(shp, k):
+        nf = toolbox.pad(h.amp * np.exp(1j * (h.phase.astype(np.float64) + k)), shp)
+        return np.fft.fftshift(np.fft.fft2(np.fft.fftshift(nf), norm="ortho"))
+
+    for shp, k in (((256, 256), 0), ((512, 1024), kern), ((128, 128), kern), ((256, 256), kern)):
+        ff = h.get_farfield(shp, propagation_kernel=k)
+        assert ff.shape == shp and np.iscomplexobj(ff)
+        err = rel_l2(ff, expected(shp, k))
+        report(f"get_farfield {shp} kernel={'array' if not np.isscalar(k) else k}", rel_l2=err)
+        assert err < 2e-6
+    # the default shape refreshes amp_ff / phase_ff like the reference does
+    ff = h.get_farfield()
+    assert rel_l2(h.amp_ff, np.abs(ff)) < 1e-6
+    aff = dict(M=np.array([[1.02, 0.01], [-0.02, 0.97]]), b=np.array([3.5, -2.25]))
+    out = h.get_farfield((256, 256), propagation_kernel=0, affine=aff)
+    ref = affine_transform(input=expected((256, 256), 0).astype(np.complex64), matrix=aff["M"], offset=aff["b"],
+                           output_shape=(256, 256), order=3, mode="constant", cval=0)
+    assert rel_l2(out, ref) < 1e-5
+    with pytest.raises(ValueError):
+        h.get_farfield((256, 256), propagation_kernel=np.zeros((3, 3)))

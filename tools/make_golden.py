@@ -231,6 +231,35 @@ def gen_spot_cases(alg):
             save(f"spot_{method.replace('-', '')}_{fb}", meta, rec)
 
 
+def gen_multiplane_cases(alg):
+    """MultiplaneHologram (_multiplane.py): three children of different pad shapes on one 48x80 SLM."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_cases as gc
+    for method, maxiter, kw in (("GS", 4, {}), ("WGS-Leonardo", 5, {}), ("WGS-Kim", 6, {"fix_phase_iteration": 3})):
+        children = gc.multiplane_children(alg.Hologram, alg.SpotHologram)
+        mp = alg.MultiplaneHologram(children, weights=list(gc.MULTIPLANE_WEIGHTS))
+        rec = {}
+
+        def snap(h):
+            rec[f"phase_{h.iter}"] = np.array(h.phase, copy=True)
+            return False
+
+        mp.optimize(method, maxiter=maxiter, verbose=False, callback=snap, stat_groups=["computational"], **kw)
+        rec["final_phase"] = np.array(mp.phase, copy=True)
+        rec["weights"] = np.array(mp.weights, copy=True)
+        for i, h in enumerate(children):
+            rec[f"child{i}_final_ampff"] = np.array(h.amp_ff, copy=True)
+            rec[f"child{i}_final_weights"] = np.array(h.weights, copy=True)
+            rec[f"child{i}_fixed_history"] = np.array([bool(x) for x in h.stats["flags"]["fixed_phase"]])
+            rec[f"child{i}_iter"] = np.array(h.iter)
+            for n, lst in h.stats["stats"]["computational"].items():
+                rec[f"child{i}_stats_{n}"] = np.array(lst, dtype=float)
+        rec["spot_knm_rounded"] = np.array(children[1].spot_knm_rounded)
+        meta = dict(kind="multiplane", method=method, maxiter=maxiter, kwargs=kw, dtype="float32",
+                    slm_shape=gc.MULTIPLANE_SLM, weights=list(gc.MULTIPLANE_WEIGHTS))
+        save(f"multiplane_{method.replace('-', '')}", meta, rec)
+
+
 def gen_helper_cases(alg, toolbox, analysis):
     """F7: unpad/pad index tuples, get_padded_shape table, take windows, integration width."""
     out = {}
@@ -373,6 +402,7 @@ def main():
         "helpers": lambda: gen_helper_cases(alg, toolbox, analysis),
         "cfg1": lambda: gen_cfg1(alg),
         "compressed": lambda: gen_compressed_cases(alg),
+        "multiplane": lambda: gen_multiplane_cases(alg),
     }
     if args.cfg2:
         steps["cfg2"] = lambda: gen_cfg2(alg)
