@@ -746,6 +746,11 @@ class OracleCompressedSpotHologram(OracleHologram):
         if self.propagation_kernel is not None:
             self.phase -= self.propagation_kernel
 
+    def inverse_nearfield(self):                  # _farfield2nearfield_cupy(extract=False) :887-914
+        K = self.kernel()
+        self.nearfield = (self.farfield[np.newaxis, :] @ K).reshape(self.slm_shape).astype(self.ctype)
+        return self.nearfield
+
     def update_weights(self):                     # _update_weights :950-989
         fb = self.flags["feedback"]
         if fb == "computational":
