@@ -31,13 +31,96 @@ class SimpleSLM:
     def get_source_radius(self):
         return self.source["amplitude_radius"]
 
+    def get_spot_radius_kxy(self):
+        """Approximate farfield spot radius in "kxy" (slm.py:1355-1390)."""
+        from ..holography import toolbox
+        rad_pix = self.source["amplitude_radius"] / np.mean(self.pitch)
+        rad_freq = np.reciprocal(rad_pix)
+        return float(np.mean(toolbox.convert_vector([rad_freq, rad_freq], from_units="freq", to_units="kxy",
+                                                    hardware=self, shape=self.shape)))
+
     def get_source_zernike_scaling(self):
         return np.reciprocal(2 * self.source["amplitude_radius"])       # slm.py:1205-1213
 
 
-class SimpleFourierSLM:
-    """An SLM without camera calibration, enough for the computational feedback modes."""
+class SimpleCamera:
+    """Geometry of a camera: ``shape`` (h, w) and pixel ``pitch_um``; no acquisition."""
 
-    def __init__(self, slm):
+    def __init__(self, shape, pitch_um=(4.0, 4.0)):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.pitch_um = np.array([pitch_um, pitch_um] if np.isscalar(pitch_um) else pitch_um, dtype=float)
+
+
+class SimpleFourierSLM:
+    """
+    An SLM, optionally with a camera geometry and an *analytic* Fourier calibration -- enough for every
+    computational feedback mode, the ``"ij"`` spot basis and the hologram-side work of
+    ``FourierSLM.fourier_grid_project`` (cameraslms.py:1088-1155).  No image acquisition.
+    """
+
+    def __init__(self, slm, cam=None, mag=1.0):
         self.slm = slm
+        self.cam = cam
+        self.mag = mag
         self.calibrations = {}
+
+    def fourier_calibrate_analytic(self, M, b):
+        """cameraslms.py:1157-1194: ij = M (kxy - a) + b with a = 0."""
+        M = np.squeeze(np.asarray(M, dtype=float))
+        if M.shape != (2, 2):
+            raise ValueError("Expected a 2x2 matrix for M.")
+        self.calibrations["fourier"] = {"M": M, "b": np.asarray(b, dtype=float).reshape(2, 1),
+                                        "a": np.zeros((2, 1))}
+        return self.calibrations["fourier"]
+
+    def _fourier(self):
+        if "fourier" not in self.calibrations:
+            raise RuntimeError("Fourier calibration must exist to be used.")
+        return self.calibrations["fourier"]
+
+    @staticmethod
+    def _vectors2(v):
+        v = np.asarray(v, dtype=float)
+        if v.ndim == 1:
+            v = v.reshape(-1, 1)
+        if v.shape[0] != 2:
+            raise NotImplementedError("depth (3-vector) conversion needs the full FourierSLM of the reference")
+        return v
+
+    def kxyslm_to_ijcam(self, kxy):
+        """cameraslms.py:1240-1294 (lateral part)."""
+        c = self._fourier()
+        return np.matmul(c["M"], self._vectors2(kxy) - c["a"]) + c["b"]
+
+    def ijcam_to_kxyslm(self, ij):
+        """cameraslms.py:1296-1354 (lateral part)."""
+        c = self._fourier()
+        return np.matmul(np.linalg.inv(c["M"]), self._vectors2(ij) - c["b"]) + c["a"]
+
+    def fourier_grid_project(self, array_shape=10, array_pitch=10, array_center=None, **kwargs):
+        """
+        cameraslms.py:1088-1155: a ``"knm"`` grid of spots on the smallest square power-of-two pad,
+        with the orientation check, optimised (default 10 iterations); the phase is written to the
+        SLM when the SLM object can take one.  Returns the optimised hologram.
+        """
+        import warnings
+        from ..holography.algorithms import SpotHologram
+        from ..holography.toolbox import format_2vectors
+        if not np.all(np.isclose(array_pitch, np.rint(array_pitch))):
+            warnings.warn("array_pitch is non-integer")
+        shape = SpotHologram.get_padded_shape(self, padding_order=1, square_padding=True)
+        hologram = SpotHologram.make_rectangular_array(
+            shape, array_shape=array_shape, array_pitch=array_pitch,
+            array_center=None if array_center is None else (
+                format_2vectors(array_center) + format_2vectors((shape[1] / 2.0, shape[0] / 2.0))),
+            basis="knm", orientation_check=True, cameraslm=self)
+        if "maxiter" not in kwargs:
+            kwargs["maxiter"] = 10
+        for key in kwargs:
+            if key not in ("method", "maxiter", "verbose", "callback", "feedback", "stat_groups", "name",
+                           "fixed_phase", "raw_stats", "blur_ij"):
+                warnings.warn(f"Unexpected argument '{key}' passed to fourier_grid_project(). This may be ignored.")
+        hologram.optimize(**kwargs)
+        if hasattr(self.slm, "set_phase"):
+            self.slm.set_phase(hologram.get_phase(), settle=True)
+        return hologram

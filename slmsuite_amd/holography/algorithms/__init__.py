@@ -710,23 +710,39 @@ class SpotHologram(FeedbackHologram):
             self.null_region_knm = null_region
 
         # integration width (_spots.py:1270-1306)
-        psf_knm = 0
+        psf_knm, psf_ij = 0, 0
         if cameraslm is not None and hasattr(getattr(cameraslm, "slm", cameraslm), "get_spot_radius_kxy"):
             slm = getattr(cameraslm, "slm", cameraslm)
             psf_kxy = np.mean(slm.get_spot_radius_kxy())
             psf_knm = toolbox.convert_radius(psf_kxy, "kxy", "knm", slm, shape)
             if np.isnan(psf_knm):
                 psf_knm = 0
+            if self.spot_ij is not None:
+                psf_ij = toolbox.convert_radius(psf_kxy, "kxy", "ij", cameraslm, shape)
+                if np.isnan(psf_ij):
+                    psf_ij = 0
         min_psf = 3
         dist_knm = np.max([toolbox.smallest_distance(self.spot_knm) / 1.5, min_psf])
         width = np.clip(10 * psf_knm, min_psf, dist_knm)
         self.spot_integration_width_knm = int(2 * np.floor(width / 2) + 1)
-        self.spot_integration_width_ij = None
+        if self.spot_ij is not None:
+            dist_ij = np.max([toolbox.smallest_distance(self.spot_ij) / 1.5, min_psf])
+            width_ij = np.clip(10 * psf_ij, min_psf, dist_ij)
+            self.spot_integration_width_ij = int(2 * np.floor(width_ij / 2) + 1)
+        else:
+            self.spot_integration_width_ij = None
 
         if (np.any(self.spot_knm[0] < 0) or np.any(self.spot_knm[1] < 0)
                 or np.any(self.spot_knm[0] >= shape[1]) or np.any(self.spot_knm[1] >= shape[0])):
             raise ValueError("Spots outside SLM computational space bounds!\nSpots:\n{}\nBounds: {}".format(
                 self.spot_knm, shape))
+
+        if self.spot_ij is not None and getattr(cameraslm, "cam", None) is not None:      # _spots.py:1326-1339
+            cam_shape, wij = cameraslm.cam.shape, self.spot_integration_width_ij
+            if (np.any(self.spot_ij[0] < wij / 2) or np.any(self.spot_ij[1] < wij / 2)
+                    or np.any(self.spot_ij[0] >= cam_shape[1] - wij / 2)
+                    or np.any(self.spot_ij[1] >= cam_shape[0] - wij / 2)):
+                raise ValueError("Spots outside camera bounds!\nSpots:\n{}\nBounds: {}".format(self.spot_ij, cam_shape))
 
         if self.null_knm is not None:
             if self.null_radius_knm is None:

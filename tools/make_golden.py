@@ -260,6 +260,36 @@ def gen_multiplane_cases(alg):
         save(f"multiplane_{method.replace('-', '')}", meta, rec)
 
 
+def gen_fourier_cases(alg):
+    """Callers in FourierSLM: ij-basis SpotHologram and the set-up of fourier_grid_project."""
+    fs = make_fourier_slm()
+    ij = np.array([[100., 150, 128, 171.5], [90, 128, 170, 66.25]])
+    phase0 = synth.seed_phase(800, (48, 64))
+    h = alg.SpotHologram((128, 128), ij, basis="ij", cameraslm=fs, phase=phase0.copy())
+    rec = dict(spot_ij=ij, spot_knm=np.array(h.spot_knm), spot_kxy=np.array(h.spot_kxy),
+               spot_knm_rounded=np.array(h.spot_knm_rounded), width=np.array(h.spot_integration_width_knm),
+               amp=np.array(h.amp))
+    h.optimize("WGS-Kim", maxiter=6, verbose=False, feedback="computational_spot", fix_phase_iteration=3,
+               stat_groups=["computational_spot"])
+    rec["final_phase"] = np.array(h.phase)
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    rec["final_ampff_spots"] = np.array(h.amp_ff[ky, kx])
+    rec["final_weights_spots"] = np.array(h.weights[ky, kx])
+    for n, lst in h.stats["stats"]["computational_spot"].items():
+        rec[f"stats_{n}"] = np.array(lst, dtype=float)
+    g = fs.fourier_grid_project(array_shape=(4, 3), array_pitch=(3, 4), array_center=(2, -1), maxiter=2, verbose=False)
+    rec["grid_width"] = np.array([g.spot_integration_width_knm, g.spot_integration_width_ij])
+    rec["width_ij"] = np.array(h.spot_integration_width_ij)
+    rec["psf_kxy"] = np.array(fs.slm.get_spot_radius_kxy())
+    rec["grid_shape"] = np.array(g.shape)
+    rec["grid_spot_knm"] = np.array(g.spot_knm)
+    rec["grid_spot_ij"] = np.array(g.spot_ij)
+    rec["grid_target_nonzero"] = np.array(np.nonzero(g.target))
+    rec["grid_target_values"] = np.array(g.target[np.nonzero(g.target)])
+    save("fourier_callers", dict(kind="fourier", slm_shape=(48, 64), seed=800, M=[[6000., 0], [0, 6000.]],
+                                 b=[128., 128.]), rec)
+
+
 def gen_helper_cases(alg, toolbox, analysis):
     """F7: unpad/pad index tuples, get_padded_shape table, take windows, integration width."""
     out = {}
@@ -403,6 +433,7 @@ def main():
         "cfg1": lambda: gen_cfg1(alg),
         "compressed": lambda: gen_compressed_cases(alg),
         "multiplane": lambda: gen_multiplane_cases(alg),
+        "fourier": lambda: gen_fourier_cases(alg),
     }
     if args.cfg2:
         steps["cfg2"] = lambda: gen_cfg2(alg)
