@@ -30,6 +30,9 @@
 #ifndef HGS_TILE_DB
 #define HGS_TILE_DB false
 #endif
+#ifndef HGS_SPARSE_SKIP
+#define HGS_SPARSE_SKIP 1
+#endif
 #ifndef HGS_FUSED_OCC
 #define HGS_FUSED_OCC 2
 #endif
@@ -647,6 +650,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
             const unsigned idx = lane_pos<T>(j, m);
+            // wave-uniform skip of pixels with zero weight and zero target (see col_tile_kernel)
+            if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
+                __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS) && tr[m] != (R)0)) == 0) {
+                v[m] = mk<R>(0, 0);
+                return;
+            }
             const Cx<R> F = v[m] * sc;
             const R p2 = F.x * F.x + F.y * F.y;
             const R wraw = wr[m];
@@ -830,6 +839,15 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 const unsigned idx = lane_pos<T>(j, m);
+                // Sparse targets (spot arrays): where weight and target are both zero the rule leaves the
+                // weight at zero (T == 0 -> factor 1, :1841) and the constrained field is w * e^{i phi} = 0.
+                // Skip the arithmetic when that holds for the whole wave (not when phase_ff or amp_ff of
+                // every pixel must be produced).
+                if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
+                    __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
+                    v[m] = mk<R>(0, 0);
+                    return;
+                }
                 const Cx<R> F = cmul(v[m], om);
                 const R p2 = F.x * F.x + F.y * F.y;
                 const R wraw = wr[m];
