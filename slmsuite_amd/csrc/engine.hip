@@ -102,11 +102,18 @@ template <typename R> struct Engine : EngineBase {
     double* ext_amp = nullptr;
     R* spot_fb = nullptr;
     C* nfbuf = nullptr;               // [B][Sh][Sw] complex nearfield of f2n_complex (MultiplaneHologram)
+    // sparse targets (spot arrays): columns that hold a non-zero weight or target
+    unsigned char* col_active = nullptr;   // [B][Pw]
+    int* col_list = nullptr;               // [B][Pw] compacted
+    int* n_active_dev = nullptr;           // [B]
+    int n_active_max = 0, n_active_min = 0;
+    bool sparse_dirty = true;
     // statistics of the fused path (hgs_iterate_stats)
     double* stat_partial = nullptr;   // [B][blocks][STAT_WAVES][STAT_N]
     double* stat_tsum = nullptr;      // [B] sum T^2
     struct StatCtx { int groups = 0, width = 1; double* dev_out = nullptr; int* dxy = nullptr; };
     StatCtx* stat_ctx = nullptr;      // non-null while hgs_iterate_stats drives the fused loop
+    size_t stat_nslots = 0;
     // kind 1 (compressed)
     R* xg = nullptr;
     R* yg = nullptr;
@@ -135,7 +142,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -214,7 +221,7 @@ template <typename R> struct Engine : EngineBase {
         if (dalloc(&gh, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE;
         if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
         if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
-        if (dalloc(&wpartial, (size_t)B * std::max(col_blocks, tile_blocks))) return HGS_ERR_DEVICE;
+        if (dalloc(&wpartial, (size_t)B * std::max(std::max(col_blocks, tile_blocks), n_cu * 3))) return HGS_ERR_DEVICE;
         if (dalloc(&fpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&sums, (size_t)4 * B)) return HGS_ERR_DEVICE;
@@ -489,8 +496,10 @@ template <typename R> struct Engine : EngineBase {
             }
             case HGS_TARGET:
                 has_target = true;
+                sparse_dirty = true;
                 return upload_T<R>(t, host, nbytes);
             case HGS_WEIGHTS: {
+                sparse_dirty = true;
                 int e = upload_T<R>(w, host, nbytes);
                 if (e) return e;
                 return fill_wscale_one();
@@ -593,6 +602,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int reset_weights() override {
+        sparse_dirty = true;
         hipLaunchKernelGGL(reset_weights_kernel<R>, dim3(ew_blocks * B), dim3(256), 0, stream, w, (const R*)t, zw, B * P);
         HIPCHK(hipGetLastError());
         return fill_wscale_one();
@@ -607,11 +617,36 @@ template <typename R> struct Engine : EngineBase {
         a.xcd_map = row_xcd;
         return a;
     }
-    int run_row(int mode, bool finalize) {
+    int run_row(int mode, bool finalize, bool load_sparse = false, bool store_sparse = false) {
         return timed(HGS_K_ROW, [&]() -> int {
-            LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks, B), stream, row_args(finalize)));
+            RowArgs<R> a = row_args(finalize);
+            a.load_active = load_sparse ? col_active : nullptr;
+            a.store_active = store_sparse ? col_active : nullptr;
+            LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks, B), stream, a));
             return 0;
         });
+    }
+    // (re)build the active-column list when weights or target changed since the last scan
+    int refresh_sparse() {
+        if (!sparse_dirty) return 0;
+        if (!col_active) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_active), (size_t)B * g.Pw));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list), (size_t)B * g.Pw * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_active_dev), (size_t)B * sizeof(int)));
+        }
+        hipLaunchKernelGGL(scan_active_cols<R>, dim3(g.Pw, B), dim3(256), 0, stream, (const R*)w, (const R*)t, g.Ph, g.Pw,
+                           col_active);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
+                           col_list, n_active_dev);
+        HIPCHK(hipGetLastError());
+        std::vector<int> h(B);
+        HIPCHK(hipMemcpyAsync(h.data(), n_active_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        n_active_max = *std::max_element(h.begin(), h.end());
+        n_active_min = *std::min_element(h.begin(), h.end());
+        sparse_dirty = false;
+        return 0;
     }
     ColArgs<R> col_args() {
         ColArgs<R> a{};
@@ -770,6 +805,7 @@ template <typename R> struct Engine : EngineBase {
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "farfield is not materialised");
         if (int e = need_pff()) return e;
         if (int e = normalize_weights_now()) return e;
+        if (p.do_update) sparse_dirty = true;     // the general rules rewrite the weight array
         if (st->mraf_enabled && st->zero_mode) { if (int e = need_zw()) return e; }
         if (st->mraf_enabled && st->fixed_phase && !have_pff && !p.store_phase)
             return fail(HGS_ERR_STATE, "fixed_phase with MRAF needs a stored phase_ff (reference quirk A12)");
@@ -852,9 +888,21 @@ template <typename R> struct Engine : EngineBase {
             return 0;
         }
         farfield_valid = false;
-        if (int e = run_row(0, false)) return e;
+        // Sparse targets: when few columns hold a non-zero weight/target, only those columns are
+        // transformed (col_fused_kernel with a column list) and only they cross HBM between the two
+        // kernels.  Iterations that must produce phase_ff or amp_ff of every pixel run dense.
+        bool sparse_enabled = false;
+        if (env_int("HGS_SPARSE", 1) && g.Ph >= 4096 && !env_int("HGS_OLD_FUSED", 0)) {
+            if (int e = refresh_sparse()) return e;
+            sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
+        }
+        auto col_sparse = [&](const Plan& p) {
+            return sparse_enabled && !p.store_phase && !(stat_ctx && (stat_ctx->groups & 2));
+        };
+        Plan p = plan_iteration(st, hist ? hist : nullptr);
+        bool sp = col_sparse(p);
+        if (int e = run_row(0, false, false, sp)) return e;
         for (int i = 0; i < n; ++i) {
-            Plan p = plan_iteration(st, hist ? hist + i : nullptr);
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
             int r = timed(HGS_K_COL_FUSED, [&]() -> int {
                 ColArgs<R> a = col_args();
@@ -864,13 +912,23 @@ template <typename R> struct Engine : EngineBase {
                     a.spartial = stat_partial;
                     a.tsum = stat_tsum;
                     a.inv_fsum = 1.0 / amp_norm2;
+                    // launches of different geometry share the partial buffer: reset the slots
+                    hipLaunchKernelGGL(stat_fill_neutral, dim3((unsigned)((stat_nslots + 255) / 256)), dim3(256), 0, stream,
+                                       stat_partial, stat_nslots);
                 }
                 const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
                 // slots of the load layout the SLM rows occupy (tile-resident kernel needs <= 6)
                 const int Tc = g.Ph / 16;
                 const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;
                 wpartial_n = col_blocks;
-                if (env_int("HGS_OLD_FUSED", 0)) {
+                if (sp) {
+                    a.col_list = col_list;
+                    a.n_active = n_active_dev;
+                    const int blocks = std::min(n_active_max, n_cu * 3);
+                    wpartial_n = blocks;
+                    if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                    else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                } else if (env_int("HGS_OLD_FUSED", 0)) {
                     LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
                 } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
                     wpartial_n = tile_blocks;
@@ -886,9 +944,18 @@ template <typename R> struct Engine : EngineBase {
             if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
             if (p.do_update) w_pending = true;
-            // the row kernel that follows folds the weight-norm partials into wscale
-            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0)) return e;
             st->iter++;
+            // the next iteration's plan decides which columns this row kernel must produce
+            Plan pn{0, 0, 0};
+            bool sp_next = false;
+            if (i + 1 < n) {
+                pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
+                sp_next = col_sparse(pn);
+            }
+            // the row kernel that follows folds the weight-norm partials into wscale
+            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0, sp, sp_next)) return e;
+            p = pn;
+            sp = sp_next;
         }
         return 0;
     }
@@ -958,8 +1025,9 @@ template <typename R> struct Engine : EngineBase {
         StatCtx c;
         c.groups = groups;
         c.width = width;
-        const int max_blocks = std::max(tile_blocks, col_blocks);
+        const int max_blocks = std::max(std::max(tile_blocks, col_blocks), n_cu * 3);
         const size_t nslots = (size_t)B * max_blocks * STAT_WAVES;
+        stat_nslots = nslots;
         if (!stat_partial) { if (dalloc(&stat_partial, nslots * STAT_N)) return HGS_ERR_DEVICE; }
         if (!stat_tsum) { if (dalloc(&stat_tsum, (size_t)B)) return HGS_ERR_DEVICE; }
         if (groups & 2) { if (int e = need_aff()) return e; }

@@ -277,6 +277,10 @@ template <typename R> struct RowArgs {
     int n_wpartial;
     R* wscale;
     int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
+    // sparse targets: per-column activity [b][Pw] (1 = the column kernel of this iteration wrote /
+    // the next one will read that column); nullptr = all columns
+    const unsigned char* load_active;
+    const unsigned char* store_active;
     Cx<R>* nf_out;       // MODE 1 only: store the complex nearfield rows [b][Sh][Sw] instead of extracting
                          // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
 };
@@ -312,6 +316,16 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
     const unsigned gh_lane = (unsigned)(j >> 2) * g.Sh * 4u + (unsigned)(j & 3);
     const unsigned gh_step = (unsigned)T * g.Sh;
     const int c_lane = j - g.c0;   // SLM column of element m is c_lane + m*T
+    // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list)
+    unsigned lmask = 0xffffu, smask = 0xffffu;
+    if (a.load_active != nullptr) {
+        lmask = 0;
+        static_for<0, 16>([&](auto m_) { constexpr int m = m_; lmask |= (unsigned)(a.load_active[(size_t)b * g.Pw + j + m * T] != 0) << m; });
+    }
+    if (a.store_active != nullptr) {
+        smask = 0;
+        static_for<0, 16>([&](auto m_) { constexpr int m = m_; smask |= (unsigned)(a.store_active[(size_t)b * g.Pw + j + m * T] != 0) << m; });
+    }
 
     // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
     // assumption): give the four rows that share each 128-byte GH line to four blocks of the same
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 Cx<R> h = mk<R>(0, 0);
-                if (valid) h = (ghr + (size_t)m * gh_step)[gh_lane];
+                if (valid && ((lmask >> m) & 1u)) h = (ghr + (size_t)m * gh_step)[gh_lane];
                 v[m] = h * sgn;
             });
             fft.template run<+1>(v, lds, j);
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                 const R sc = sgn * a.scale;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
+                    if ((smask >> m) & 1u) (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
                 });
             }
         }
@@ -425,6 +439,11 @@ template <typename R> struct ColArgs {
     R scale;          // 1/sqrt(Ph)
     int store_pff;    // STORE: also write phase_ff
     CParams<R> cp;
+    // col_fused_kernel only: sparse targets.  When col_list != nullptr the kernel transforms just the
+    // listed columns (those holding a non-zero weight or target): every other column of the constrained
+    // farfield is exactly zero, so its inverse transform is zero and the row kernel does not read it.
+    const int* col_list;   // [batch][Pw] compacted active columns
+    const int* n_active;   // [batch]
     // fused kernels only: statistics of this iteration (hgs_iterate_stats)
     int do_stats;          // bit 0: accumulate the "computational" statistics; bit 1: store amp_ff
     double* spartial;      // [batch][gridDim.x][STAT_WAVES][STAT_N]
@@ -590,7 +609,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
     const int ntiles = g.Pw / 4;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int ncols = my_tiles * PASSES;
+    const bool listed = a.col_list != nullptr;     // CPAR == 1 (host checks)
+    const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
+    const int n_act = listed ? a.n_active[b] : 0;
+    const int ncols = listed ? ((int)blockIdx.x < n_act ? (n_act - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
+                             : my_tiles * PASSES;
     R acc_w = 0;
     double* stat_slot = scratch + 16 + (tid >> 6) * STAT_N;
     StatAcc<R> sacc;
@@ -605,6 +628,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     R wr[16], tr[16];
 
     auto col_of = [&](int q, int& ct, int& c4) {
+        if (listed) {
+            const int col = clist[blockIdx.x + q * gridDim.x];
+            ct = col >> 2;
+            c4 = col & 3;
+            return;
+        }
         ct = blockIdx.x + (q / PASSES) * gridDim.x;
         c4 = (q % PASSES) * CPAR + cpar;
     };
@@ -1412,6 +1441,50 @@ template <typename R> __global__ void multiplane_combine(MpArgs<R> a) {
     }
     const R ph = M::atan2(acc.y, acc.x);
     for (int k = 0; k < a.n; ++k) a.phase[k][i] = ph;
+}
+
+// ---- sparse targets: which columns hold a non-zero (or NaN) weight or target --------------------------
+// grid = (Pw, batch), one workgroup per column (contiguous Ph values of each array)
+template <typename R> __global__ void scan_active_cols(const R* w, const R* t, int Ph, int Pw, unsigned char* active) {
+    __shared__ int any;
+    const int col = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const size_t base = ((size_t)b * Pw + col) * Ph;
+    bool nz = false;
+    for (int i = threadIdx.x; i < Ph; i += blockDim.x) {
+        const R wv = w[base + i], tv = t[base + i];
+        nz = nz || !(wv == (R)0) || !(tv == (R)0);      // NaN counts as active
+    }
+    if (__builtin_amdgcn_ballot_w64(nz) != 0 && (threadIdx.x & 63) == 0) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) active[(size_t)b * Pw + col] = (unsigned char)any;
+}
+// one workgroup per hologram: ordered compaction of the active columns
+static __global__ void compact_active_cols(const unsigned char* active, int Pw, int* list, int* n_active) {
+    __shared__ int base;
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < Pw; c0 += blockDim.x) {
+        const int c = c0 + threadIdx.x;
+        const bool on = c < Pw && active[(size_t)b * Pw + c] != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+        if (lane == 0) wsum[wid] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wid; ++k) off += wsum[k];
+        if (on) list[(size_t)b * Pw + off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < nw; ++k) tot += wsum[k];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_active[b] = base;
 }
 
 }  // namespace hgs

@@ -572,3 +572,37 @@ def test_get_farfield_shape_kernel_affine():
     assert rel_l2(out, ref) < 1e-5
     with pytest.raises(ValueError):
         h.get_farfield((256, 256), propagation_kernel=np.zeros((3, 3)))
+
+
+# ---- sparse targets: only the columns that hold a weight / target are transformed -------------------------
+@pytest.mark.parametrize("method,kw", [("WGS-Leonardo", {}), ("WGS-Kim", {"fix_phase_iteration": 3}), ("GS", {})])
+def test_sparse_column_path_matches_dense_path(method, kw, monkeypatch):
+    """
+    4096^2 pad, 300 spots at scattered positions (not a grid): the active-column path (default) against
+    the same engine with HGS_SPARSE=0.  Kim walks dense (phase_ff stored) -> sparse (fixed phase);
+    statistics ride along in both.
+    """
+    shape, slm = (4096, 4096), (1152, 1920)
+    n = 300
+    xy = np.vstack((1024 + np.floor(2048 * synth.uniform01(77, (n,), 0)), 1024 + np.floor(2048 * synth.uniform01(77, (n,), 1))))
+    xy = np.unique(xy.astype(int), axis=1).astype(float)
+    amp = 0.5 + synth.uniform01(78, (xy.shape[1],), 0)
+
+    def run(sparse):
+        monkeypatch.setenv("HGS_SPARSE", "1" if sparse else "0")
+        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(79, slm))
+        h.optimize(method, maxiter=7, verbose=False, stat_groups=["computational"], **kw)
+        h.optimize(method, maxiter=2, verbose=False, **kw)          # state persists; plain fused call
+        return h
+
+    a, b = run(True), run(False)
+    ky, kx = a.spot_knm_rounded[1], a.spot_knm_rounded[0]
+    errs = dict(phase=phase_rel_l2(a.phase, b.phase), spot_amp=rel_l2(a.amp_ff[ky, kx], b.amp_ff[ky, kx]),
+                weights=rel_l2(a.weights, b.weights), amp_ff=rel_l2(a.amp_ff[::8, ::8], b.amp_ff[::8, ::8]))
+    report(f"sparse vs dense column path {method}", **errs)
+    assert errs["phase"] < 3e-5 and errs["spot_amp"] < 1e-5 and errs["weights"] < 2e-5 and errs["amp_ff"] < 3e-5
+    assert a.stats["flags"]["fixed_phase"] == b.stats["flags"]["fixed_phase"]
+    for nme in STAT_NAMES:
+        np.testing.assert_allclose(a.stats["stats"]["computational"][nme][:7], b.stats["stats"]["computational"][nme][:7],
+                                   rtol=2e-4, atol=1e-7)
+    assert np.count_nonzero(a.weights) == xy.shape[1]
