@@ -357,36 +357,48 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
             });
             fft.template run<+1>(v, lds, j);
             const R sc = sgn * a.scale;
-            static_for<0, 16>([&](auto m_) {
-                constexpr int m = m_;
-                const int c = c_lane + m * T;
-                if (valid && c >= 0 && c < g.Sw) {
-                    // nf = sgn * scale * v;  _nearfield_extract :1030, :1036
-                    if (MODE == 1 && a.nf_out != nullptr) {
-                        (a.nf_out + (size_t)b * g.Sh * g.Sw + srow)[c] = v[m] * sc;
-                    } else {
-                        R p = HGS_ABL_TRANS ? (v[m].y * sc + v[m].x) : M::atan2(v[m].y * sc, v[m].x * sc);
-                        if (kn != nullptr) p -= kn[c];
-                        ph[c] = p;
-                        v[m].x = p;  // keep for the fused rebuild
+            if constexpr (MODE == 1) {
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const int c = c_lane + m * T;
+                    if (valid && c >= 0 && c < g.Sw) {
+                        // nf = sgn * scale * v;  _nearfield_extract :1030, :1036
+                        if (a.nf_out != nullptr) {
+                            (a.nf_out + (size_t)b * g.Sh * g.Sw + srow)[c] = v[m] * sc;
+                        } else {
+                            R p = M::atan2(v[m].y * sc, v[m].x * sc);
+                            if (kn != nullptr) p -= kn[c];
+                            ph[c] = p;
+                        }
                     }
-                }
-                if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
-            });
+                    if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                });
+            }
         }
         if constexpr (MODE != 1) {
             // ---- build the nearfield row (amp * exp(i(phase+kernel)), zero padded), transform ----
+            // MODE 2 (inverse of iteration i fused with the forward of i+1): the phase is never
+            // materialised -- phase = atan2(nf) - kernel (:1030-1036) and the rebuild uses
+            // exp(i(phase + kernel)) = nf/|nf| (:1004-1008), so the kernel cancels and one rsqrt replaces
+            // atan2 + sincos; atan2(0,0) = 0 gives the phasor 1.  The last row kernel of an
+            // hgs_iterate call runs MODE 1 and writes the phase.
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 const int c = c_lane + m * T;
                 Cx<R> nf = mk<R>(0, 0);
                 if (valid && c >= 0 && c < g.Sw) {
-                    R p = (MODE == 2) ? v[m].x : ph[c];
-                    if (kn != nullptr) p += kn[c];
-                    R s, co;
-                    if (HGS_ABL_TRANS) { s = p; co = p + (R)1; } else M::sincos(p, &s, &co);
-                    const R amv = ((am != nullptr) ? am[c] : a.amp_scalar) * sgn;
-                    nf = mk<R>(amv * co, amv * s);
+                    const R amv = (am != nullptr) ? am[c] : a.amp_scalar;
+                    if constexpr (MODE == 2) {
+                        // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
+                        const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
+                        nf = (p2 > (R)0) ? v[m] * (amv * M::rsqrt(p2)) : mk<R>(amv * sgn, 0);
+                    } else {
+                        R p = ph[c];
+                        if (kn != nullptr) p += kn[c];
+                        R s, co;
+                        M::sincos(p, &s, &co);
+                        nf = mk<R>(amv * sgn * co, amv * sgn * s);
+                    }
                 }
                 v[m] = nf;
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
