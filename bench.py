@@ -10,6 +10,11 @@ SLM 1152 x 1920, WGS-Leonardo, fp32, synthetic seed phase, state resident in HBM
 ``--batch`` independent holograms (weak scaling); the only collective is the final
 all-gather of the phase masks (reported as gather_ms, outside the timed region).
 
+The headline is timed with the dense kernels forced (every farfield column transformed, as the
+canonical byte count assumes); the engine's default for spot targets -- transform only the columns
+that hold a spot, identical results -- is timed in an extra pass and reported as
+``engine_default_path``.
+
 Rank 0 prints one JSON line: metric/value (whole-job iterations/s), plus
   roofline      the dominant kernel (fused column kernel) against the 8 TB/s HBM peak:
                 ALGORITHMIC bytes per launch (44 * P * r * batch) / its mean duration,
@@ -49,6 +54,11 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=16, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (self-test)")
+    ap.add_argument("--sparse-columns", type=int, default=0,
+                    help="1: time the engine's default (sparse-target aware) path as the headline; 0 (default): "
+                         "force the dense kernels (every farfield column transformed) for the headline and "
+                         "report the default path separately")
+    ap.add_argument("--no-extra-pass", action="store_true")
     return ap.parse_args()
 
 
@@ -105,6 +115,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    hb.engine.set_option(L.OPT_SPARSE_COLUMNS, args.sparse_columns)
     # warmup (also takes the hologram past iteration 0 so every timed step updates weights)
     hb.time_iterations(args.method, max(1, args.warmup))
     barrier()
@@ -124,6 +135,20 @@ def main():
         hb.time_iterations(args.method, args.steps)
         prof = hb.engine.profile_read()
         hb.engine.profile_enable(False)
+
+    # the engine's default for this workload: only the columns that hold a spot are transformed
+    sparse_ms = None
+    if not args.no_extra_pass and not args.sparse_columns:
+        hb.engine.set_option(L.OPT_SPARSE_COLUMNS, 1)
+        hb.time_iterations(args.method, max(1, args.warmup))
+        sparse_ms = hb.time_iterations(args.method, args.steps)
+        sprof = None
+        if not args.no_roofline_pass:
+            hb.engine.profile_enable(True)
+            hb.time_iterations(args.method, args.steps)
+            sprof = hb.engine.profile_read()
+            hb.engine.profile_enable(False)
+        hb.engine.set_option(L.OPT_SPARSE_COLUMNS, 0)
 
     # final gather of the phase masks over RCCL, timed separately
     gather_ms = None
@@ -184,7 +209,18 @@ def main():
             "event_ms_per_step": ms_events / args.steps, "gather_ms": gather_ms,
             "engine": hb.engine.version(),
             "roofline": roof, "cpu_baseline": cpu,
+            "column_mode": "sparse-aware (engine default)" if args.sparse_columns else
+                           "dense kernels forced (HGS_OPT_SPARSE_COLUMNS=0): all 4096 columns transformed",
         }
+        if sparse_ms is not None:
+            line["engine_default_path"] = {
+                "what": "same workload with the engine default HGS_OPT_SPARSE_COLUMNS=1: only the farfield columns "
+                        "holding a non-zero weight/target are transformed and moved (identical results)",
+                "value": world * args.batch * args.steps / (sparse_ms * 1e-3), "unit": "iterations/s (rank-0 HIP events)",
+                "ms_per_step": sparse_ms / args.steps,
+                "col_kernel_us": None if sprof is None else sprof["col_fused"]["ms"] * 1e3 / max(1, sprof["col_fused"]["launches"]),
+                "row_kernel_us": None if sprof is None else sprof["row"]["ms"] * 1e3 / max(1, sprof["row"]["launches"]),
+            }
         print(json.dumps(line))
     hb.close()
     if dist is not None:

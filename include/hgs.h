@@ -154,6 +154,13 @@ int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double*
 
 int hgs_sync(hgs_engine* e);
 
+/* Engine options.  HGS_OPT_SPARSE_COLUMNS (default 1): on the fused path, when at most half of the
+ * farfield columns hold a non-zero weight or target (spot arrays), transform only those columns
+ * and move only them between the two kernels; the results are those of the dense path (every other
+ * column of the constrained farfield is exactly zero).  0 forces the dense kernels. */
+enum { HGS_OPT_SPARSE_COLUMNS = 1 };
+int hgs_set_option(hgs_engine* e, int option, int value);
+
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */
 enum { HGS_K_ROW = 0, HGS_K_COL_FUSED = 1, HGS_K_COL_FWD = 2, HGS_K_COL_INV = 3, HGS_K_ELEMENTWISE = 4,
        HGS_K_COUNT = 5 };

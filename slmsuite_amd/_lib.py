@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HGS_LIB", os.path.join(_HERE, "libhgs.so"))   # HGS_LIB: A/B builds only
 
 HGS_OK, HGS_ERR_ARG, HGS_ERR_DEVICE, HGS_ERR_STATE, HGS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+OPT_SPARSE_COLUMNS = 1      # hgs_set_option
 
 # array selectors (include/hgs.h)
 (PHASE, AMP, AMP_SCALAR, PROP_KERNEL, TARGET, WEIGHTS, PHASE_FF, FARFIELD, AMP_FF, SPOT_INDEX,
@@ -69,6 +70,7 @@ def load():
         "hgs_iterate_stats": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_uint8), C.c_int, C.c_int,
                                         P(C.c_double), P(C.c_double)]),
         "hgs_sync": (C.c_int, [eng]),
+        "hgs_set_option": (C.c_int, [eng, C.c_int, C.c_int]),
         "hgs_profile_enable": (C.c_int, [eng, C.c_int]),
         "hgs_profile_read": (C.c_int, [eng, P(C.c_double)]),
         "hgs_iterate_timed": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_double)]),
@@ -85,7 +87,7 @@ def load():
 
 EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device",
            "hgs_reset_weights", "hgs_nearfield2farfield", "hgs_farfield_constraint",
-           "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_multiplane_farfield2nearfield", "hgs_sync", "hgs_profile_enable",
+           "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_multiplane_farfield2nearfield", "hgs_set_option", "hgs_sync", "hgs_profile_enable",
            "hgs_profile_read", "hgs_iterate_timed", "hgs_last_error", "hgs_version")
 
 

@@ -66,6 +66,7 @@ struct EngineBase {
                               double* out) = 0;
     virtual int stats(int group, int width, const double* xy, double* out) = 0;
     virtual int sync() = 0;
+    virtual int set_option(int option, int value) = 0;
     virtual int profile_enable(int on) = 0;
     virtual int profile_read(double* out) = 0;
     virtual int iterate_timed(hgs_step* st, int n, double* ms) = 0;
@@ -106,8 +107,10 @@ template <typename R> struct Engine : EngineBase {
     unsigned char* col_active = nullptr;   // [B][Pw]
     int* col_list = nullptr;               // [B][Pw] compacted
     int* n_active_dev = nullptr;           // [B]
+    unsigned short* lane_mask = nullptr;   // [B][Pw/16] row-kernel view of col_active
     int n_active_max = 0, n_active_min = 0;
     bool sparse_dirty = true;
+    int opt_sparse = 1;                    // HGS_OPT_SPARSE_COLUMNS
     // statistics of the fused path (hgs_iterate_stats)
     double* stat_partial = nullptr;   // [B][blocks][STAT_WAVES][STAT_N]
     double* stat_tsum = nullptr;      // [B] sum T^2
@@ -142,7 +145,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, lane_mask, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -622,6 +625,7 @@ template <typename R> struct Engine : EngineBase {
             RowArgs<R> a = row_args(finalize);
             a.load_active = load_sparse ? col_active : nullptr;
             a.store_active = store_sparse ? col_active : nullptr;
+            a.lane_mask = lane_mask;
             LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks, B), stream, a));
             return 0;
         });
@@ -633,12 +637,13 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_active), (size_t)B * g.Pw));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list), (size_t)B * g.Pw * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_active_dev), (size_t)B * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
         }
         hipLaunchKernelGGL(scan_active_cols<R>, dim3(g.Pw, B), dim3(256), 0, stream, (const R*)w, (const R*)t, g.Ph, g.Pw,
                            col_active);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
-                           col_list, n_active_dev);
+                           col_list, n_active_dev, lane_mask);
         HIPCHK(hipGetLastError());
         std::vector<int> h(B);
         HIPCHK(hipMemcpyAsync(h.data(), n_active_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -892,7 +897,7 @@ template <typename R> struct Engine : EngineBase {
         // transformed (col_fused_kernel with a column list) and only they cross HBM between the two
         // kernels.  Iterations that must produce phase_ff or amp_ff of every pixel run dense.
         bool sparse_enabled = false;
-        if (env_int("HGS_SPARSE", 1) && g.Ph >= 4096 && !env_int("HGS_OLD_FUSED", 0)) {
+        if (env_int("HGS_SPARSE", opt_sparse) && g.Ph >= 4096 && !env_int("HGS_OLD_FUSED", 0)) {
             if (int e = refresh_sparse()) return e;
             sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
         }
@@ -1192,6 +1197,12 @@ template <typename R> struct Engine : EngineBase {
         return fail(HGS_ERR_ARG, "unknown statistics group %d", group);
     }
 
+    int set_option(int option, int value) override {
+        switch (option) {
+            case HGS_OPT_SPARSE_COLUMNS: opt_sparse = value ? 1 : 0; return 0;
+        }
+        return fail(HGS_ERR_ARG, "unknown option %d", option);
+    }
     int sync() override {
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
@@ -1280,6 +1291,7 @@ int hgs_stats(hgs_engine* e, int group, int width, const double* xy, double* out
     return e->impl->stats(group, width, xy, out);
 }
 int hgs_sync(hgs_engine* e) { ENG(e) return e->impl->sync(); }
+int hgs_set_option(hgs_engine* e, int option, int value) { ENG(e) return e->impl->set_option(option, value); }
 int hgs_profile_enable(hgs_engine* e, int on) { ENG(e) return e->impl->profile_enable(on); }
 int hgs_profile_read(hgs_engine* e, double* out) {
     ENG(e)

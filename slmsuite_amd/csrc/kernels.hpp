@@ -281,6 +281,7 @@ template <typename R> struct RowArgs {
     // the next one will read that column); nullptr = all columns
     const unsigned char* load_active;
     const unsigned char* store_active;
+    const unsigned short* lane_mask;   // [b][Pw/16]: bit m = column j + m*Pw/16 active
     Cx<R>* nf_out;       // MODE 1 only: store the complex nearfield rows [b][Sh][Sw] instead of extracting
                          // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
 };
@@ -316,15 +317,13 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
     const unsigned gh_lane = (unsigned)(j >> 2) * g.Sh * 4u + (unsigned)(j & 3);
     const unsigned gh_step = (unsigned)T * g.Sh;
     const int c_lane = j - g.c0;   // SLM column of element m is c_lane + m*T
-    // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list)
+    // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list);
+    // lane_mask[b][16][Pw/16] holds the 16-bit mask of lane j of a length-Pw row transform
     unsigned lmask = 0xffffu, smask = 0xffffu;
-    if (a.load_active != nullptr) {
-        lmask = 0;
-        static_for<0, 16>([&](auto m_) { constexpr int m = m_; lmask |= (unsigned)(a.load_active[(size_t)b * g.Pw + j + m * T] != 0) << m; });
-    }
-    if (a.store_active != nullptr) {
-        smask = 0;
-        static_for<0, 16>([&](auto m_) { constexpr int m = m_; smask |= (unsigned)(a.store_active[(size_t)b * g.Pw + j + m * T] != 0) << m; });
+    if (a.load_active != nullptr || a.store_active != nullptr) {
+        const unsigned mk16 = a.lane_mask[(size_t)b * T + j];
+        if (a.load_active != nullptr) lmask = mk16;
+        if (a.store_active != nullptr) smask = mk16;
     }
 
     // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
@@ -1473,7 +1472,8 @@ template <typename R> __global__ void scan_active_cols(const R* w, const R* t, i
     if (threadIdx.x == 0) active[(size_t)b * Pw + col] = (unsigned char)any;
 }
 // one workgroup per hologram: ordered compaction of the active columns
-static __global__ void compact_active_cols(const unsigned char* active, int Pw, int* list, int* n_active) {
+static __global__ void compact_active_cols(const unsigned char* active, int Pw, int* list, int* n_active,
+                                           unsigned short* lane_mask) {
     __shared__ int base;
     __shared__ int wsum[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1497,6 +1497,12 @@ static __global__ void compact_active_cols(const unsigned char* active, int Pw, 
         __syncthreads();
     }
     if (threadIdx.x == 0) n_active[b] = base;
+    const int T = Pw / 16;
+    for (int j = threadIdx.x; j < T; j += blockDim.x) {
+        unsigned m16 = 0;
+        for (int m = 0; m < 16; ++m) m16 |= (unsigned)(active[(size_t)b * Pw + j + m * T] != 0) << m;
+        lane_mask[(size_t)b * T + j] = (unsigned short)m16;
+    }
 }
 
 }  // namespace hgs

@@ -144,6 +144,9 @@ class Engine:
         w = (C.c_double * n)(*[float(x) for x in weights])
         L.check(engines[0].lib.hgs_multiplane_farfield2nearfield(handles, w, n))
 
+    def set_option(self, option, value):
+        L.check(self.lib.hgs_set_option(self._h, int(option), int(value)))
+
     def sync(self):
         L.check(self.lib.hgs_sync(self._h))
 
