@@ -14,6 +14,8 @@
 #include "../../include/hgs.h"
 #include "launch.hpp"
 #include "compressed_kernels.hpp"
+#include "cgemm.hpp"
+#include "compressed_sep.hpp"
 
 namespace hgs {
 
@@ -126,6 +128,20 @@ template <typename R> struct Engine : EngineBase {
     double* cnorm = nullptr;
     R* ext_r = nullptr;
     int c_nblocks = 0, c_degree = -1, c_rows = 0;
+    // separable (matrix-core) form of the compressed transforms, fp32 only (compressed_sep.hpp)
+    bool grid_sep[2] = {false, false}, c_sep = false;
+    std::vector<double> xs_host, ys_host;
+    double* sep_c = nullptr;        // [2][SEP_MAXDEG+1][N] polynomial coefficients of fx_n, fy_n
+    double* sep_g = nullptr;        // xs[W] then ys[H]
+    float2* sep_ex = nullptr;       // [N][W]
+    float2* sep_exT = nullptr;      // [W][N]
+    float2* sep_ey = nullptr;       // [N][H]
+    float2* sep_nfT = nullptr;      // [B][W][H]
+    float2* sep_b2 = nullptr;       // [B][N][H]
+    float2* sep_c1 = nullptr;       // [B][split1][N][H]
+    float2* sep_c2 = nullptr;       // [B][split2][H][W]
+    double* sep_norm = nullptr;     // [B][ceil(N/4)]
+    int sep_split1 = 1, sep_kper1 = 0, sep_split2 = 1, sep_kper2 = 0, sep_degx = 0, sep_degy = 0;
     std::vector<int32_t> mono_host;
     std::vector<R> coeff_host;
     bool has_grid[2] = {false, false}, has_mono = false, has_coeff = false;
@@ -145,7 +161,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, lane_mask, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, lane_mask, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -301,6 +317,105 @@ template <typename R> struct Engine : EngineBase {
         } else {
             HIPCHK(hipMemcpy(coeff, coeff_host.data(), (size_t)M * N * sizeof(R), hipMemcpyHostToDevice));
         }
+        return sep_refresh();
+    }
+
+    // ---- separable / matrix-core form (compressed_sep.hpp) ----
+    static void split_for(int tiles, int K, int n_cu, int* split, int* k_per) {
+        int sp = std::max(1, (4 * n_cu + tiles - 1) / tiles);
+        sp = std::min(sp, std::max(1, K / 256));
+        int kp = ((K + sp - 1) / sp + CG_BK - 1) / CG_BK * CG_BK;
+        sp = (K + kp - 1) / kp;
+        *split = sp;
+        *k_per = kp;
+    }
+    int sep_refresh() {
+        c_sep = false;
+        if (sizeof(R) != 4 || cfg.kind != 1) return 0;
+        if (!(has_grid[0] && has_grid[1] && grid_sep[0] && grid_sep[1] && has_mono && has_coeff)) return 0;
+        const int M = cfg.n_monomials, N = cfg.n_spots, H = g.Sh, W = g.Sw;
+        int dx = 0, dy = 0;
+        for (int m = 0; m < M; ++m) {
+            const int px = mono_host[2 * m], py = mono_host[2 * m + 1];
+            if (px < 0 || py < 0 || (px > 0 && py > 0) || px > SEP_MAXDEG || py > SEP_MAXDEG) return 0;   // not separable
+            dx = std::max(dx, px);
+            dy = std::max(dy, py);
+        }
+        std::vector<double> c((size_t)2 * (SEP_MAXDEG + 1) * N, 0.0);
+        for (int m = 0; m < M; ++m) {
+            const int px = mono_host[2 * m], py = mono_host[2 * m + 1];
+            double* dst = (py == 0) ? &c[(size_t)px * N] : &c[((size_t)(SEP_MAXDEG + 1) + py) * N];
+            for (int n = 0; n < N; ++n) dst[n] += (double)coeff_host[(size_t)m * N + n];
+        }
+        if (!sep_c) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c), c.size() * sizeof(double)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_g), (size_t)(W + H) * sizeof(double)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_ex), (size_t)N * W * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_exT), (size_t)N * W * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_ey), (size_t)N * H * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_nfT), (size_t)B * W * H * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_b2), (size_t)B * N * H * sizeof(float2)));
+            split_for(((N + CG_BM - 1) / CG_BM) * ((H + CG_BN - 1) / CG_BN), W, n_cu, &sep_split1, &sep_kper1);
+            split_for(((H + CG_BM - 1) / CG_BM) * ((W + CG_BN - 1) / CG_BN), N, n_cu, &sep_split2, &sep_kper2);
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c1), (size_t)B * sep_split1 * N * H * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c2), (size_t)B * sep_split2 * H * W * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_norm), (size_t)B * ((N + 3) / 4) * sizeof(double)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_kouter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)CG_LDS_BYTES));
+        }
+        HIPCHK(hipMemcpyAsync(sep_c, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(sep_g, xs_host.data(), (size_t)W * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(sep_g + W, ys_host.data(), (size_t)H * sizeof(double), hipMemcpyHostToDevice, stream));
+        sep_degx = dx;
+        sep_degy = dy;
+        hipLaunchKernelGGL(sep_build_table, dim3((W + 255) / 256, N), dim3(256), 0, stream, (const double*)sep_c, dx, N,
+                           (const double*)sep_g, W, sep_ex, sep_exT);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(sep_build_table, dim3((H + 255) / 256, N), dim3(256), 0, stream,
+                           (const double*)(sep_c + (size_t)(SEP_MAXDEG + 1) * N), dy, N, (const double*)(sep_g + W), H, sep_ey,
+                           (float2*)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));   // c / xs_host are host temporaries
+        c_sep = true;
+        return 0;
+    }
+    bool use_sep() const {
+        return c_sep && env_int("HGS_C_SEPARABLE", 1) && cfg.n_spots >= env_int("HGS_C_SEP_MIN", 32);
+    }
+    int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int K, int lda, int ldb, int split, int k_per,
+                     size_t strideA, size_t strideB) {
+        CgemmArgs a{A, Bm, C, M, N, K, lda, ldb, split, k_per, strideA, strideB};
+        hipLaunchKernelGGL(cgemm_kouter, dim3((M + CG_BM - 1) / CG_BM, (N + CG_BN - 1) / CG_BN, split * B), dim3(256),
+                           CG_LDS_BYTES, stream, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    // n2f: T = Ex^T-table x nf^T on the matrix cores, then the y contraction with Ey
+    int sep_n2f() {
+        const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
+        hipLaunchKernelGGL(sep_build_nft<R>, dim3((W + 31) / 32, (H + 31) / 32, B), dim3(32, 8), 0, stream, (const R*)phase,
+                           has_amp ? (const R*)amp : (const R*)nullptr, has_kern ? (const R*)kern : (const R*)nullptr,
+                           (R)amp_scalar, H, W, sep_nfT);
+        HIPCHK(hipGetLastError());
+        if (int e = launch_cgemm(sep_exT, sep_nfT, sep_c1, N, H, W, N, H, sep_split1, sep_kper1, 0, (size_t)W * H)) return e;
+        const int nred = (N + 3) / 4;
+        hipLaunchKernelGGL(sep_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_split1,
+                           (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(256), 0, stream, cargs(), (const double*)sep_norm, nred);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    // f2n: conj(nf) = (conj(ff) Ey)^T x Ex on the matrix cores, then phase extraction (or the complex field)
+    int sep_f2n(Cx<R>* nf_out) {
+        const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
+        hipLaunchKernelGGL(sep_build_b2<R>, dim3((H + 255) / 256, N, B), dim3(256), 0, stream, (const Cx<R>*)ff,
+                           (const float2*)sep_ey, N, H, sep_b2);
+        HIPCHK(hipGetLastError());
+        if (int e = launch_cgemm(sep_b2, sep_ex, sep_c2, H, W, N, H, W, sep_split2, sep_kper2, (size_t)N * H, 0)) return e;
+        hipLaunchKernelGGL(sep_f2n_finish<R>, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, (const float2*)sep_c2,
+                           sep_split2, S, has_kern ? (const R*)kern : (const R*)nullptr, phase, nf_out);
+        HIPCHK(hipGetLastError());
         return 0;
     }
 
@@ -323,6 +438,7 @@ template <typename R> struct Engine : EngineBase {
         if (store_pff) { if (int e = need_pff()) return e; }
         const int nred = (int)((P + 255) / 256);
         int r = timed(HGS_K_COL_FWD, [&]() -> int {
+            if (use_sep()) return sep_n2f();
             CArgs<R> a = cargs();
             const dim3 grid(c_nblocks, B);
             if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a);
@@ -349,6 +465,7 @@ template <typename R> struct Engine : EngineBase {
     int f2n_compressed() {
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
         int r = timed(HGS_K_COL_INV, [&]() -> int {
+            if (use_sep()) return sep_f2n(nullptr);
             CArgs<R> a = cargs();
             const dim3 grid(c_nblocks, B);
             if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
@@ -523,7 +640,26 @@ template <typename R> struct Engine : EngineBase {
                 HIPCHK(hipMemcpy(which == HGS_XGRID ? xg : yg, host, nbytes, hipMemcpyHostToDevice));
                 has_grid[which == HGS_XGRID ? 0 : 1] = true;
                 farfield_valid = false;
-                return 0;
+                {   // product grid?  x depends on the column only, y on the row only
+                    const R* h = (const R*)host;
+                    const int H = g.Sh, W = g.Sw;
+                    bool sep = true;
+                    if (which == HGS_XGRID) {
+                        for (int y = 1; y < H && sep; ++y)
+                            for (int x = 0; x < W; ++x)
+                                if (h[(size_t)y * W + x] != h[x]) { sep = false; break; }
+                        xs_host.assign(W, 0.0);
+                        for (int x = 0; x < W; ++x) xs_host[x] = (double)h[x];
+                    } else {
+                        for (int y = 0; y < H && sep; ++y)
+                            for (int x = 1; x < W; ++x)
+                                if (h[(size_t)y * W + x] != h[(size_t)y * W]) { sep = false; break; }
+                        ys_host.assign(H, 0.0);
+                        for (int y = 0; y < H; ++y) ys_host[y] = (double)h[(size_t)y * W];
+                    }
+                    grid_sep[which == HGS_XGRID ? 0 : 1] = sep;
+                }
+                return sep_refresh();
             }
             case HGS_MONOMIALS: {
                 if (cfg.kind != 1) return fail(HGS_ERR_STATE, "monomials belong to the compressed engine");
@@ -702,6 +838,7 @@ template <typename R> struct Engine : EngineBase {
         if (!nfbuf) { if (dalloc(&nfbuf, B * S)) return HGS_ERR_DEVICE; }
         if (cfg.kind == 1) {
             int r = timed(HGS_K_COL_INV, [&]() -> int {
+                if (use_sep()) return sep_f2n(nfbuf);
                 CArgs<R> a = cargs();
                 a.nf_out = nfbuf;
                 const dim3 grid(c_nblocks, B);

@@ -42,7 +42,9 @@ per_iter = dt / (args.iters + 0.5)                        # + the trailing forwa
 S = args.slm[0] * args.slm[1]
 evals = 2.0 * args.spots * S / per_iter
 flop = (2 * args.dim + 8 + 2)
-print(json.dumps({"metric": "CompressedSpotHologram WGS-Kim iterations/s", "value": 1 / per_iter,
+mode = "direct kernels" if os.environ.get("HGS_C_SEPARABLE", "1") == "0" else "separable form on the matrix cores (D <= 3)"
+print(json.dumps({"metric": "CompressedSpotHologram WGS-Kim iterations/s", "value": 1 / per_iter, "path": mode,
+                  "mfma_tflops": 2 * 8.0 * args.spots * S / per_iter / 1e12,
                   "spots": args.spots, "slm": list(args.slm), "dim": args.dim, "ms_per_iter": per_iter * 1e3,
                   "kernel_evaluations_per_s": evals, "tflops_equiv": evals * flop / 1e12,
                   "frac_fp32_vector_peak": evals * flop / 157.3e12,
