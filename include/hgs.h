@@ -154,10 +154,13 @@ int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double*
 
 int hgs_sync(hgs_engine* e);
 
-/* Engine options.  HGS_OPT_SPARSE_COLUMNS (default 1): on the fused path, when at most half of the
- * farfield columns hold a non-zero weight or target (spot arrays), transform only those columns
- * and move only them between the two kernels; the results are those of the dense path (every other
- * column of the constrained farfield is exactly zero).  0 forces the dense kernels. */
+/* Engine options.  HGS_OPT_SPARSE_COLUMNS (default 1): in hgs_iterate / hgs_iterate_stats, when few of
+ * the farfield columns hold a non-zero weight or target (spot arrays), transform only those columns
+ * and move only them between the two kernels; the phase and the weights are those of the dense path
+ * (every other column of the constrained farfield is exactly zero).  Covers pixel feedback and, with
+ * the spot columns dilated by the integration window, the spot feedback modes.  While it is active,
+ * HGS_PHASE_FF stored by WGS-Kim is refreshed on the active columns only (the rest cannot influence the
+ * loop; hgs_nearfield2farfield(store_phase_ff = 1) refreshes every pixel).  0 forces the dense kernels. */
 enum { HGS_OPT_SPARSE_COLUMNS = 1 };
 int hgs_set_option(hgs_engine* e, int option, int value);
 

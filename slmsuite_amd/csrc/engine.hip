@@ -110,6 +110,13 @@ template <typename R> struct Engine : EngineBase {
     int* col_list = nullptr;               // [B][Pw] compacted
     int* n_active_dev = nullptr;           // [B]
     unsigned short* lane_mask = nullptr;   // [B][Pw/16] row-kernel view of col_active
+    // the same for the columns the spot integration windows touch (spot feedback / spot statistics)
+    unsigned char* col_active_d = nullptr;
+    int* col_list_d = nullptr;
+    int* n_active_d_dev = nullptr;
+    unsigned short* lane_mask_d = nullptr;
+    int n_active_d_max = 0, dil_lo = 0, dil_hi = 0;
+    bool dil_valid = false;
     int n_active_max = 0, n_active_min = 0;
     bool sparse_dirty = true;
     int opt_sparse = 1;                    // HGS_OPT_SPARSE_COLUMNS
@@ -161,7 +168,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, lane_mask, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -241,7 +248,7 @@ template <typename R> struct Engine : EngineBase {
         if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
         if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
         if (dalloc(&wpartial, (size_t)B * std::max(std::max(col_blocks, tile_blocks), n_cu * 3))) return HGS_ERR_DEVICE;
-        if (dalloc(&fpartial, (size_t)B * col_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&fpartial, (size_t)B * std::max(col_blocks, n_cu * 3))) return HGS_ERR_DEVICE;
         if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&sums, (size_t)4 * B)) return HGS_ERR_DEVICE;
         if (dalloc(&wscale, (size_t)B)) return HGS_ERR_DEVICE;
@@ -665,6 +672,7 @@ template <typename R> struct Engine : EngineBase {
                 if (cfg.kind != 1) return fail(HGS_ERR_STATE, "monomials belong to the compressed engine");
                 if (nbytes != (size_t)2 * cfg.n_monomials * sizeof(int32_t)) return fail(HGS_ERR_ARG, "monomials: bad size");
                 const int32_t* h = (const int32_t*)host;
+                if (has_mono && std::equal(mono_host.begin(), mono_host.end(), h)) return 0;   // unchanged term set
                 mono_host.assign(h, h + 2 * cfg.n_monomials);
                 HIPCHK(hipMemcpy(mono, host, nbytes, hipMemcpyHostToDevice));
                 has_mono = true;
@@ -756,15 +764,37 @@ template <typename R> struct Engine : EngineBase {
         a.xcd_map = row_xcd;
         return a;
     }
-    int run_row(int mode, bool finalize, bool load_sparse = false, bool store_sparse = false) {
+    // load / store: 0 = every column, 1 = active columns, 2 = active columns dilated by the spot windows
+    int run_row(int mode, bool finalize, int load_sparse = 0, int store_sparse = 0) {
         return timed(HGS_K_ROW, [&]() -> int {
             RowArgs<R> a = row_args(finalize);
-            a.load_active = load_sparse ? col_active : nullptr;
-            a.store_active = store_sparse ? col_active : nullptr;
-            a.lane_mask = lane_mask;
+            a.load_mask = load_sparse == 1 ? lane_mask : load_sparse == 2 ? lane_mask_d : nullptr;
+            a.store_mask = store_sparse == 1 ? lane_mask : store_sparse == 2 ? lane_mask_d : nullptr;
             LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks, B), stream, a));
             return 0;
         });
+    }
+    // active columns dilated by the offsets [lo, hi] of the spot integration window
+    int refresh_dilated(int lo, int hi) {
+        if (dil_valid && lo == dil_lo && hi == dil_hi) return 0;
+        if (!col_active_d) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_active_d), (size_t)B * g.Pw));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list_d), (size_t)B * g.Pw * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_active_d_dev), (size_t)B * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_d), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
+        }
+        hipLaunchKernelGGL(dilate_active_cols, dim3((g.Pw + 255) / 256, B), dim3(256), 0, stream,
+                           (const unsigned char*)col_active, g.Pw, lo, hi, col_active_d);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active_d, g.Pw,
+                           col_list_d, n_active_d_dev, lane_mask_d);
+        HIPCHK(hipGetLastError());
+        std::vector<int> h(B);
+        HIPCHK(hipMemcpyAsync(h.data(), n_active_d_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        n_active_d_max = *std::max_element(h.begin(), h.end());
+        dil_lo = lo; dil_hi = hi; dil_valid = true;
+        return 0;
     }
     // (re)build the active-column list when weights or target changed since the last scan
     int refresh_sparse() {
@@ -787,6 +817,7 @@ template <typename R> struct Engine : EngineBase {
         n_active_max = *std::max_element(h.begin(), h.end());
         n_active_min = *std::min_element(h.begin(), h.end());
         sparse_dirty = false;
+        dil_valid = false;
         return 0;
     }
     ColArgs<R> col_args() {
@@ -1014,11 +1045,106 @@ template <typename R> struct Engine : EngineBase {
         return cfg.kind == 0 && !st->mraf_enabled && st->feedback == HGS_FB_PIXEL && st->method != HGS_WGS_NOGRETTE;
     }
 
+    // ---- spot feedback on sparse targets ("computational_spot" / "external_spot", _spots.py:1573-1624) ----
+    // The N-vector weight rule needs |F|^2 only in the w x w windows around the spots, so the forward
+    // transform runs on the spot columns dilated by the window (col_kernel FWD|STORE over a list), the
+    // existing window-sum / N-vector kernels update the weights at the spot pixels, and the constrained
+    // field is formed and transformed back by the fused kernel over the spot columns (weight update
+    // off).  Everything else of the farfield is exactly zero and is neither computed nor moved.
+    bool spot_sparse_ok(const hgs_step* st) {
+        if (cfg.kind != 0 || st->mraf_enabled || st->method == HGS_GS || st->feedback == HGS_FB_PIXEL) return false;
+        if (!env_int("HGS_SPARSE", opt_sparse) || g.Ph < 4096 || env_int("HGS_FORCE_STEPWISE", 0)) return false;
+        if (refresh_sparse()) return false;
+        return n_active_min > 0 && n_active_max * 4 <= g.Pw;
+    }
+    int iterate_spot_sparse(hgs_step* st, int n, uint8_t* hist) {
+        if (int e = normalize_weights_now()) return e;      // the N-vector rule keeps the weights normalised
+        if (int e = need_ff()) return e;
+        const int groups = stat_ctx ? stat_ctx->groups : 0;
+        auto window = [](int w, int* lo, int* hi) { *lo = (int)std::floor(-(w - 1) / 2.0); *hi = *lo + w - 1; };
+        int lo = 0, hi = 0, l2, h2;
+        if (st->feedback == HGS_FB_SPOT_WINDOW) window(st->spot_window, &lo, &hi);
+        if (groups & 2) { window(stat_ctx->width, &l2, &h2); lo = std::min(lo, l2); hi = std::max(hi, h2); }
+        if (int e = refresh_dilated(lo, hi)) return e;
+        auto windows_needed = [&](const Plan& q) {
+            return (st->feedback == HGS_FB_SPOT_WINDOW && q.do_update) || (groups & 2);
+        };
+        farfield_valid = false;
+        Plan p = plan_iteration(st, hist ? hist : nullptr);
+        if (int e = run_row(0, false, 0, windows_needed(p) ? 2 : 1)) return e;
+        for (int i = 0; i < n; ++i) {
+            if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
+            const CParams<R> cp = cparams(st, p);
+            if (windows_needed(p)) {
+                int r = timed(HGS_K_COL_FWD, [&]() -> int {
+                    ColArgs<R> a = col_args();
+                    a.col_list = col_list_d;
+                    a.n_active = n_active_d_dev;
+                    LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(std::min(n_active_d_max, n_cu * 3), B), stream, a));
+                    return 0;
+                });
+                if (r) return r;
+            }
+            if (p.do_update) {
+                int r = timed(HGS_K_ELEMENTWISE, [&]() -> int {
+                    SpotArgs<R> sa{};
+                    sa.g = g; sa.n_spots = cfg.n_spots; sa.width = st->spot_window; sa.feedback = st->feedback;
+                    sa.spot_xy = spot_xy; sa.amp_ff = aff; sa.ext_amp = ext_amp; sa.spot_amp = spot_amp; sa.w = w;
+                    sa.fb = spot_fb; sa.cp = cp;
+                    if (st->feedback == HGS_FB_SPOT_WINDOW) {
+                        hipLaunchKernelGGL(spot_window<R>, dim3((cfg.n_spots + 127) / 128, B), dim3(128), 0, stream, sa);
+                        HIPCHK(hipGetLastError());
+                    }
+                    hipLaunchKernelGGL(spot_update<R>, dim3(B), dim3(256), 0, stream, sa);
+                    HIPCHK(hipGetLastError());
+                    return 0;
+                });
+                if (r) return r;
+            }
+            int r = timed(HGS_K_COL_FUSED, [&]() -> int {
+                ColArgs<R> a = col_args();
+                a.cp = cp;
+                a.cp.do_update = 0;                          // the weights were updated above
+                a.col_list = col_list;
+                a.n_active = n_active_dev;
+                const int blocks = std::min(n_active_max, n_cu * 3);
+                wpartial_n = blocks;
+                const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
+                if (groups & 1) {
+                    a.do_stats = 1;
+                    a.spartial = stat_partial;
+                    a.tsum = stat_tsum;
+                    a.inv_fsum = 1.0 / amp_norm2;
+                    hipLaunchKernelGGL(stat_fill_neutral, dim3((unsigned)((stat_nslots + 255) / 256)), dim3(256), 0, stream,
+                                       stat_partial, stat_nslots);
+                    LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                } else {
+                    LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                }
+                return 0;
+            });
+            if (r) return r;
+            if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
+            if (p.store_phase) have_pff = true;
+            st->iter++;
+            Plan pn{0, 0, 0};
+            int store_next = 1;
+            if (i + 1 < n) {
+                pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
+                store_next = windows_needed(pn) ? 2 : 1;
+            }
+            if (int e = run_row(i + 1 < n ? 2 : 1, false, 1, store_next)) return e;
+            p = pn;
+        }
+        return 0;
+    }
+
     int iterate(hgs_step* st, int n, uint8_t* hist) override {
         if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
         if (n == 0) return 0;
         if (int e = check_step(st)) return e;
         const bool fused = fused_ok(st) && !env_int("HGS_FORCE_STEPWISE", 0);
+        if (!fused && spot_sparse_ok(st)) return iterate_spot_sparse(st, n, hist);
         if (!fused) {
             for (int i = 0; i < n; ++i) {
                 if (int e = n2f(0)) return e;
@@ -1039,7 +1165,8 @@ template <typename R> struct Engine : EngineBase {
             sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
         }
         auto col_sparse = [&](const Plan& p) {
-            return sparse_enabled && !p.store_phase && !(stat_ctx && (stat_ctx->groups & 2));
+            (void)p;   // phase_ff is stored (WGS-Kim) on the active columns only: nothing else can be read back
+            return sparse_enabled && !(stat_ctx && (stat_ctx->groups & 2));
         };
         Plan p = plan_iteration(st, hist ? hist : nullptr);
         bool sp = col_sparse(p);
@@ -1150,7 +1277,8 @@ template <typename R> struct Engine : EngineBase {
             }
         }
         for (size_t k = 0; k < (size_t)n * 2 * B * 4; ++k) out[k] = NAN;
-        const bool fused = fused_ok(st) && !env_int("HGS_FORCE_STEPWISE", 0) && !env_int("HGS_OLD_FUSED", 0);
+        const bool fused = (fused_ok(st) || spot_sparse_ok(st)) && !env_int("HGS_FORCE_STEPWISE", 0) &&
+                           !env_int("HGS_OLD_FUSED", 0);
         if (!fused) {
             // general path: materialise, reduce, constrain -- one host read of a few doubles per iteration
             for (int i = 0; i < n; ++i) {

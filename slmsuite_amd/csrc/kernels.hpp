@@ -277,11 +277,9 @@ template <typename R> struct RowArgs {
     int n_wpartial;
     R* wscale;
     int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
-    // sparse targets: per-column activity [b][Pw] (1 = the column kernel of this iteration wrote /
-    // the next one will read that column); nullptr = all columns
-    const unsigned char* load_active;
-    const unsigned char* store_active;
-    const unsigned short* lane_mask;   // [b][Pw/16]: bit m = column j + m*Pw/16 active
+    // sparse targets: which columns the column kernel of this iteration wrote / the next one will read
+    const unsigned short* load_mask;    // [b][Pw/16]: bit m of entry j = column j + m*Pw/16 is to be read ...
+    const unsigned short* store_mask;   // ... / written; nullptr = every column
     Cx<R>* nf_out;       // MODE 1 only: store the complex nearfield rows [b][Sh][Sw] instead of extracting
                          // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
 };
@@ -320,11 +318,8 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
     // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list);
     // lane_mask[b][16][Pw/16] holds the 16-bit mask of lane j of a length-Pw row transform
     unsigned lmask = 0xffffu, smask = 0xffffu;
-    if (a.load_active != nullptr || a.store_active != nullptr) {
-        const unsigned mk16 = a.lane_mask[(size_t)b * T + j];
-        if (a.load_active != nullptr) lmask = mk16;
-        if (a.store_active != nullptr) smask = mk16;
-    }
+    if (a.load_mask != nullptr) lmask = a.load_mask[(size_t)b * T + j];
+    if (a.store_mask != nullptr) smask = a.store_mask[(size_t)b * T + j];
 
     // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
     // assumption): give the four rows that share each 128-byte GH line to four blocks of the same
@@ -483,12 +478,28 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
     double acc_w = 0, acc_f = 0;
     const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
 
+    // column schedule: tiles of 4 columns strided over the grid, or (col_list != nullptr, CPAR == 1)
+    // just the listed columns -- sparse targets, see ColArgs::col_list
+    const bool listed = a.col_list != nullptr;
+    const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
+    const int n_act = listed ? a.n_active[b] : 0;
+    const int ntiles = g.Pw / 4;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nq = listed ? ((int)blockIdx.x < n_act ? (n_act - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
+                          : my_tiles * PASSES;
 #pragma unroll 1
-    for (int ct = blockIdx.x; ct < g.Pw / 4; ct += gridDim.x) {
+    for (int q = 0; q < nq; ++q) {
+        int ct, c4;
+        if (listed) {
+            const int col = clist[blockIdx.x + q * gridDim.x];
+            ct = col >> 2;
+            c4 = col & 3;
+        } else {
+            ct = blockIdx.x + (q / PASSES) * gridDim.x;
+            c4 = (q % PASSES) * CPAR + cpar;
+        }
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
-#pragma unroll 1
-        for (int pass = 0; pass < PASSES; ++pass) {
-            const int c4 = pass * CPAR + cpar;
+        {
             const int kx = ct * 4 + c4;
             const size_t cb = (size_t)b * P + (size_t)kx * g.Ph;   // column base in the P arrays
             Cx<R> v[16];
@@ -1470,6 +1481,18 @@ template <typename R> __global__ void scan_active_cols(const R* w, const R* t, i
     if (__builtin_amdgcn_ballot_w64(nz) != 0 && (threadIdx.x & 63) == 0) any = 1;
     __syncthreads();
     if (threadIdx.x == 0) active[(size_t)b * Pw + col] = (unsigned char)any;
+}
+// dil[c] = any active[c - d], d in [lo, hi]: the columns a w-wide integration window around a spot
+// column touches (analysis.take offsets floor(-(w-1)/2) ...).  grid = (ceil(Pw/256), batch)
+static __global__ void dilate_active_cols(const unsigned char* active, int Pw, int lo, int hi, unsigned char* dil) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= Pw) return;
+    unsigned char on = 0;
+    for (int d = lo; d <= hi; ++d) {
+        const int s = c - d;
+        if (s >= 0 && s < Pw && active[(size_t)b * Pw + s]) on = 1;
+    }
+    dil[(size_t)b * Pw + c] = on;
 }
 // one workgroup per hologram: ordered compaction of the active columns
 static __global__ void compact_active_cols(const unsigned char* active, int Pw, int* list, int* n_active,

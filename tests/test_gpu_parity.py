@@ -606,3 +606,46 @@ def test_sparse_column_path_matches_dense_path(method, kw, monkeypatch):
         np.testing.assert_allclose(a.stats["stats"]["computational"][nme][:7], b.stats["stats"]["computational"][nme][:7],
                                    rtol=2e-4, atol=1e-7)
     assert np.count_nonzero(a.weights) == xy.shape[1]
+
+
+@pytest.mark.parametrize("method,feedback,kw", [
+    ("WGS-Leonardo", "computational_spot", {}),
+    ("WGS-Kim", "computational_spot", {"fix_phase_iteration": 3}),
+    ("WGS-Nogrette", "computational_spot", {}),
+    ("WGS-Leonardo", "external_spot", {}),
+    ("WGS-Kim", "computational", {"fix_phase_iteration": 3}),
+])
+def test_sparse_spot_feedback_matches_general_path(method, feedback, kw, monkeypatch):
+    """
+    Spot feedback on a 4096^2 pad (scattered spots): the sparse path -- forward transform of the spot
+    columns dilated by the integration window, N-vector rule, fused constraint + inverse over the spot
+    columns -- against the general (materialising) path of the same engine (HGS_SPARSE=0), with both
+    statistics groups recorded in the loop and a plain call afterwards.
+    """
+    shape, slm = (4096, 4096), (1152, 1920)
+    n = 200
+    xy = np.vstack((1024 + 8 * np.floor(256 * synth.uniform01(87, (n,), 0)), 1024 + 8 * np.floor(256 * synth.uniform01(87, (n,), 1))))
+    xy = np.unique(xy.astype(int), axis=1).astype(float)
+    amp = 0.5 + synth.uniform01(88, (xy.shape[1],), 0)
+
+    def run(sparse):
+        monkeypatch.setenv("HGS_SPARSE", "1" if sparse else "0")
+        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(89, slm))
+        if feedback == "external_spot":
+            h.external_spot_amp = h.spot_amp * (1 + 0.2 * (synth.uniform01(90, (len(h),), 5) - 0.5))
+        h.optimize(method, maxiter=6, verbose=False, feedback=feedback, stat_groups=["computational", "computational_spot"], **kw)
+        h.optimize(method, maxiter=2, verbose=False, feedback=feedback, **kw)
+        return h
+
+    a, b = run(True), run(False)
+    ky, kx = a.spot_knm_rounded[1], a.spot_knm_rounded[0]
+    errs = dict(phase=phase_rel_l2(a.phase, b.phase), spot_amp=rel_l2(a.amp_ff[ky, kx], b.amp_ff[ky, kx]),
+                weights=rel_l2(a.weights[ky, kx], b.weights[ky, kx]))
+    report(f"sparse spot feedback {method} {feedback}", **errs)
+    assert errs["phase"] < 3e-5 and errs["spot_amp"] < 1e-5 and errs["weights"] < 2e-5
+    assert a.stats["flags"]["fixed_phase"] == b.stats["flags"]["fixed_phase"]
+    assert np.count_nonzero(a.weights) == np.count_nonzero(b.weights) == xy.shape[1]
+    for grp in ("computational", "computational_spot"):
+        for nme in STAT_NAMES:
+            np.testing.assert_allclose(a.stats["stats"][grp][nme][:6], b.stats["stats"][grp][nme][:6], rtol=3e-4, atol=1e-7,
+                                       err_msg=f"{grp}.{nme}")
