@@ -1042,7 +1042,9 @@ template <typename R> struct Engine : EngineBase {
     }
 
     bool fused_ok(const hgs_step* st) const {
-        return cfg.kind == 0 && !st->mraf_enabled && st->feedback == HGS_FB_PIXEL && st->method != HGS_WGS_NOGRETTE;
+        // MRAF rides the fused kernels unless the zero region carries zero_weights feedback (:1613-1616)
+        return cfg.kind == 0 && !(st->mraf_enabled && st->zero_mode) && st->feedback == HGS_FB_PIXEL &&
+               st->method != HGS_WGS_NOGRETTE;
     }
 
     // ---- spot feedback on sparse targets ("computational_spot" / "external_spot", _spots.py:1573-1624) ----
@@ -1173,42 +1175,61 @@ template <typename R> struct Engine : EngineBase {
         if (int e = run_row(0, false, false, sp)) return e;
         for (int i = 0; i < n; ++i) {
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
-            int r = timed(HGS_K_COL_FUSED, [&]() -> int {
-                ColArgs<R> a = col_args();
-                a.cp = cparams(st, p);
-                if (stat_ctx) {
-                    a.do_stats = stat_ctx->groups;
-                    a.spartial = stat_partial;
-                    a.tsum = stat_tsum;
-                    a.inv_fsum = 1.0 / amp_norm2;
-                    // launches of different geometry share the partial buffer: reset the slots
-                    hipLaunchKernelGGL(stat_fill_neutral, dim3((unsigned)((stat_nslots + 255) / 256)), dim3(256), 0, stream,
-                                       stat_partial, stat_nslots);
-                }
-                const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
-                // slots of the load layout the SLM rows occupy (tile-resident kernel needs <= 6)
-                const int Tc = g.Ph / 16;
-                const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;
-                wpartial_n = col_blocks;
-                if (sp) {
-                    a.col_list = col_list;
-                    a.n_active = n_active_dev;
-                    const int blocks = std::min(n_active_max, n_cu * 3);
-                    wpartial_n = blocks;
-                    if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
-                    else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
-                } else if (env_int("HGS_OLD_FUSED", 0)) {
-                    LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
-                } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
-                    wpartial_n = tile_blocks;
-                    if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
-                    else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
-                } else {
-                    if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
-                    else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
-                }
-                return 0;
-            });
+            // MRAF with a weight update takes two passes over the columns: the rebuilt field mixes the
+            // NORMALISED weights (signal region) with the un-weighted farfield (noise region), so ||w'|| has
+            // to be known first.  Pass 0: forward transform + weight update (+ statistics), no inverse;
+            // then wscale = 1/||w'||; pass 1: forward transform again, rebuild, inverse.
+            const bool two_pass = st->mraf_enabled && p.do_update;
+            int r = 0;
+            for (int pass = 0; pass < (two_pass ? 2 : 1) && !r; ++pass) {
+                r = timed(HGS_K_COL_FUSED, [&]() -> int {
+                    ColArgs<R> a = col_args();
+                    a.cp = cparams(st, p);
+                    int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
+                    if (two_pass && pass == 0) {
+                        a.cp.weights_only = 1;
+                        phase_mode = 0;
+                    }
+                    if (two_pass && pass == 1) a.cp.do_update = 0;
+                    if (stat_ctx && !(two_pass && pass == 1)) {
+                        a.do_stats = stat_ctx->groups;
+                        a.spartial = stat_partial;
+                        a.tsum = stat_tsum;
+                        a.inv_fsum = 1.0 / amp_norm2;
+                        // launches of different geometry share the partial buffer: reset the slots
+                        hipLaunchKernelGGL(stat_fill_neutral, dim3((unsigned)((stat_nslots + 255) / 256)), dim3(256), 0, stream,
+                                           stat_partial, stat_nslots);
+                    }
+                    // slots of the load layout the SLM rows occupy (tile-resident kernel needs <= 6)
+                    const int Tc = g.Ph / 16;
+                    const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;
+                    wpartial_n = col_blocks;
+                    if (sp) {
+                        a.col_list = col_list;
+                        a.n_active = n_active_dev;
+                        const int blocks = std::min(n_active_max, n_cu * 3);
+                        wpartial_n = blocks;
+                        if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                        else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                    } else if (env_int("HGS_OLD_FUSED", 0)) {
+                        LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
+                    } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
+                        wpartial_n = tile_blocks;
+                        if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                        else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                    } else {
+                        if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                        else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                    }
+                    if (two_pass && pass == 0) {
+                        if (int e = reduce(wpartial, wpartial_n, sums + 2 * B)) return e;
+                        hipLaunchKernelGGL(scale_from_sum<R>, dim3((B + 63) / 64), dim3(64), 0, stream,
+                                           (const double*)(sums + 2 * B), wscale, B);
+                        HIPCHK(hipGetLastError());
+                    }
+                    return 0;
+                });
+            }
             if (r) return r;
             if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
@@ -1221,8 +1242,8 @@ template <typename R> struct Engine : EngineBase {
                 pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
                 sp_next = col_sparse(pn);
             }
-            // the row kernel that follows folds the weight-norm partials into wscale
-            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0, sp, sp_next)) return e;
+            // the row kernel that follows folds the weight-norm partials into wscale (unless already done)
+            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0 && !two_pass, sp, sp_next)) return e;
             p = pn;
             sp = sp_next;
         }

@@ -69,6 +69,9 @@ template <typename R> struct CParams {
     int mraf;         // target holds NaN (noise) / 0 (zero) regions (:1606-1653)
     int has_mraf_factor;
     int zero_mode;    // 0: zero region := 0 ; 1: zero_weights feedback (:1613-1616)
+    int weights_only; // fused kernels: forward transform + weight update (+ statistics) only, no inverse.
+                      // MRAF mixes the normalised weights with the un-weighted noise region, so ||w'|| must
+                      // be known before the field is rebuilt: pass 1 updates the weights, pass 2 rebuilds.
     R p_exp, p_fac, mraf_factor, zero_factor;
     R inv_fnorm;      // 1/||amp_ff|| (Parseval constant ||amp|| in the fused path)
     R log2_inv_fnorm;
@@ -175,9 +178,9 @@ template <typename R> struct StatAcc {
         rmin = emin = INFINITY;
         rmax = emax = -INFINITY;
     }
-    // one pixel with T != 0 (the fused path never sees NaN targets)
+    // one pixel of the mask (T != 0 and not NaN)
     __device__ __forceinline__ void add(R p2, R absF, R t, double at, double bf) {
-        if (t != (R)0) {
+        if (t != (R)0 && t == t) {                     // mask: T != 0 and not NaN (MRAF noise region)
             const double tp = (double)t * (double)t * at, fp = (double)p2 * bf;
             if (tp != 0.0) {
                 const double ratio = fp / tp, err = tp - fp;
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
             wr[m] = wc[lane_pos<T>(j, m)];
-            if (cp.do_update || STATS) tr[m] = tc[lane_pos<T>(j, m)];
+            if (cp.do_update || STATS || cp.mraf) tr[m] = tc[lane_pos<T>(j, m)];
         });
     };
     auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             const unsigned idx = lane_pos<T>(j, m);
             // wave-uniform skip of pixels with zero weight and zero target (see col_tile_kernel)
             if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
-                __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS) && tr[m] != (R)0)) == 0) {
+                __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS || cp.mraf) && tr[m] != (R)0)) == 0) {
                 v[m] = mk<R>(0, 0);
                 return;
             }
@@ -746,6 +749,16 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if constexpr (PHASE == 1) pfc[idx] = M::atan2(F.y, F.x);
             }
             v[m] = mk<R>(wv * co * sgn, wv * si * sgn);
+            if (cp.mraf) {                                  // mixed-region amplitude freedom (:1606-1653)
+                const R t = tr[m];
+                if (is_nan(t)) {
+                    const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
+                    v[m] = F * mf;
+                } else if (t == (R)0) {
+                    v[m] = mk<R>(0, 0);
+                    if constexpr (PHASE == 1) pfc[idx] = (R)0;
+                }
+            }
             if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
 
@@ -755,8 +768,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             issue_wt(q + 1);
             issue_g(q + 1, gn);
         }
-        fft.template run<+1>(v, lds, j);
-        {
+        if (!cp.weights_only) {
+            fft.template run<+1>(v, lds, j);
             Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     R gtx[NR][4], gty[NR][4];   // the tile (scalar arrays: arrays of 2-vectors are not promoted to registers)
     R wr[16], tr[16];
 
-    const bool upd = cp.do_update != 0 || STATS;   // target needed by the update and by the statistics
+    const bool upd = cp.do_update != 0 || STATS || cp.mraf != 0;   // target needed by the update, the statistics, MRAF
     double* stat_slot = scratch + 16 + (j >> 6) * STAT_N;
     StatAcc<R> sacc;
     double stat_at = 0;
@@ -939,6 +952,15 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
                 // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
                 v[m] = cmulc(ph, om) * wv;
+                if (cp.mraf) {                              // mixed-region amplitude freedom (:1606-1653)
+                    const R t = tr[m];
+                    if (is_nan(t)) {                        // noise region keeps the field (times mraf_factor)
+                        v[m] = cmulc(cp.has_mraf_factor ? F * cp.mraf_factor : F, om);
+                    } else if (t == (R)0) {                 // zero region (no zero_weights feedback on this path)
+                        v[m] = mk<R>(0, 0);
+                        if constexpr (PHASE == 1) pfc[idx] = (R)0;   // atan2 of the zeroed field
+                    }
+                }
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (STATS) sacc.flush(stat_slot);
@@ -951,6 +973,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, upd, j, wr, tr);
             }
 
+            if (cp.weights_only) continue;
             fft.template run<+1, HGS_TILE_DB>(v, lds, j);
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
@@ -962,6 +985,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
             }
         }
+        if (cp.weights_only) continue;
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
