@@ -127,8 +127,12 @@ template <typename R> __device__ __forceinline__ bool is_pinf(R x) { return x ==
 
 // ---- block reduction of a double (sum) into partial[slot]; all lanes call ---------------------------
 __device__ __forceinline__ double wave_sum(double v) {
+    const int lane = threadIdx.x & 63, nl = min(64, (int)blockDim.x - ((int)threadIdx.x & ~63));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(v, o, 64);
+        if (lane + o < nl) v += u;
+    }
     return v;
 }
 // scratch: at least 16 doubles of LDS not in use by anyone else at the call
@@ -157,14 +161,28 @@ constexpr int STAT_N = 8;            // tf, es, es2, cnt, rmin, rmax, emin, emax
 constexpr int STAT_WAVES = 16;       // slots per workgroup in the partial buffer (max 1024 lanes)
 constexpr int SCRATCH_DOUBLES = 16 + STAT_WAVES * STAT_N;
 
+// (workgroups of the small transforms have fewer than 64 lanes: values shuffled in from lanes that do
+// not exist are ignored)
+__device__ __forceinline__ int wave_lanes() {
+    const int base = (int)threadIdx.x & ~63;
+    return min(64, (int)blockDim.x - base);
+}
 __device__ __forceinline__ double wave_min(double v) {
+    const int lane = threadIdx.x & 63, nl = wave_lanes();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(v, o, 64);
+        if (lane + o < nl) v = fmin(v, u);
+    }
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
+    const int lane = threadIdx.x & 63, nl = wave_lanes();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(v, o, 64);
+        if (lane + o < nl) v = fmax(v, u);
+    }
     return v;
 }
 

@@ -503,10 +503,12 @@ def test_in_pass_statistics_match_general_path_and_reference(name):
     assert h_dev.stats["method"] == h_gen.stats["method"]
 
 
-@pytest.mark.parametrize("name", ["holo_GS_A_f32", "holo_WGSKim_A_f32", "holo_GS_A_f64"])
+@pytest.mark.parametrize("name", ["holo_GS_A_f32", "holo_WGSKim_A_f32", "holo_GS_A_f64", "mraf_WGSLeonardo_mf0.5_zfNone",
+                                  "mraf_GS_mf0.5_zfNone"])
 def test_in_pass_statistics_dense_target(name):
-    """Dense image targets (every pixel in the mask), fp32 and fp64, small transforms (col_fused_kernel)."""
-    if name not in golden_names("holo_"):
+    """Dense image targets (every pixel in the mask), fp32 and fp64, small transforms (col_fused_kernel);
+    MRAF targets (NaN noise region excluded from the mask, two-pass weight update)."""
+    if name not in golden_names("holo_") + golden_names("mraf_"):
         pytest.skip("fixture not recorded")
     meta, gold = load_golden(name)
     h_dev, h_gen = Hologram(**hologram_inputs(meta)), Hologram(**hologram_inputs(meta))
