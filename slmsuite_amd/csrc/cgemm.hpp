@@ -94,32 +94,37 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kbeg + (kt + 1) * CG_BK);
         const float* L = cg_lds + buf * BUF;
-#pragma unroll
-        for (int kk = 0; kk < CG_BK / 2; ++kk) {
+        // operand fragments of k-pair kk+1 are fetched from LDS before the MFMAs of pair kk issue
+        float ar[2][2], ai[2][2], br[2][2], bi[2][2];
+        auto fetch = [&](int kk, int slot) {
             const int k = 2 * kk + kq;
             const float* row = L + k * 128;
-            float ar[2], ai[2], nai[2], br[2], bi[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c = cg_swz(k, wm * 64 + i * 32 + rr);
-                ar[i] = row[c];
-                ai[i] = row[PLANE + c];
-                nai[i] = -ai[i];
+                ar[slot][i] = row[c];
+                ai[slot][i] = row[PLANE + c];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = cg_swz(k, wn * 64 + j * 32 + rr);
-                br[j] = row[2 * PLANE + c];
-                bi[j] = row[3 * PLANE + c];
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c = cg_swz(k, wn * 64 + jj * 32 + rr);
+                br[slot][jj] = row[2 * PLANE + c];
+                bi[slot][jj] = row[3 * PLANE + c];
             }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < CG_BK / 2; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < CG_BK / 2) fetch(kk + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    cr[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i], br[j], cr[i][j], 0, 0, 0);
-                    ci[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i], bi[j], ci[i][j], 0, 0, 0);
-                    cr[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(nai[i], bi[j], cr[i][j], 0, 0, 0);
-                    ci[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[i], br[j], ci[i][j], 0, 0, 0);
+                for (int jj = 0; jj < 2; ++jj) {
+                    cr[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[cur][i], br[cur][jj], cr[i][jj], 0, 0, 0);
+                    ci[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[cur][i], bi[cur][jj], ci[i][jj], 0, 0, 0);
+                    cr[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[cur][i], bi[cur][jj], cr[i][jj], 0, 0, 0);
+                    ci[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[cur][i], br[cur][jj], ci[i][jj], 0, 0, 0);
                 }
         }
         if (kt + 1 < nk) lstore(buf ^ 1);

@@ -328,12 +328,19 @@ template <typename R> struct Engine : EngineBase {
     }
 
     // ---- separable / matrix-core form (compressed_sep.hpp) ----
+    // split-K factor: fill the 2 * n_cu resident workgroups of cgemm_kouter in whole rounds (a 128 x 128
+    // output grid rarely does by itself: 711 tiles = 1.39 rounds, 135 tiles = 0.26), smallest such split
     static void split_for(int tiles, int K, int n_cu, int* split, int* k_per) {
-        int sp = std::max(1, (4 * n_cu + tiles - 1) / tiles);
-        sp = std::min(sp, std::max(1, K / 256));
-        int kp = ((K + sp - 1) / sp + CG_BK - 1) / CG_BK * CG_BK;
-        sp = (K + kp - 1) / kp;
-        *split = sp;
+        const int slots = 2 * n_cu;
+        int best = 1;
+        double best_eff = 0;
+        for (int sp = 1; sp <= 32 && K / sp >= 128; ++sp) {
+            const int w = tiles * sp;
+            const double eff = (double)w / ((double)((w + slots - 1) / slots) * slots);
+            if (eff > best_eff + 0.08) { best_eff = eff; best = sp; }   // partial tiles cost traffic: need a real gain
+        }
+        int kp = ((K + best - 1) / best + CG_BK - 1) / CG_BK * CG_BK;
+        *split = (K + kp - 1) / kp;
         *k_per = kp;
     }
     int sep_refresh() {
