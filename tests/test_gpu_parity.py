@@ -651,3 +651,32 @@ def test_sparse_spot_feedback_matches_general_path(method, feedback, kw, monkeyp
         for nme in STAT_NAMES:
             np.testing.assert_allclose(a.stats["stats"][grp][nme][:6], b.stats["stats"][grp][nme][:6], rtol=3e-4, atol=1e-7,
                                        err_msg=f"{grp}.{nme}")
+
+
+def test_batch_with_different_sparse_targets_full_size():
+    """
+    cfg 3 slice with per-hologram targets: three spot patterns with different active columns share one
+    4096^2 engine (grid.y = hologram; per-hologram column lists and lane masks) and must match three
+    single engines; WGS-Kim crosses the phase-fixing iteration.
+    """
+    from slmsuite_amd.batch import HologramBatch
+    shape, slm = (4096, 4096), (1152, 1920)
+    singles, targets, phases = [], [], []
+    for i, (grid, pitch) in enumerate((((8, 8), (64, 64)), ((5, 12), (96, 40)), ((16, 3), (24, 200)))):
+        h = SpotHologram.make_rectangular_array(shape, grid, pitch, basis="knm", slm_shape=slm,
+                                                phase=synth.seed_phase(120 + i, slm))
+        targets.append(h.target.copy())
+        phases.append(synth.seed_phase(120 + i, slm))
+        h.optimize("WGS-Kim", maxiter=6, verbose=False, fix_phase_iteration=3)
+        singles.append(h)
+    hb = HologramBatch(shape, slm, np.stack(targets), np.stack(phases))
+    try:
+        hb.optimize("WGS-Kim", maxiter=6, fix_phase_iteration=3)
+        got = hb.phases()
+        w = hb.engine.get(L.WEIGHTS)
+    finally:
+        hb.close()
+    for i, h in enumerate(singles):
+        e = phase_rel_l2(got[i], h.phase)
+        report(f"batch of different sparse targets, hologram {i}", phase=e, weights=rel_l2(w[i], h.weights))
+        assert e < 1e-6 and rel_l2(w[i], h.weights) < 1e-6
