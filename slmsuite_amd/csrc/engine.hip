@@ -1100,10 +1100,7 @@ template <typename R> struct Engine : EngineBase {
                     sa.g = g; sa.n_spots = cfg.n_spots; sa.width = st->spot_window; sa.feedback = st->feedback;
                     sa.spot_xy = spot_xy; sa.amp_ff = aff; sa.ext_amp = ext_amp; sa.spot_amp = spot_amp; sa.w = w;
                     sa.fb = spot_fb; sa.cp = cp;
-                    if (st->feedback == HGS_FB_SPOT_WINDOW) {
-                        hipLaunchKernelGGL(spot_window<R>, dim3((cfg.n_spots + 127) / 128, B), dim3(128), 0, stream, sa);
-                        HIPCHK(hipGetLastError());
-                    }
+                    sa.inline_window = 1;
                     hipLaunchKernelGGL(spot_update<R>, dim3(B), dim3(256), 0, stream, sa);
                     HIPCHK(hipGetLastError());
                     return 0;

@@ -1217,13 +1217,18 @@ template <typename R> struct SpotArgs {
     R* w;                           // column-major weights (normalised storage)
     R* fb;                          // [batch][N] scratch: feedback amplitudes
     CParams<R> cp;
+    int inline_window;              // spot_update computes the window sums itself (one launch fewer)
 };
 
 // fb[n] = sqrt( sum_{w x w window at floor(v)} amp_ff^2 ) in float64 (analysis.take, quirk A18)
+template <typename R> __device__ __forceinline__ R spot_window_value(const SpotArgs<R>& a, int b, int n);
 template <typename R> __global__ void spot_window(SpotArgs<R> a) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= a.n_spots) return;
+    a.fb[(size_t)b * a.n_spots + n] = spot_window_value(a, b, n);
+}
+template <typename R> __device__ __forceinline__ R spot_window_value(const SpotArgs<R>& a, int b, int n) {
     const size_t P = (size_t)a.g.Ph * a.g.Pw;
     const int kx = a.spot_xy[n], ky = a.spot_xy[a.n_spots + n];
     const int lo = -((a.width - 1) / 2) - (((a.width - 1) & 1) ? 1 : 0);  // floor(-(w-1)/2)
@@ -1235,7 +1240,7 @@ template <typename R> __global__ void spot_window(SpotArgs<R> a) {
             const R v2 = v * v;  // cp.square in working precision, then astype(float) (:1592, take :202)
             s += (double)v2;
         }
-    a.fb[(size_t)b * a.n_spots + n] = (R)::sqrt(s);
+    return (R)::sqrt(s);
 }
 
 // One block per hologram: N-vector weight update with target = spot_amp, normalised as an N-vector
@@ -1246,6 +1251,10 @@ template <typename R> __global__ void spot_update(SpotArgs<R> a) {
     const int b = blockIdx.x;
     const size_t P = (size_t)a.g.Ph * a.g.Pw;
     const int N = a.n_spots;
+    if (a.feedback == 1 && a.inline_window) {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) a.fb[(size_t)b * N + n] = spot_window_value(a, b, n);
+        __syncthreads();    // every later read of fb[n] is by this workgroup
+    }
     // ||feedback||
     double acc = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
