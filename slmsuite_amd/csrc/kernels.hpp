@@ -30,6 +30,9 @@
 #ifndef HGS_TILE_DB
 #define HGS_TILE_DB false
 #endif
+#ifndef HGS_ROW_PHASOR
+#define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
+#endif
 #ifndef HGS_SPARSE_SKIP
 #define HGS_SPARSE_SKIP 1
 #endif
@@ -403,10 +406,18 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                 Cx<R> nf = mk<R>(0, 0);
                 if (valid && c >= 0 && c < g.Sw) {
                     const R amv = (am != nullptr) ? am[c] : a.amp_scalar;
-                    if constexpr (MODE == 2) {
+                    if constexpr (MODE == 2 && HGS_ROW_PHASOR) {
                         // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         nf = (p2 > (R)0) ? v[m] * (amv * M::rsqrt(p2)) : mk<R>(amv * sgn, 0);
+                    } else if constexpr (MODE == 2) {
+                        // the reference's own arithmetic: phase rounded to working precision, then exp(i phase)
+                        const R scs = sgn * a.scale;
+                        R p = M::atan2(v[m].y * scs, v[m].x * scs);
+                        if (kn != nullptr) { p -= kn[c]; p += kn[c]; }
+                        R s, co;
+                        M::sincos(p, &s, &co);
+                        nf = mk<R>(amv * sgn * co, amv * sgn * s);
                     } else {
                         R p = ph[c];
                         if (kn != nullptr) p += kn[c];
