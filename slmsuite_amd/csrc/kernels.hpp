@@ -244,6 +244,17 @@ template <typename R> struct StatAcc {
     }
 };
 
+// (|F| c / T)^-p for the Leonardo / Kim rule of the fused kernels, from |F|^2: the ratio is formed FIRST, so
+// the logarithm is taken of a number near 1 for a converging spot (log2 of the three factors separately
+// cancels ~20 against ~20 and leaves 1e-6 relative noise per update, ten times the reference's np.power).
+template <typename R> __device__ __forceinline__ R leonardo_factor(R p2, R t, R inv_fnorm, R p_exp) {
+    using M = Math<R>;
+    const R q = inv_fnorm / t;
+    const R r2 = p2 * q * q;                       // (|F| c / T)^2
+    if (!(r2 < (R)INFINITY)) return (R)1;          // overflow of the ratio (:1840) and NaN targets (:1843) -> 1
+    return M::exp2((R)-0.5 * p_exp * M::log2(r2));   // r2 = 0 -> inf: callers map it to 1 (:1867)
+}
+
 // ---- the WGS weight rule for one element (rows 9-10; _hologram.py:1830-1873) -------------------------
 //   fb  : feedback amplitude already divided by its L2 norm
 //   returns the multiplicative factor fc
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 const R t = tr[m];
                 if (cp.method == M_LEONARDO || cp.method == M_KIM) {
                     if (t != (R)0) {                       // T == 0 -> factor 1 (:1841)
-                        R fc = M::exp2(-cp.p_exp * ((R)0.5 * M::log2(p2) + cp.log2_inv_fnorm - M::log2(t)));
+                        R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
                         if (!(fc < (R)INFINITY)) fc = 1;   // inf (:1840,:1867) and nan (:1843) -> 1
                         wv *= fc;
                     }
@@ -949,7 +960,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     const R t = tr[m];
                     if (cp.method == M_LEONARDO || cp.method == M_KIM) {
                         if (t != (R)0) {
-                            R fc = M::exp2(-cp.p_exp * ((R)0.5 * M::log2(p2) + cp.log2_inv_fnorm - M::log2(t)));
+                            R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
                             if (!(fc < (R)INFINITY)) fc = 1;
                             wv *= fc;
                         }
