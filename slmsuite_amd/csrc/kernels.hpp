@@ -99,12 +99,36 @@ __device__ __forceinline__ void sincos_bounded(float x, float* s, float* c) {
     *c = ((n + 1) & 2) ? -cc : cc;
 }
 
+// sin/cos of a stored farfield phase (|x| <= ~pi for anything atan2 produced): the reduction by pi/2 in
+// fp32 with a two-term Cody-Waite constant is exact to 1e-7 up to |x| ~ 1e3; larger arguments (a
+// user-supplied phase_ff) take the fp64 reduction.  Same polynomials, no fp64 ops on the hot path.
+__device__ __forceinline__ void sincos_phase(float x, float* s, float* c) {
+    if (__builtin_amdgcn_ballot_w64(fabsf(x) > 1.0e3f) != 0) {   // wave-uniform, never taken for atan2 output
+        sincos_bounded(x, s, c);
+        return;
+    }
+    const float q = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-q, 1.5707963705062866f, x);            // pi/2 rounded to fp32 ...
+    r = fmaf(-q, -4.371138828673793e-8f, r);               // ... and its remainder
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                          z * z, fmaf(-0.5f, z, 1.0f));
+    const int n = (int)q;
+    const float ss = (n & 1) ? pc : ps;
+    const float cc = (n & 1) ? ps : pc;
+    *s = (n & 2) ? -ss : ss;
+    *c = ((n + 1) & 2) ? -cc : cc;
+}
+
 template <typename R> struct Math;
 template <> struct Math<float> {
+    static __device__ __forceinline__ void sincos_phase(float a, float* s, float* c) { hgs::sincos_phase(a, s, c); }
     static __device__ __forceinline__ void sincos(float a, float* s, float* c) { sincos_bounded(a, s, c); }
     static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float powneg(float x, float p) { return exp2f(-p * log2f(x)); }
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float log2(float x) { return log2f(x); }
@@ -114,9 +138,11 @@ template <> struct Math<float> {
 };
 template <> struct Math<double> {
     static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+    static __device__ __forceinline__ void sincos_phase(double a, double* s, double* c) { ::sincos(a, s, c); }
     static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double powneg(double x, double p) { return ::pow(x, -p); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
@@ -249,7 +275,7 @@ template <typename R> struct StatAcc {
 // cancels ~20 against ~20 and leaves 1e-6 relative noise per update, ten times the reference's np.power).
 template <typename R> __device__ __forceinline__ R leonardo_factor(R p2, R t, R inv_fnorm, R p_exp) {
     using M = Math<R>;
-    const R q = inv_fnorm / t;
+    const R q = inv_fnorm * Math<R>::rcp(t);       // 1-ulp reciprocal: the ratio is squared and logged anyway
     const R r2 = p2 * q * q;                       // (|F| c / T)^2
     if (!(r2 < (R)INFINITY)) return (R)1;          // overflow of the ratio (:1840) and NaN targets (:1843) -> 1
     return M::exp2((R)-0.5 * p_exp * M::log2(r2));   // r2 = 0 -> inf: callers map it to 1 (:1867)
@@ -741,6 +767,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         // ---- constraint + weight update on F = sc * v ----
         R* wc = a.w + cb;
         R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
+        bool w_changed = false;
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
             const unsigned idx = lane_pos<T>(j, m);
@@ -766,7 +793,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                     wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, (R)0);
                 }
                 if (is_nan(wv)) wv = (R)0.0001;            // :1873
-                if (wv != wraw) wc[idx] = wv;              // unchanged values (zeros of a sparse target) stay put
+                w_changed |= (wv != wraw);                 // stored after the loop; unchanged lanes (zeros of a
+                wr[m] = wv;                                // sparse target) write nothing
                 acc_w += wv * wv;
             }
             if constexpr (STATS) {
@@ -776,7 +804,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             }
             R co, si;
             if constexpr (PHASE == 2) {
-                M::sincos(pfc[idx], &si, &co);
+                M::sincos_phase(pfc[idx], &si, &co);
             } else {
                 if (p2 > (R)0) {                           // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
                     const R inv = M::rsqrt(p2);
@@ -803,6 +831,9 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         });
 
         if constexpr (STATS) sacc.flush(stat_slot);
+        if (cp.do_update && w_changed) {
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
+        }
         // ---- prefetch the next column while this one is transformed back ----
         if (q + 1 < ncols) {
             issue_wt(q + 1);
@@ -940,6 +971,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
             R* wc = a.w + cb;
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
+            bool w_changed = false;
+            // phase_ff of this lane's 16 pixels: 64 contiguous bytes, read (PHASE 2) / written (PHASE 1) as such
+            R pf[PHASE != 0 ? 16 : 1];
+            if constexpr (PHASE == 2)
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; pf[m] = pfc[lane_pos<T>(j, m)]; });
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 const unsigned idx = lane_pos<T>(j, m);
@@ -968,7 +1004,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                         wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, (R)0);
                     }
                     if (is_nan(wv)) wv = (R)0.0001;
-                    if (wv != wraw) wc[idx] = wv;
+                    w_changed |= (wv != wraw);                 // stored after the loop, 64 contiguous bytes per lane
+                    wr[m] = wv;
                     acc_w += wv * wv;
                 }
                 if constexpr (STATS) {
@@ -979,7 +1016,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 Cx<R> ph;
                 if constexpr (PHASE == 2) {
                     R sn, cs;
-                    M::sincos(pfc[idx], &sn, &cs);
+                    M::sincos_phase(pf[m], &sn, &cs);
                     ph = mk<R>(cs, sn);
                 } else {
                     if (p2 > (R)0) {
@@ -988,7 +1025,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     } else {
                         ph = mk<R>(1, 0);
                     }
-                    if constexpr (PHASE == 1) pfc[idx] = M::atan2(F.y, F.x);
+                    if constexpr (PHASE == 1) pf[m] = M::atan2(F.y, F.x);
                 }
                 // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
                 v[m] = cmulc(ph, om) * wv;
@@ -998,12 +1035,18 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                         v[m] = cmulc(cp.has_mraf_factor ? F * cp.mraf_factor : F, om);
                     } else if (t == (R)0) {                 // zero region (no zero_weights feedback on this path)
                         v[m] = mk<R>(0, 0);
-                        if constexpr (PHASE == 1) pfc[idx] = (R)0;   // atan2 of the zeroed field
+                        if constexpr (PHASE == 1) pf[m] = (R)0;      // atan2 of the zeroed field
                     }
                 }
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (STATS) sacc.flush(stat_slot);
+            // updated weights of this lane (unchanged lanes -- zeros of a sparse target -- write nothing)
+            if (cp.do_update && w_changed) {
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
+            }
+            if constexpr (PHASE == 1)
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; pfc[lane_pos<T>(j, m)] = pf[m]; });
             // weights/target of the next column (or of the first column of the next tile) land
             // under the inverse transform below and the next forward transform
             {
