@@ -485,8 +485,24 @@ class Hologram:
             run += 1
         return run
 
+    # the target is a plain host array; assigning it invalidates what was derived from it
+    @property
+    def target(self):
+        return self.__dict__.get("_target")
+
+    @target.setter
+    def target(self, value):
+        self.__dict__["_target"] = value
+        self.__dict__["_mraf_flag"] = None
+
     def _mraf_enabled(self):
-        return bool(np.isnan(np.sum(self.target)))          # _mraf_helper_routines :1498
+        """_mraf_helper_routines :1498: NaN anywhere in the target.  Evaluated once per assigned target (a
+        16.7 M-pixel host reduction costs more than forty fused iterations); in-place edits of ``target``
+        need ``set_target`` to reach the device anyway."""
+        flag = self.__dict__.get("_mraf_flag")
+        if flag is None:
+            flag = self.__dict__["_mraf_flag"] = bool(np.isnan(np.sum(self.target)))
+        return flag
 
     def _spot_window(self):
         return 3
