@@ -1172,11 +1172,20 @@ template <typename R> struct Engine : EngineBase {
         }
         auto col_sparse = [&](const Plan& p) {
             (void)p;   // phase_ff is stored (WGS-Kim) on the active columns only: nothing else can be read back
-            return sparse_enabled && !(stat_ctx && (stat_ctx->groups & 2));
+            return sparse_enabled;
         };
+        // "computational_spot" statistics on the sparse path: amp_ff is produced on the spot columns dilated
+        // by the integration window (col_kernel FWD|STORE over that list) before the fused kernel runs
+        const bool spot_stats = stat_ctx && (stat_ctx->groups & 2);
+        if (sparse_enabled && spot_stats) {
+            const int lo = (int)std::floor(-(stat_ctx->width - 1) / 2.0);
+            if (int e = refresh_dilated(lo, lo + stat_ctx->width - 1)) return e;
+            if (int e = need_ff()) return e;
+        }
+        const int store_sparse = spot_stats ? 2 : 1;
         Plan p = plan_iteration(st, hist ? hist : nullptr);
         bool sp = col_sparse(p);
-        if (int e = run_row(0, false, false, sp)) return e;
+        if (int e = run_row(0, false, 0, sp ? store_sparse : 0)) return e;
         for (int i = 0; i < n; ++i) {
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
             // MRAF with a weight update takes two passes over the columns: the rebuilt field mixes the
@@ -1185,6 +1194,16 @@ template <typename R> struct Engine : EngineBase {
             // then wscale = 1/||w'||; pass 1: forward transform again, rebuild, inverse.
             const bool two_pass = st->mraf_enabled && p.do_update;
             int r = 0;
+            if (sp && spot_stats) {
+                r = timed(HGS_K_COL_FWD, [&]() -> int {
+                    ColArgs<R> a = col_args();
+                    a.col_list = col_list_d;
+                    a.n_active = n_active_d_dev;
+                    LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(std::min(n_active_d_max, n_cu * 3), B), stream, a));
+                    return 0;
+                });
+                if (r) return r;
+            }
             for (int pass = 0; pass < (two_pass ? 2 : 1) && !r; ++pass) {
                 r = timed(HGS_K_COL_FUSED, [&]() -> int {
                     ColArgs<R> a = col_args();
@@ -1195,8 +1214,8 @@ template <typename R> struct Engine : EngineBase {
                         phase_mode = 0;
                     }
                     if (two_pass && pass == 1) a.cp.do_update = 0;
-                    if (stat_ctx && !(two_pass && pass == 1)) {
-                        a.do_stats = stat_ctx->groups;
+                    if (stat_ctx && !(two_pass && pass == 1) && (!sp || (stat_ctx->groups & 1))) {
+                        a.do_stats = sp ? (stat_ctx->groups & 1) : stat_ctx->groups;   // sparse: amp_ff already stored
                         a.spartial = stat_partial;
                         a.tsum = stat_tsum;
                         a.inv_fsum = 1.0 / amp_norm2;
@@ -1247,7 +1266,8 @@ template <typename R> struct Engine : EngineBase {
                 sp_next = col_sparse(pn);
             }
             // the row kernel that follows folds the weight-norm partials into wscale (unless already done)
-            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0 && !two_pass, sp, sp_next)) return e;
+            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0 && !two_pass, sp ? 1 : 0, sp_next ? store_sparse : 0))
+                return e;
             p = pn;
             sp = sp_next;
         }
