@@ -1571,13 +1571,16 @@ int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double*
     if (!children || !weights || n < 1) return hgs::fail(HGS_ERR_ARG, "multiplane: need at least one child and its weight");
     if (n > hgs::MP_MAX) return hgs::fail(HGS_ERR_UNSUPPORTED, "multiplane: at most %d children", hgs::MP_MAX);
     hgs::EngineBase::MpInfo info[hgs::MP_MAX];
-    for (int k = 0; k < n; ++k) {
+    for (int k = 0; k < n; ++k) {       // validate the whole family before touching any state
         if (!children[k] || !children[k]->impl) return hgs::fail(HGS_ERR_ARG, "multiplane: null child %d", k);
-        if (int r = children[k]->impl->f2n_complex()) return r;
         if (int r = children[k]->impl->mp_info(&info[k])) return r;
         if (info[k].S != info[0].S || info[k].B != info[0].B || info[k].real_bytes != info[0].real_bytes ||
             info[k].device != info[0].device)
             return hgs::fail(HGS_ERR_ARG, "multiplane: child %d differs in SLM shape, batch, precision or device", k);
+    }
+    for (int k = 0; k < n; ++k) {
+        if (int r = children[k]->impl->f2n_complex()) return r;
+        if (int r = children[k]->impl->mp_info(&info[k])) return r;     // the nearfield buffer exists now
     }
     // every child's inverse transform must have landed before child 0's stream reads them
     for (int k = 1; k < n; ++k)

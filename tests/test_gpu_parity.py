@@ -376,6 +376,36 @@ def test_errors_are_loud():
         h.optimize("not-a-method", maxiter=1, verbose=False)
     with pytest.raises(NotImplementedError):
         h.optimize("WGS-Leonardo", maxiter=2, verbose=False, feedback="experimental")
+    # C-ABI level: bad arguments come back as status codes with a message, never as a crash
+    e = Engine((64, 64), (32, 32))
+    try:
+        with pytest.raises(ValueError):
+            e.set(L.PHASE, np.zeros((3, 3), dtype=np.float32))               # wrong size
+        with pytest.raises(ValueError):
+            e.set_option(99, 1)                                              # unknown option
+        with pytest.raises(L.HgsError):
+            e.get(L.FARFIELD)                                                # nothing materialised yet
+        from slmsuite_amd.engine import make_step
+        st = make_step({"method": "WGS-Leonardo", "feedback": "computational", "feedback_exponent": 0.8}, 0)
+        with pytest.raises(L.HgsError):
+            e.iterate(st, 1)                                                 # no target yet
+        e.set(L.TARGET, synth.random_target(1, (64, 64)))
+        e.reset_weights()
+        e.set(L.PHASE, synth.seed_phase(1, (32, 32)))
+        with pytest.raises(ValueError):
+            e.iterate(st, -1)
+        with pytest.raises(L.HgsError):
+            e.iterate_stats(st, 2, ["computational_spot"])                   # spot statistics without spots
+        hist, stats = e.iterate_stats(st, 2, ["computational"])
+        assert len(hist) == 2 and 0 < stats[1]["computational"][0]["efficiency"] <= 1
+        other = Engine((128, 128), (48, 48))
+        try:
+            with pytest.raises(ValueError):
+                Engine.multiplane_farfield2nearfield([e, other], [1.0, 1.0])   # different SLM shapes
+        finally:
+            other.close()
+    finally:
+        e.close()
 
 
 # ---- BASELINE config 5: mixed-region-amplitude-freedom at 8192^2, fp32 vs fp64 --------------------------
