@@ -33,6 +33,10 @@ constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 16;
 
 __device__ __forceinline__ int cg_swz(int k, int c) { return c ^ ((k & 1) << 5); }
 
+// PADDED: the caller guarantees that every 16 x 128 tile the grid touches is addressable and that the
+// padding is zero (lda >= 128-multiple of M, ldb likewise, split * k_per rows) -- no bounds checks, 32-byte
+// loads.  The staging (global -> registers -> planar LDS) is 30 % of the kernel time otherwise.
+template <bool PADDED>
 __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cg_lds[];
     // buffer layout: [buf][plane (Ar, Ai, Br, Bi)][16][128]
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * CG_BM, n0 = blockIdx.y * CG_BN;
     const int s = blockIdx.z % a.split, b = blockIdx.z / a.split;
-    const int kbeg = s * a.k_per, kend = min(a.K, kbeg + a.k_per);
+    const int kbeg = s * a.k_per, kend = PADDED ? kbeg + a.k_per : min(a.K, kbeg + a.k_per);
     const float2* A = a.A + (size_t)b * a.strideA;
     const float2* B = a.B + (size_t)b * a.strideB;
 
@@ -50,6 +54,17 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
     float2 ra[8], rb[8];
     auto gload = [&](int k0) {
         const int k = k0 + sk;
+        if constexpr (PADDED) {
+            const float4* pa = reinterpret_cast<const float4*>(A + (size_t)k * a.lda + m0 + sc);
+            const float4* pb = reinterpret_cast<const float4*>(B + (size_t)k * a.ldb + n0 + sc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 va = pa[i], vb = pb[i];
+                ra[2 * i] = make_float2(va.x, va.y); ra[2 * i + 1] = make_float2(va.z, va.w);
+                rb[2 * i] = make_float2(vb.x, vb.y); rb[2 * i + 1] = make_float2(vb.z, vb.w);
+            }
+            return;
+        }
         const bool kin = k < kend;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -92,7 +107,10 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * CG_BK);
+#ifndef CG_ABL
+#define CG_ABL 0     // microbenchmark ablations: 1 = no global loads / LDS stores in the loop, 2 = also no barrier
+#endif
+        if (CG_ABL == 0 && kt + 1 < nk) gload(kbeg + (kt + 1) * CG_BK);
         const float* L = cg_lds + buf * BUF;
         // operand fragments of k-pair kk+1 are fetched from LDS before the MFMAs of pair kk issue
         float ar[2][2], ai[2][2], br[2][2], bi[2][2];
@@ -127,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
                     ci[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[cur][i], br[cur][jj], ci[i][jj], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+        if (CG_ABL == 0 && kt + 1 < nk) lstore(buf ^ 1);
+        if (CG_ABL < 2) __syncthreads();
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

@@ -149,6 +149,7 @@ template <typename R> struct Engine : EngineBase {
     float2* sep_c2 = nullptr;       // [B][split2][H][W]
     double* sep_norm = nullptr;     // [B][ceil(N/4)]
     int sep_split1 = 1, sep_kper1 = 0, sep_split2 = 1, sep_kper2 = 0, sep_degx = 0, sep_degy = 0;
+    int sep_Np = 0, sep_Hp = 0, sep_Wp = 0, sep_Wk = 0, sep_Nk = 0;   // padded leading dimensions / row counts
     std::vector<int32_t> mono_host;
     std::vector<R> coeff_host;
     bool has_grid[2] = {false, false}, has_mono = false, has_coeff = false;
@@ -362,20 +363,30 @@ template <typename R> struct Engine : EngineBase {
             for (int n = 0; n < N; ++n) dst[n] += (double)coeff_host[(size_t)m * N + n];
         }
         if (!sep_c) {
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c), c.size() * sizeof(double)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_g), (size_t)(W + H) * sizeof(double)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_ex), (size_t)N * W * sizeof(float2)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_exT), (size_t)N * W * sizeof(float2)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_ey), (size_t)N * H * sizeof(float2)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_nfT), (size_t)B * W * H * sizeof(float2)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_b2), (size_t)B * N * H * sizeof(float2)));
+            // operands of the matrix-core GEMM are padded to whole tiles (zero filled once, never rewritten)
+            auto up = [](int v, int q) { return (v + q - 1) / q * q; };
             split_for(((N + CG_BM - 1) / CG_BM) * ((H + CG_BN - 1) / CG_BN), W, n_cu, &sep_split1, &sep_kper1);
             split_for(((H + CG_BM - 1) / CG_BM) * ((W + CG_BN - 1) / CG_BN), N, n_cu, &sep_split2, &sep_kper2);
+            sep_Np = up(N, CG_BM); sep_Hp = up(H, CG_BN); sep_Wp = up(W, CG_BN);
+            sep_Wk = sep_split1 * sep_kper1;
+            sep_Nk = sep_split2 * sep_kper2;
+            auto zalloc = [&](float2** p, size_t n) -> int {
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(float2)));
+                HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(float2), stream));
+                return 0;
+            };
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c), c.size() * sizeof(double)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_g), (size_t)(W + H) * sizeof(double)));
+            if (zalloc(&sep_ex, (size_t)sep_Nk * sep_Wp)) return HGS_ERR_DEVICE;       // [Nk][Wp]  (B of the f2n GEMM)
+            if (zalloc(&sep_exT, (size_t)sep_Wk * sep_Np)) return HGS_ERR_DEVICE;      // [Wk][Np]  (A of the n2f GEMM)
+            if (zalloc(&sep_ey, (size_t)N * H)) return HGS_ERR_DEVICE;
+            if (zalloc(&sep_nfT, (size_t)B * sep_Wk * sep_Hp)) return HGS_ERR_DEVICE;  // [B][Wk][Hp]
+            if (zalloc(&sep_b2, (size_t)B * sep_Nk * sep_Hp)) return HGS_ERR_DEVICE;   // [B][Nk][Hp]
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c1), (size_t)B * sep_split1 * N * H * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c2), (size_t)B * sep_split2 * H * W * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_norm), (size_t)B * ((N + 3) / 4) * sizeof(double)));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_kouter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)CG_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_kouter<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES));
         }
         HIPCHK(hipMemcpyAsync(sep_c, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(sep_g, xs_host.data(), (size_t)W * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -383,11 +394,11 @@ template <typename R> struct Engine : EngineBase {
         sep_degx = dx;
         sep_degy = dy;
         hipLaunchKernelGGL(sep_build_table, dim3((W + 255) / 256, N), dim3(256), 0, stream, (const double*)sep_c, dx, N,
-                           (const double*)sep_g, W, sep_ex, sep_exT);
+                           (const double*)sep_g, W, sep_ex, sep_Wp, sep_exT, sep_Np);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(sep_build_table, dim3((H + 255) / 256, N), dim3(256), 0, stream,
                            (const double*)(sep_c + (size_t)(SEP_MAXDEG + 1) * N), dy, N, (const double*)(sep_g + W), H, sep_ey,
-                           (float2*)nullptr);
+                           H, (float2*)nullptr, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));   // c / xs_host are host temporaries
         c_sep = true;
@@ -399,7 +410,7 @@ template <typename R> struct Engine : EngineBase {
     int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int K, int lda, int ldb, int split, int k_per,
                      size_t strideA, size_t strideB) {
         CgemmArgs a{A, Bm, C, M, N, K, lda, ldb, split, k_per, strideA, strideB};
-        hipLaunchKernelGGL(cgemm_kouter, dim3((M + CG_BM - 1) / CG_BM, (N + CG_BN - 1) / CG_BN, split * B), dim3(256),
+        hipLaunchKernelGGL(cgemm_kouter<true>, dim3((M + CG_BM - 1) / CG_BM, (N + CG_BN - 1) / CG_BN, split * B), dim3(256),
                            CG_LDS_BYTES, stream, a);
         HIPCHK(hipGetLastError());
         return 0;
@@ -409,9 +420,10 @@ template <typename R> struct Engine : EngineBase {
         const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
         hipLaunchKernelGGL(sep_build_nft<R>, dim3((W + 31) / 32, (H + 31) / 32, B), dim3(32, 8), 0, stream, (const R*)phase,
                            has_amp ? (const R*)amp : (const R*)nullptr, has_kern ? (const R*)kern : (const R*)nullptr,
-                           (R)amp_scalar, H, W, sep_nfT);
+                           (R)amp_scalar, H, W, sep_nfT, sep_Hp, (size_t)sep_Wk * sep_Hp);
         HIPCHK(hipGetLastError());
-        if (int e = launch_cgemm(sep_exT, sep_nfT, sep_c1, N, H, W, N, H, sep_split1, sep_kper1, 0, (size_t)W * H)) return e;
+        if (int e = launch_cgemm(sep_exT, sep_nfT, sep_c1, N, H, W, sep_Np, sep_Hp, sep_split1, sep_kper1, 0,
+                                 (size_t)sep_Wk * sep_Hp)) return e;
         const int nred = (N + 3) / 4;
         hipLaunchKernelGGL(sep_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_split1,
                            (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
@@ -424,9 +436,10 @@ template <typename R> struct Engine : EngineBase {
     int sep_f2n(Cx<R>* nf_out) {
         const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
         hipLaunchKernelGGL(sep_build_b2<R>, dim3((H + 255) / 256, N, B), dim3(256), 0, stream, (const Cx<R>*)ff,
-                           (const float2*)sep_ey, N, H, sep_b2);
+                           (const float2*)sep_ey, N, H, sep_b2, sep_Hp, (size_t)sep_Nk * sep_Hp);
         HIPCHK(hipGetLastError());
-        if (int e = launch_cgemm(sep_b2, sep_ex, sep_c2, H, W, N, H, W, sep_split2, sep_kper2, (size_t)N * H, 0)) return e;
+        if (int e = launch_cgemm(sep_b2, sep_ex, sep_c2, H, W, N, sep_Hp, sep_Wp, sep_split2, sep_kper2,
+                                 (size_t)sep_Nk * sep_Hp, 0)) return e;
         hipLaunchKernelGGL(sep_f2n_finish<R>, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, (const float2*)sep_c2,
                            sep_split2, S, has_kern ? (const R*)kern : (const R*)nullptr, phase, nf_out);
         HIPCHK(hipGetLastError());
