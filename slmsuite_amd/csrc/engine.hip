@@ -105,6 +105,7 @@ template <typename R> struct Engine : EngineBase {
     double* ext_amp = nullptr;
     R* spot_fb = nullptr;
     C* nfbuf = nullptr;               // [B][Sh][Sw] complex nearfield of f2n_complex (MultiplaneHologram)
+    R* nog_dev = nullptr;             // [B] -1/mean(fc) of the fused WGS-Nogrette pass
     // sparse targets (spot arrays): columns that hold a non-zero weight or target
     unsigned char* col_active = nullptr;   // [B][Pw]
     int* col_list = nullptr;               // [B][Pw] compacted
@@ -169,7 +170,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -1063,8 +1064,7 @@ template <typename R> struct Engine : EngineBase {
 
     bool fused_ok(const hgs_step* st) const {
         // MRAF rides the fused kernels unless the zero region carries zero_weights feedback (:1613-1616)
-        return cfg.kind == 0 && !(st->mraf_enabled && st->zero_mode) && st->feedback == HGS_FB_PIXEL &&
-               st->method != HGS_WGS_NOGRETTE;
+        return cfg.kind == 0 && !(st->mraf_enabled && st->zero_mode) && st->feedback == HGS_FB_PIXEL;
     }
 
     // ---- spot feedback on sparse targets ("computational_spot" / "external_spot", _spots.py:1573-1624) ----
@@ -1206,6 +1206,10 @@ template <typename R> struct Engine : EngineBase {
             // to be known first.  Pass 0: forward transform + weight update (+ statistics), no inverse;
             // then wscale = 1/||w'||; pass 1: forward transform again, rebuild, inverse.
             const bool two_pass = st->mraf_enabled && p.do_update;
+            // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
+            // one more forward-only pass that just accumulates it
+            const bool nog = st->method == HGS_WGS_NOGRETTE && p.do_update;
+            if (nog && !nog_dev) { if (dalloc(&nog_dev, (size_t)B)) return HGS_ERR_DEVICE; }
             int r = 0;
             if (sp && spot_stats) {
                 r = timed(HGS_K_COL_FWD, [&]() -> int {
@@ -1217,17 +1221,24 @@ template <typename R> struct Engine : EngineBase {
                 });
                 if (r) return r;
             }
-            for (int pass = 0; pass < (two_pass ? 2 : 1) && !r; ++pass) {
+            for (int pass = nog ? -1 : 0; pass < (two_pass ? 2 : 1) && !r; ++pass) {
                 r = timed(HGS_K_COL_FUSED, [&]() -> int {
                     ColArgs<R> a = col_args();
                     a.cp = cparams(st, p);
                     int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
+                    if (pass == -1) {                 // Nogrette: sum of fc only
+                        a.cp.nog_pass = 1;
+                        a.cp.weights_only = 1;
+                        phase_mode = 0;
+                    } else if (nog) {
+                        a.cp.nog = nog_dev;
+                    }
                     if (two_pass && pass == 0) {
                         a.cp.weights_only = 1;
                         phase_mode = 0;
                     }
                     if (two_pass && pass == 1) a.cp.do_update = 0;
-                    if (stat_ctx && !(two_pass && pass == 1) && (!sp || (stat_ctx->groups & 1))) {
+                    if (stat_ctx && pass == 0 && (!sp || (stat_ctx->groups & 1))) {
                         a.do_stats = sp ? (stat_ctx->groups & 1) : stat_ctx->groups;   // sparse: amp_ff already stored
                         a.spartial = stat_partial;
                         a.tsum = stat_tsum;
@@ -1256,6 +1267,12 @@ template <typename R> struct Engine : EngineBase {
                     } else {
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
                         else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                    }
+                    if (pass == -1) {
+                        if (int e = reduce(wpartial, wpartial_n, sums + 1 * B)) return e;
+                        hipLaunchKernelGGL(nog_finalize<R>, dim3((B + 63) / 64), dim3(64), 0, stream, (const double*)(sums + 1 * B),
+                                           sp ? (const int*)n_active_dev : (const int*)nullptr, g.Ph, g.Pw, nog_dev, B);
+                        HIPCHK(hipGetLastError());
                     }
                     if (two_pass && pass == 0) {
                         if (int e = reduce(wpartial, wpartial_n, sums + 2 * B)) return e;

@@ -72,6 +72,8 @@ template <typename R> struct CParams {
     int mraf;         // target holds NaN (noise) / 0 (zero) regions (:1606-1653)
     int has_mraf_factor;
     int zero_mode;    // 0: zero region := 0 ; 1: zero_weights feedback (:1613-1616)
+    int nog_pass;     // fused kernels: only accumulate sum(fc) of the Nogrette rule (nanmean, :1851) into wpartial
+    const R* nog;     // [batch] -1/mean(fc) from that pass (WGS-Nogrette), else nullptr
     int weights_only; // fused kernels: forward transform + weight update (+ statistics) only, no inverse.
                       // MRAF mixes the normalised weights with the un-weighted noise region, so ||w'|| must
                       // be known before the field is rebuilt: pass 1 updates the weights, pass 2 rebuilds.
@@ -284,6 +286,14 @@ template <typename R> __device__ __forceinline__ R leonardo_factor(R p2, R t, R 
 // ---- the WGS weight rule for one element (rows 9-10; _hologram.py:1830-1873) -------------------------
 //   fb  : feedback amplitude already divided by its L2 norm
 //   returns the multiplicative factor fc
+// fc = feedback / target of the multiplicative rules with its fix-ups (:1837-1843)
+template <typename R> __device__ __forceinline__ R nogrette_fc(R fb, R t) {
+    R fc = fb / t;
+    if (is_pinf(fc)) fc = 1;
+    if (t == (R)0) fc = 1;
+    if (is_nan(fc)) fc = 1;
+    return fc;
+}
 template <typename R>
 __device__ __forceinline__ R weight_factor(int method, R fb, R t, R p_exp, R p_fac, R nog_neg_inv_mean) {
     using M = Math<R>;
@@ -706,6 +716,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const int ncols = listed ? ((int)blockIdx.x < n_act ? (n_act - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
                              : my_tiles * PASSES;
     R acc_w = 0;
+    const R nogv = cp.nog != nullptr ? cp.nog[b] : (R)0;
     double* stat_slot = scratch + 16 + (tid >> 6) * STAT_N;
     StatAcc<R> sacc;
     double stat_at = 0;
@@ -775,10 +786,16 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
                 __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS || cp.mraf) && tr[m] != (R)0)) == 0) {
                 v[m] = mk<R>(0, 0);
+                if (cp.nog_pass) acc_w += (R)1;              // T == 0 -> fc = 1 (:1841)
                 return;
             }
             const Cx<R> F = v[m] * sc;
             const R p2 = F.x * F.x + F.y * F.y;
+            if (cp.nog_pass) {                              // Nogrette: sum of fc = feedback / target over all pixels
+                acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
+                v[m] = mk<R>(0, 0);
+                return;
+            }
             const R wraw = wr[m];
             R wv = wraw * wsc;
             if (cp.do_update) {
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                         wv *= fc;
                     }
                 } else {
-                    wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, (R)0);
+                    wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, nogv);
                 }
                 if (is_nan(wv)) wv = (R)0.0001;            // :1873
                 w_changed |= (wv != wraw);                 // stored after the loop; unchanged lanes (zeros of a
@@ -922,6 +939,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     R wr[16], tr[16];
 
     const bool upd = cp.do_update != 0 || STATS || cp.mraf != 0;   // target needed by the update, the statistics, MRAF
+    const R nogv = cp.nog != nullptr ? cp.nog[b] : (R)0;
     double* stat_slot = scratch + 16 + (j >> 6) * STAT_N;
     StatAcc<R> sacc;
     double stat_at = 0;
@@ -986,10 +1004,16 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
                     __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
                     v[m] = mk<R>(0, 0);
+                    if (cp.nog_pass) acc_w += (R)1;          // T == 0 -> fc = 1 (:1841)
                     return;
                 }
                 const Cx<R> F = cmul(v[m], om);
                 const R p2 = F.x * F.x + F.y * F.y;
+                if (cp.nog_pass) {                          // Nogrette: sum of fc = feedback / target over all pixels
+                    acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
+                    v[m] = mk<R>(0, 0);
+                    return;
+                }
                 const R wraw = wr[m];
                 R wv = wraw * wsc;
                 if (cp.do_update) {
@@ -1001,7 +1025,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                             wv *= fc;
                         }
                     } else {
-                        wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, (R)0);
+                        wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, nogv);
                     }
                     if (is_nan(wv)) wv = (R)0.0001;
                     w_changed |= (wv != wraw);                 // stored after the loop, 64 contiguous bytes per lane
@@ -1642,6 +1666,16 @@ static __global__ void compact_active_cols(const unsigned char* active, int Pw, 
         for (int m = 0; m < 16; ++m) m16 |= (unsigned)(active[(size_t)b * Pw + j + m * T] != 0) << m;
         lane_mask[(size_t)b * T + j] = (unsigned short)m16;
     }
+}
+
+// WGS-Nogrette on the fused path: nog[b] = -1 / nanmean(fc) from the column kernel's partial sums; columns the
+// sparse path did not visit hold T = 0 everywhere, i.e. fc = 1 per pixel.
+template <typename R>
+__global__ void nog_finalize(const double* sum, const int* n_active, int Ph, int Pw, R* nog, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double skipped = n_active != nullptr ? (double)(Pw - n_active[b]) * (double)Ph : 0.0;
+    nog[b] = (R)(-(1.0 / ((sum[b] + skipped) / ((double)Ph * (double)Pw))));
 }
 
 }  // namespace hgs

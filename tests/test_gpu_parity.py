@@ -123,7 +123,7 @@ def step_pairs(gold):
     return [k for k in sorted(have_p) if (k + 1) in have_p and k in have_w]
 
 
-@pytest.mark.parametrize("mode", ["fused", "stepwise"])
+@pytest.mark.parametrize("mode", ["fused", "fused+stats", "stepwise"])
 @pytest.mark.parametrize("name", golden_names("holo_"))
 def test_single_step_matches_reference(name, mode):
     meta, gold = load_golden(name)
@@ -134,7 +134,10 @@ def test_single_step_matches_reference(name, mode):
     for k in pairs:
         h = forced_hologram(meta, gold, k)
         kw = dict(meta["kwargs"])
-        if mode == "stepwise":
+        if mode == "stepwise":      # a callback keeps the loop on the general (materialising) operators
+            h.optimize(meta["method"], maxiter=1, verbose=False, stat_groups=["computational"],
+                       callback=lambda hh: False, **kw)
+        elif mode == "fused+stats":   # device-resident loop with the statistics accumulated in the pass
             h.optimize(meta["method"], maxiter=1, verbose=False, stat_groups=["computational"], **kw)
         else:
             h.optimize(meta["method"], maxiter=1, verbose=False, **kw)
@@ -191,12 +194,15 @@ def test_trajectory_matches_reference(name):
     assert phase_rel_l2(h2.phase, gold["final_phase"]) < tol
 
 
+@pytest.mark.parametrize("mode", ["fused", "stepwise"])
 @pytest.mark.parametrize("name", golden_names("mraf_"))
-def test_mraf_single_steps(name):
-    """MRAF (NaN noise region, zero region, mraf_factor, zero_factor) through the general path."""
+def test_mraf_single_steps(name, mode):
+    """MRAF (NaN noise region, zero region, mraf_factor, zero_factor): the fused kernels (zero_factor forces the
+    general operators) and the general path (callback) against the recorded steps."""
     meta, gold = load_golden(name)
+    cb = (lambda hh: False) if mode == "stepwise" else None
     h = Hologram(**hologram_inputs(meta))
-    h.optimize(meta["method"], maxiter=1, verbose=False, **meta["kwargs"])
+    h.optimize(meta["method"], maxiter=1, verbose=False, callback=cb, **meta["kwargs"])
     assert phase_rel_l2(h.phase, gold["phase_1"]) < 5e-6
     # teacher-forced 2 -> 3 is not recorded (no phase_3); check 1 -> 2 from the recorded state
     h = Hologram(**hologram_inputs(meta))
@@ -205,10 +211,14 @@ def test_mraf_single_steps(name):
     h.stats["flags"]["fixed_phase"] = [False]
     h.stats["method"] = [meta["method"]]
     if "zero_factor" not in meta["kwargs"]:       # zero_weights state is not part of the snapshot
-        h.optimize(meta["method"], maxiter=1, verbose=False, **meta["kwargs"])
+        h.optimize(meta["method"], maxiter=1, verbose=False, callback=cb, **meta["kwargs"])
+        ep = phase_rel_l2(h.phase, gold["phase_2"])
+        ew = rel_l2(h.weights, gold["weights_2"]) if "weights_2" in gold else 0.0
+        report(f"mraf step 1->2 {name} {mode}", phase=ep, weights=ew)
         if meta["method"] == "GS":
-            assert phase_rel_l2(h.phase, gold["phase_2"]) < 5e-6
-            assert rel_l2(h.weights, gold["weights_2"]) < 3e-6
+            assert ep < 5e-6 and ew < 3e-6
+        else:       # pixel-wise WGS inside the signal region divides by speckle amplitudes
+            assert ep < 2e-3 and ew < 1e-3
 
 
 @pytest.mark.parametrize("name", golden_names("spot_"))
