@@ -1177,16 +1177,13 @@ template <typename R> struct Engine : EngineBase {
         farfield_valid = false;
         // Sparse targets: when few columns hold a non-zero weight/target, only those columns are
         // transformed (col_fused_kernel with a column list) and only they cross HBM between the two
-        // kernels.  Iterations that must produce phase_ff or amp_ff of every pixel run dense.
+        // kernels.  phase_ff (WGS-Kim) is then stored on the active columns only: nothing else can be
+        // read back by the loop.
         bool sparse_enabled = false;
         if (env_int("HGS_SPARSE", opt_sparse) && g.Ph >= 4096 && !env_int("HGS_OLD_FUSED", 0)) {
             if (int e = refresh_sparse()) return e;
             sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
         }
-        auto col_sparse = [&](const Plan& p) {
-            (void)p;   // phase_ff is stored (WGS-Kim) on the active columns only: nothing else can be read back
-            return sparse_enabled;
-        };
         // "computational_spot" statistics on the sparse path: amp_ff is produced on the spot columns dilated
         // by the integration window (col_kernel FWD|STORE over that list) before the fused kernel runs
         const bool spot_stats = stat_ctx && (stat_ctx->groups & 2);
@@ -1197,7 +1194,7 @@ template <typename R> struct Engine : EngineBase {
         }
         const int store_sparse = spot_stats ? 2 : 1;
         Plan p = plan_iteration(st, hist ? hist : nullptr);
-        bool sp = col_sparse(p);
+        const bool sp = sparse_enabled;
         if (int e = run_row(0, false, 0, sp ? store_sparse : 0)) return e;
         for (int i = 0; i < n; ++i) {
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
@@ -1288,18 +1285,13 @@ template <typename R> struct Engine : EngineBase {
             if (p.store_phase) have_pff = true;
             if (p.do_update) w_pending = true;
             st->iter++;
-            // the next iteration's plan decides which columns this row kernel must produce
             Plan pn{0, 0, 0};
-            bool sp_next = false;
-            if (i + 1 < n) {
-                pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
-                sp_next = col_sparse(pn);
-            }
-            // the row kernel that follows folds the weight-norm partials into wscale (unless already done)
-            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0 && !two_pass, sp ? 1 : 0, sp_next ? store_sparse : 0))
+            if (i + 1 < n) pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
+            // the row kernel that follows folds the weight-norm partials into wscale (unless already done);
+            // on the sparse path it reads the active columns and writes those the next column launches read
+            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0 && !two_pass, sp ? 1 : 0, sp ? store_sparse : 0))
                 return e;
             p = pn;
-            sp = sp_next;
         }
         return 0;
     }
