@@ -39,6 +39,7 @@ WORKLOADS = {
     # name: (padded shape, slm shape, spot grid, pitch)
     "cfg2": ((4096, 4096), (1152, 1920), (32, 32), (64, 64)),
     "small": ((1024, 1024), (288, 480), (16, 16), (32, 32)),
+    "hd": ((2048, 2048), (1080, 1920), (16, 16), (64, 64)),        # a 1920x1080 SLM at padding_order = 1
     "cfg5pad": ((8192, 8192), (1152, 1920), (32, 32), (128, 128)),
 }
 

@@ -817,6 +817,12 @@ template <typename R> struct Engine : EngineBase {
         dil_lo = lo; dil_hi = hi; dil_valid = true;
         return 0;
     }
+    // columns a workgroup pass of the column kernels handles side by side (ColCfg<N>::CPAR)
+    int col_cpar() const {
+        const int T = g.Ph / 16;
+        return T >= 256 ? 1 : std::min(4, 256 / T);
+    }
+    int list_blocks(int n_list) const { return std::max(1, std::min((n_list + col_cpar() - 1) / col_cpar(), n_cu * 3)); }
     // (re)build the active-column list when weights or target changed since the last scan
     int refresh_sparse() {
         if (!sparse_dirty) return 0;
@@ -1075,7 +1081,7 @@ template <typename R> struct Engine : EngineBase {
     // off).  Everything else of the farfield is exactly zero and is neither computed nor moved.
     bool spot_sparse_ok(const hgs_step* st) {
         if (cfg.kind != 0 || st->mraf_enabled || st->method == HGS_GS || st->feedback == HGS_FB_PIXEL) return false;
-        if (!env_int("HGS_SPARSE", opt_sparse) || g.Ph < 4096 || env_int("HGS_FORCE_STEPWISE", 0)) return false;
+        if (!env_int("HGS_SPARSE", opt_sparse) || env_int("HGS_FORCE_STEPWISE", 0)) return false;
         if (refresh_sparse()) return false;
         return n_active_min > 0 && n_active_max * 4 <= g.Pw;
     }
@@ -1086,7 +1092,9 @@ template <typename R> struct Engine : EngineBase {
         auto window = [](int w, int* lo, int* hi) { *lo = (int)std::floor(-(w - 1) / 2.0); *hi = *lo + w - 1; };
         int lo = 0, hi = 0, l2, h2;
         if (st->feedback == HGS_FB_SPOT_WINDOW) window(st->spot_window, &lo, &hi);
-        if (groups & 2) { window(stat_ctx->width, &l2, &h2); lo = std::min(lo, l2); hi = std::max(hi, h2); }
+        // the statistics windows sit at floor(spot_knm) (analysis.take, quirk A18), the weights at rint(spot_knm):
+        // one more column to the left
+        if (groups & 2) { window(stat_ctx->width, &l2, &h2); lo = std::min(lo, l2 - 1); hi = std::max(hi, h2); }
         if (int e = refresh_dilated(lo, hi)) return e;
         auto windows_needed = [&](const Plan& q) {
             return (st->feedback == HGS_FB_SPOT_WINDOW && q.do_update) || (groups & 2);
@@ -1102,7 +1110,7 @@ template <typename R> struct Engine : EngineBase {
                     ColArgs<R> a = col_args();
                     a.col_list = col_list_d;
                     a.n_active = n_active_d_dev;
-                    LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(std::min(n_active_d_max, n_cu * 3), B), stream, a));
+                    LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(list_blocks(n_active_d_max), B), stream, a));
                     return 0;
                 });
                 if (r) return r;
@@ -1126,7 +1134,7 @@ template <typename R> struct Engine : EngineBase {
                 a.cp.do_update = 0;                          // the weights were updated above
                 a.col_list = col_list;
                 a.n_active = n_active_dev;
-                const int blocks = std::min(n_active_max, n_cu * 3);
+                const int blocks = list_blocks(n_active_max);
                 wpartial_n = blocks;
                 const int phase_mode = p.use_fixed ? 2 : (p.store_phase ? 1 : 0);
                 if (groups & 1) {
@@ -1180,7 +1188,7 @@ template <typename R> struct Engine : EngineBase {
         // kernels.  phase_ff (WGS-Kim) is then stored on the active columns only: nothing else can be
         // read back by the loop.
         bool sparse_enabled = false;
-        if (env_int("HGS_SPARSE", opt_sparse) && g.Ph >= 4096 && !env_int("HGS_OLD_FUSED", 0)) {
+        if (env_int("HGS_SPARSE", opt_sparse) && !env_int("HGS_OLD_FUSED", 0)) {
             if (int e = refresh_sparse()) return e;
             sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
         }
@@ -1188,8 +1196,10 @@ template <typename R> struct Engine : EngineBase {
         // by the integration window (col_kernel FWD|STORE over that list) before the fused kernel runs
         const bool spot_stats = stat_ctx && (stat_ctx->groups & 2);
         if (sparse_enabled && spot_stats) {
+            // windows sit at floor(spot_knm) (analysis.take, quirk A18), the weights at rint(spot_knm): one more
+            // column to the left
             const int lo = (int)std::floor(-(stat_ctx->width - 1) / 2.0);
-            if (int e = refresh_dilated(lo, lo + stat_ctx->width - 1)) return e;
+            if (int e = refresh_dilated(lo - 1, lo + stat_ctx->width - 1)) return e;
             if (int e = need_ff()) return e;
         }
         const int store_sparse = spot_stats ? 2 : 1;
@@ -1213,7 +1223,7 @@ template <typename R> struct Engine : EngineBase {
                     ColArgs<R> a = col_args();
                     a.col_list = col_list_d;
                     a.n_active = n_active_d_dev;
-                    LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(std::min(n_active_d_max, n_cu * 3), B), stream, a));
+                    LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(list_blocks(n_active_d_max), B), stream, a));
                     return 0;
                 });
                 if (r) return r;
@@ -1251,7 +1261,7 @@ template <typename R> struct Engine : EngineBase {
                     if (sp) {
                         a.col_list = col_list;
                         a.n_active = n_active_dev;
-                        const int blocks = std::min(n_active_max, n_cu * 3);
+                        const int blocks = list_blocks(n_active_max);
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                         else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));

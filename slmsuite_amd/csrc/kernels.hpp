@@ -557,20 +557,24 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
     double acc_w = 0, acc_f = 0;
     const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
 
-    // column schedule: tiles of 4 columns strided over the grid, or (col_list != nullptr, CPAR == 1)
+    // column schedule: tiles of 4 columns strided over the grid, or (col_list != nullptr)
     // just the listed columns -- sparse targets, see ColArgs::col_list
     const bool listed = a.col_list != nullptr;
     const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
     const int n_act = listed ? a.n_active[b] : 0;
     const int ntiles = g.Pw / 4;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nq = listed ? ((int)blockIdx.x < n_act ? (n_act - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
+    const int n_grp = (n_act + CPAR - 1) / CPAR;
+    const int nq = listed ? ((int)blockIdx.x < n_grp ? (n_grp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
                           : my_tiles * PASSES;
 #pragma unroll 1
     for (int q = 0; q < nq; ++q) {
         int ct, c4;
+        bool vcol = true;        // a lane group past the end of the list runs on zeros and stores nothing
         if (listed) {
-            const int col = clist[blockIdx.x + q * gridDim.x];
+            const int e = ((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar;
+            vcol = e < n_act;
+            const int col = clist[min(e, n_act - 1)];
             ct = col >> 2;
             c4 = col & 3;
         } else {
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                     constexpr int m = m_;
                     const int r = r_lane + m * T;
                     Cx<R> x = mk<R>(0, 0);
-                    if (r >= 0 && r < g.Sh) x = gh[(unsigned)r * 4u + (unsigned)c4];
+                    if (r >= 0 && r < g.Sh && vcol) x = gh[(unsigned)r * 4u + (unsigned)c4];
                     v[m] = x * sgn;
                 });
                 fft.template run<-1>(v, lds, j);
@@ -601,9 +605,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                     constexpr int m = m_;
                     const unsigned idx = lane_pos<T>(j, m);
                     const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
-                    ffc[idx] = v[m];
-                    afc[idx] = M::sqrt(p2);
-                    if (a.store_pff) pfc[idx] = M::atan2(v[m].y, v[m].x);
+                    if (vcol) {
+                        ffc[idx] = v[m];
+                        afc[idx] = M::sqrt(p2);
+                        if (a.store_pff) pfc[idx] = M::atan2(v[m].y, v[m].x);
+                    }
                     acc_f += (double)p2;
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -710,11 +716,15 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
     const int ntiles = g.Pw / 4;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const bool listed = a.col_list != nullptr;     // CPAR == 1 (host checks)
+    // listed mode: pass q of this workgroup handles the CPAR list entries of group blockIdx.x + q*gridDim.x;
+    // a lane group beyond the end of the list runs on zeros (it shares the barriers) and stores nothing
+    const bool listed = a.col_list != nullptr;
     const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
     const int n_act = listed ? a.n_active[b] : 0;
-    const int ncols = listed ? ((int)blockIdx.x < n_act ? (n_act - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
+    const int n_grp = (n_act + CPAR - 1) / CPAR;
+    const int ncols = listed ? ((int)blockIdx.x < n_grp ? (n_grp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
                              : my_tiles * PASSES;
+    auto col_valid = [&](int q) { return !listed || ((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar < n_act; };
     R acc_w = 0;
     const R nogv = cp.nog != nullptr ? cp.nog[b] : (R)0;
     double* stat_slot = scratch + 16 + (tid >> 6) * STAT_N;
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
 
     auto col_of = [&](int q, int& ct, int& c4) {
         if (listed) {
-            const int col = clist[blockIdx.x + q * gridDim.x];
+            const int col = clist[min(((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar, n_act - 1)];
             ct = col >> 2;
             c4 = col & 3;
             return;
@@ -745,10 +755,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
         const R* wc = a.w + cb;
         const R* tc = a.t + cb;
+        const bool ok = col_valid(q);
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
-            wr[m] = wc[lane_pos<T>(j, m)];
-            if (cp.do_update || STATS || cp.mraf) tr[m] = tc[lane_pos<T>(j, m)];
+            wr[m] = ok ? wc[lane_pos<T>(j, m)] : (R)0;
+            if (cp.do_update || STATS || cp.mraf) tr[m] = ok ? tc[lane_pos<T>(j, m)] : (R)0;
         });
     };
     auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             constexpr int m = m_;
             const int r = r_lane + m * T;
             dst[m] = mk<R>(0, 0);
-            if (r >= 0 && r < g.Sh) dst[m] = gh[(unsigned)r * 4u];
+            if (r >= 0 && r < g.Sh && col_valid(q)) dst[m] = gh[(unsigned)r * 4u];
         });
     };
 
@@ -772,6 +783,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         int ct, c4;
         col_of(q, ct, c4);
         const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
+        const bool vcol = col_valid(q);
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgn; });
         fft.template run<-1>(v, lds, j);
 
@@ -786,13 +798,13 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
                 __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS || cp.mraf) && tr[m] != (R)0)) == 0) {
                 v[m] = mk<R>(0, 0);
-                if (cp.nog_pass) acc_w += (R)1;              // T == 0 -> fc = 1 (:1841)
+                if (cp.nog_pass && vcol) acc_w += (R)1;      // T == 0 -> fc = 1 (:1841)
                 return;
             }
             const Cx<R> F = v[m] * sc;
             const R p2 = F.x * F.x + F.y * F.y;
             if (cp.nog_pass) {                              // Nogrette: sum of fc = feedback / target over all pixels
-                acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
+                if (vcol) acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
                 v[m] = mk<R>(0, 0);
                 return;
             }
@@ -816,7 +828,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             }
             if constexpr (STATS) {
                 const R af = M::sqrt(p2);
-                if (a.do_stats & 2) a.amp_ff[cb + idx] = af;
+                if ((a.do_stats & 2) && vcol) a.amp_ff[cb + idx] = af;
                 sacc.add(p2, af, tr[m], stat_at, a.inv_fsum);
             }
             R co, si;
@@ -831,7 +843,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                     co = 1;
                     si = 0;
                 }
-                if constexpr (PHASE == 1) pfc[idx] = M::atan2(F.y, F.x);
+                if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
             v[m] = mk<R>(wv * co * sgn, wv * si * sgn);
             if (cp.mraf) {                                  // mixed-region amplitude freedom (:1606-1653)
@@ -841,14 +853,14 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                     v[m] = F * mf;
                 } else if (t == (R)0) {
                     v[m] = mk<R>(0, 0);
-                    if constexpr (PHASE == 1) pfc[idx] = (R)0;
+                    if constexpr (PHASE == 1) { if (vcol) pfc[idx] = (R)0; }
                 }
             }
             if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
 
         if constexpr (STATS) sacc.flush(stat_slot);
-        if (cp.do_update && w_changed) {
+        if (cp.do_update && w_changed && vcol) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
         }
         // ---- prefetch the next column while this one is transformed back ----
@@ -862,7 +874,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 const int r = r_lane + m * T;
-                if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u] = v[m] * sc;
+                if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * sc;
             });
         }
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });

@@ -720,3 +720,39 @@ def test_batch_with_different_sparse_targets_full_size():
         e = phase_rel_l2(got[i], h.phase)
         report(f"batch of different sparse targets, hologram {i}", phase=e, weights=rel_l2(w[i], h.weights))
         assert e < 1e-6 and rel_l2(w[i], h.weights) < 1e-6
+
+
+@pytest.mark.parametrize("shape,slm,n", [((256, 256), (72, 120), 7), ((512, 512), (100, 200), 13), ((1024, 1024), (288, 480), 30),
+                                         ((2048, 2048), (1080, 1920), 45), ((1024, 2048), (500, 1000), 9)])
+@pytest.mark.parametrize("method,feedback", [("WGS-Kim", "computational"), ("WGS-Leonardo", "computational_spot"),
+                                             ("WGS-Nogrette", "computational")])
+def test_sparse_paths_small_grids(shape, slm, n, method, feedback, monkeypatch):
+    """
+    Column lists on grids where a workgroup pass handles 2 or 4 columns side by side (Ph < 4096): odd
+    numbers of active columns leave lane groups past the end of the list, which must run on zeros
+    and store nothing.  Sparse path vs the same engine with HGS_SPARSE=0.
+    """
+    xs = 8 + 4 * np.floor((shape[1] / 4 - 4) * synth.uniform01(97, (n,), 0))
+    ys = 8 + 4 * np.floor((shape[0] / 4 - 4) * synth.uniform01(97, (n,), 1))
+    xy = np.unique(np.vstack((xs, ys)).astype(int), axis=1).astype(float)
+    kw = {"fix_phase_iteration": 2} if method == "WGS-Kim" else {}
+
+    def run(sparse):
+        monkeypatch.setenv("HGS_SPARSE", "1" if sparse else "0")
+        h = SpotHologram(shape, xy, basis="knm", slm_shape=slm, phase=synth.seed_phase(98, slm))
+        h.optimize(method, maxiter=5, verbose=False, feedback=feedback, stat_groups=["computational", "computational_spot"], **kw)
+        h.optimize(method, maxiter=2, verbose=False, feedback=feedback, **kw)
+        return h
+
+    a, b = run(True), run(False)
+    ky, kx = a.spot_knm_rounded[1], a.spot_knm_rounded[0]
+    errs = dict(phase=phase_rel_l2(a.phase, b.phase), spot_amp=rel_l2(a.amp_ff[ky, kx], b.amp_ff[ky, kx]),
+                weights=rel_l2(a.weights, b.weights))
+    report(f"sparse small grid {shape} {method} {feedback}", **errs)
+    assert errs["phase"] < 3e-5 and errs["spot_amp"] < 1e-5 and errs["weights"] < 2e-5
+    assert np.count_nonzero(a.weights) == xy.shape[1]
+    for grp in ("computational", "computational_spot"):
+        for nme in STAT_NAMES:
+            # pkpk_err / std_err of a converged array are differences of nearly equal fp32 powers
+            np.testing.assert_allclose(a.stats["stats"][grp][nme][:5], b.stats["stats"][grp][nme][:5], rtol=2e-3, atol=2e-6,
+                                       err_msg=f"{grp}.{nme}")
