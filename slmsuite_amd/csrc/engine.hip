@@ -791,7 +791,8 @@ template <typename R> struct Engine : EngineBase {
             RowArgs<R> a = row_args(finalize);
             a.load_mask = load_sparse == 1 ? lane_mask : load_sparse == 2 ? lane_mask_d : nullptr;
             a.store_mask = store_sparse == 1 ? lane_mask : store_sparse == 2 ? lane_mask_d : nullptr;
-            LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks, B), stream, a));
+            // one extra (row-less) block folds the weight-norm partials when asked to
+            LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks + (finalize ? 1 : 0), B), stream, a));
             return 0;
         });
     }
@@ -1269,8 +1270,14 @@ template <typename R> struct Engine : EngineBase {
                         LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
                     } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
                         wpartial_n = tile_blocks;
-                        if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
-                        else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                        const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;
+                        if (extras) {
+                            if (a.do_stats) LCHK(launch_tile_extras_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                            else LCHK(launch_tile_extras<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                        } else {
+                            if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                            else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                        }
                     } else {
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
                         else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));

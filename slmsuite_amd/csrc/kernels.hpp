@@ -368,7 +368,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
 
     // deferred weight normalisation: one block per hologram folds the partial sums of the last
     // weight update into the scalar every later reader multiplies by (_hologram.py:1877).
-    if (a.wpartial != nullptr && blockIdx.x == 0) {
+    // (done by the LAST block, which the host launches in addition to the row blocks: it owns no row, so the
+    //  reduction does not lengthen any row's critical path)
+    if (a.wpartial != nullptr && blockIdx.x == gridDim.x - 1) {
         double s = 0;
         for (int i = tid; i < a.n_wpartial; i += blockDim.x) s += a.wpartial[(size_t)b * a.n_wpartial + i];
         double* scratch = reinterpret_cast<double*>(smem);
@@ -388,9 +390,30 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
     const int c_lane = j - g.c0;   // SLM column of element m is c_lane + m*T
     // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list);
     // lane_mask[b][16][Pw/16] holds the 16-bit mask of lane j of a length-Pw row transform
+    // The loads of the H row are predicated on the mask, so its fetch is on the critical path of every
+    // workgroup: take it through the scalar cache (the 64 masks of a wave are 32 consecutive words at a
+    // wave-uniform address) and hand each lane its half-word through the LDS crossbar, instead of
+    // a per-lane global load that costs a full memory round trip before the first H load can issue.
     unsigned lmask = 0xffffu, smask = 0xffffu;
-    if (a.load_mask != nullptr) lmask = a.load_mask[(size_t)b * T + j];
-    if (a.store_mask != nullptr) smask = a.store_mask[(size_t)b * T + j];
+    auto fetch_mask = [&](const unsigned short* tab) -> unsigned {
+        if constexpr (T % 64 == 0) {
+            const int lane = tid & 63;
+            const int wbase = __builtin_amdgcn_readfirstlane((tid % T) & ~63);
+            const unsigned* mw = reinterpret_cast<const unsigned*>(tab + (size_t)b * T + wbase);   // wave-uniform
+            unsigned mine = 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const unsigned sw = mw[k];
+                mine = (lane == k) ? sw : mine;
+            }
+            const unsigned got = __shfl(mine, lane >> 1, 64);
+            return (lane & 1) ? (got >> 16) : (got & 0xffffu);
+        } else {
+            return tab[(size_t)b * T + j];
+        }
+    };
+    if (a.load_mask != nullptr) lmask = fetch_mask(a.load_mask);
+    if (a.store_mask != nullptr) smask = (a.store_mask == a.load_mask) ? lmask : fetch_mask(a.store_mask);
 
     // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
     // assumption): give the four rows that share each 128-byte GH line to four blocks of the same
@@ -921,7 +944,8 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
     });
 }
 
-template <typename R, int N, int PHASE, int NR, bool STATS = false>
+// EXTRAS = false compiles the MRAF / Nogrette / forward-only branches out (2.7 us of the 58 us dense launch)
+template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true>
 __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
     using M = Math<R>;
     constexpr int T = N / 16;
@@ -1016,12 +1040,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
                     __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
                     v[m] = mk<R>(0, 0);
-                    if (cp.nog_pass) acc_w += (R)1;          // T == 0 -> fc = 1 (:1841)
+                    if (EXTRAS && cp.nog_pass) acc_w += (R)1;          // T == 0 -> fc = 1 (:1841)
                     return;
                 }
                 const Cx<R> F = cmul(v[m], om);
                 const R p2 = F.x * F.x + F.y * F.y;
-                if (cp.nog_pass) {                          // Nogrette: sum of fc = feedback / target over all pixels
+                if (EXTRAS && cp.nog_pass) {                          // Nogrette: sum of fc = feedback / target over all pixels
                     acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
                     v[m] = mk<R>(0, 0);
                     return;
@@ -1065,7 +1089,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
                 // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
                 v[m] = cmulc(ph, om) * wv;
-                if (cp.mraf) {                              // mixed-region amplitude freedom (:1606-1653)
+                if (EXTRAS && cp.mraf) {                              // mixed-region amplitude freedom (:1606-1653)
                     const R t = tr[m];
                     if (is_nan(t)) {                        // noise region keeps the field (times mraf_factor)
                         v[m] = cmulc(cp.has_mraf_factor ? F * cp.mraf_factor : F, om);
@@ -1092,7 +1116,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, upd, j, wr, tr);
             }
 
-            if (cp.weights_only) continue;
+            if (EXTRAS && cp.weights_only) continue;
             fft.template run<+1, HGS_TILE_DB>(v, lds, j);
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
@@ -1104,7 +1128,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
             }
         }
-        if (cp.weights_only) continue;
+        if (EXTRAS && cp.weights_only) continue;
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;

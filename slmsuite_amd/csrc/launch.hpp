@@ -14,6 +14,9 @@ template <typename R> int launch_tile(int N, int phase_mode, dim3 grid, hipStrea
 // the same two kernels with the in-pass statistics compiled in (ColArgs::do_stats, hgs_iterate_stats)
 template <typename R> int launch_fused_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a);
 template <typename R> int launch_tile_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
+// ... and with the MRAF / Nogrette-sum / forward-only branches (launch_tile* compile them out)
+template <typename R> int launch_tile_extras(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
+template <typename R> int launch_tile_extras_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
 
 // blocks of the transform kernels resident per CU are bounded by LDS; exposed for grid sizing
 template <typename R> size_t row_lds_bytes(int N);

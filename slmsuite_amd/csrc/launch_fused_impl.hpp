@@ -5,17 +5,30 @@
 #ifndef HGS_STATS_TU
 #define HGS_STATS_TU 0
 #endif
+#ifndef HGS_TILE_EXTRAS_TU
+#define HGS_TILE_EXTRAS_TU 0      // 1: this unit holds only the tile-resident kernel WITH the MRAF / Nogrette /
+#endif                            //    forward-only branches (launch_tile_extras*)
 #if HGS_STATS_TU
 #define LAUNCH_FUSED launch_fused_stats
+#if HGS_TILE_EXTRAS_TU
+#define LAUNCH_TILE launch_tile_extras_stats
+#else
 #define LAUNCH_TILE launch_tile_stats
+#endif
 #else
 #define LAUNCH_FUSED launch_fused
+#if HGS_TILE_EXTRAS_TU
+#define LAUNCH_TILE launch_tile_extras
+#else
 #define LAUNCH_TILE launch_tile
+#endif
 #endif
 
 namespace hgs {
 constexpr bool kStats = HGS_STATS_TU != 0;
+constexpr bool kExtras = HGS_TILE_EXTRAS_TU != 0;
 
+#if !HGS_TILE_EXTRAS_TU
 template <typename R, int N, int PHASE>
 static int launch_fused_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
     constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
@@ -53,11 +66,13 @@ template <> int LAUNCH_FUSED<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t 
     return (int)hipErrorInvalidValue;
 }
 
+#endif   // !HGS_TILE_EXTRAS_TU
+
 #ifdef HGS_REAL_IS_FLOAT
 template <int N, int PHASE>
 static int launch_tile_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
     constexpr size_t lds = (size_t)(HGS_TILE_DB ? 2 : 1) * lds_elems<N>() * sizeof(Cx<float>) + SCRATCH_DOUBLES * sizeof(double);
-    auto k = col_tile_kernel<float, N, PHASE, 6, kStats>;
+    auto k = col_tile_kernel<float, N, PHASE, 6, kStats, kExtras>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -85,6 +100,15 @@ template <> int LAUNCH_TILE<float>(int N, int phase, dim3 grid, hipStream_t s, c
 template <> int LAUNCH_TILE<double>(int, int, dim3, hipStream_t, const ColArgs<double>&, int) {
     return (int)hipErrorInvalidValue;   // the tile-resident kernel is fp32 only
 }
+#if HGS_STATS_TU
+template <> int launch_tile_extras_stats<double>(int, int, dim3, hipStream_t, const ColArgs<double>&, int) {
+    return (int)hipErrorInvalidValue;
+}
+#else
+template <> int launch_tile_extras<double>(int, int, dim3, hipStream_t, const ColArgs<double>&, int) {
+    return (int)hipErrorInvalidValue;
+}
+#endif
 #endif
 
 }  // namespace hgs
