@@ -122,6 +122,8 @@ template <typename R> struct Engine : EngineBase {
     bool sparse_dirty = true;
     int opt_sparse = 1;                    // HGS_OPT_SPARSE_COLUMNS
     // statistics of the fused path (hgs_iterate_stats)
+    double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
+    int* stats_dxy = nullptr;         // hgs_stats group 1: floor(spot_knm)
     double* stat_partial = nullptr;   // [B][blocks][STAT_WAVES][STAT_N]
     double* stat_tsum = nullptr;      // [B] sum T^2
     struct StatCtx { int groups = 0, width = 1; double* dev_out = nullptr; int* dxy = nullptr; };
@@ -170,7 +172,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -1469,8 +1471,9 @@ template <typename R> struct Engine : EngineBase {
         if (!aff || !farfield_valid) return fail(HGS_ERR_STATE, "statistics need a materialised farfield");
         const int nb = std::min(ew_blocks, 1024);
         if (group == 0) {
-            double* d1 = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&d1), (size_t)B * nb * 7 * sizeof(double) + (size_t)B * 2 * sizeof(double)));
+            // persistent scratch: hipMalloc / hipFree per call would synchronise the device every iteration
+            if (!stats_scratch) { if (dalloc(&stats_scratch, (size_t)B * 1024 * 7 + (size_t)B * 2)) return HGS_ERR_DEVICE; }
+            double* d1 = stats_scratch;
             double* d_sfst = d1 + (size_t)B * nb * 7;
             hipLaunchKernelGGL(stats_pass1<R>, dim3(nb, B), dim3(256), 0, stream, (const R*)aff, (const R*)t, P, d1);
             HIPCHK(hipGetLastError());
@@ -1492,7 +1495,6 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h.data(), d1, (size_t)B * nb * 7 * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            hipFree(d1);
             for (int b = 0; b < B; ++b) {
                 double rmin = INFINITY, rmax = -INFINITY, emin = INFINITY, emax = -INFINITY, es = 0, es2 = 0, cnt = 0;
                 for (int i = 0; i < nb; ++i) {
@@ -1522,8 +1524,8 @@ template <typename R> struct Engine : EngineBase {
                 if (ixy[n] + flo < 0 || ixy[N + n] + flo < 0 || ixy[n] + fhi >= g.Pw || ixy[N + n] + fhi >= g.Ph)
                     return fail(HGS_ERR_ARG, "integration window of spot %d leaves the grid", n);
             }
-            int* dxy = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&dxy), 2 * N * sizeof(int)));
+            if (!stats_dxy) { if (dalloc(&stats_dxy, (size_t)2 * N)) return HGS_ERR_DEVICE; }
+            int* dxy = stats_dxy;
             HIPCHK(hipMemcpyAsync(dxy, ixy.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice, stream));
             SpotArgs<R> s{};
             s.g = g; s.n_spots = N; s.width = width; s.feedback = 1; s.spot_xy = dxy; s.amp_ff = aff; s.fb = spot_fb;
@@ -1535,7 +1537,6 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipMemcpyAsync(tv.data(), spot_amp, N * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(fs.data(), sums, B * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            hipFree(dxy);
             for (int b = 0; b < B; ++b) {
                 std::vector<double> fv(N);
                 for (int n = 0; n < N; ++n) fv[n] = (double)fb[(size_t)b * N + n];
