@@ -160,8 +160,17 @@ int hgs_sync(hgs_engine* e);
  * (every other column of the constrained farfield is exactly zero).  Covers pixel feedback and, with
  * the spot columns dilated by the integration window, the spot feedback modes.  While it is active,
  * HGS_PHASE_FF stored by WGS-Kim is refreshed on the active columns only (the rest cannot influence the
- * loop; hgs_nearfield2farfield(store_phase_ff = 1) refreshes every pixel).  0 forces the dense kernels. */
-enum { HGS_OPT_SPARSE_COLUMNS = 1 };
+ * loop; hgs_nearfield2farfield(store_phase_ff = 1) refreshes every pixel).  0 forces the dense kernels.
+ * HGS_OPT_FORCE_STEPWISE (default 0): hgs_iterate / hgs_iterate_stats loop the three general operators
+ *   (materialised farfield) even where a fused kernel exists -- the reference's own op sequence; used by tests.
+ * HGS_OPT_TILE_KERNEL (default 1): use the tile-resident fused column kernel where it applies (fp32, pad_h >= 4096).
+ * HGS_OPT_SEPARABLE (default 1), HGS_OPT_SEPARABLE_MIN_SPOTS (default 32): kind 1, run the two transforms as
+ *   complex GEMMs on the matrix cores when the basis and the grid factorise; 0 forces the direct kernels.
+ * Options are per engine and take effect at the next call; nothing is read from the environment after
+ * hgs_create (which reads the developer grid-size overrides HGS_ROW_BLOCKS / HGS_COL_BLOCKS / HGS_TILE_BLOCKS /
+ * HGS_ROW_XCD once). */
+enum { HGS_OPT_SPARSE_COLUMNS = 1, HGS_OPT_FORCE_STEPWISE = 2, HGS_OPT_TILE_KERNEL = 3, HGS_OPT_SEPARABLE = 4,
+       HGS_OPT_SEPARABLE_MIN_SPOTS = 5 };
 int hgs_set_option(hgs_engine* e, int option, int value);
 
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */

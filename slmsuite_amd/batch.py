@@ -25,6 +25,22 @@ def batch_flags(method, **flags):
     return fl
 
 
+def normalize_targets(target, dtype=np.float32):
+    """
+    Hologram._set_target (_hologram.py:741-760): target = |target| / sqrt(nansum(target^2)), per hologram.
+    The additive rules (WGS-Wu, WGS-tanh) depend on the target scale, so an un-normalised image must not reach
+    the engine.  Targets that already have unit norm (e.g. ``Hologram.target``) pass through bit-identically.
+    """
+    t = np.abs(np.asarray(target, dtype=dtype))
+    flat = t.reshape((-1,) + t.shape[-2:]) if t.ndim >= 2 else t.reshape(1, -1)
+    out = flat.copy()
+    for i in range(flat.shape[0]):
+        nrm = float(np.sqrt(np.nansum(np.square(flat[i].astype(np.float64)))))
+        if nrm > 0 and abs(nrm - 1.0) > 1e-6:
+            out[i] = flat[i] * np.dtype(dtype).type(1.0 / nrm)
+    return out.reshape(t.shape).astype(dtype, copy=False)
+
+
 class HologramBatch:
     """``batch`` holograms sharing geometry/amp (and optionally target) on one GPU."""
 
@@ -42,7 +58,7 @@ class HologramBatch:
             e.set(L.AMP, a * (1 / np.sqrt(np.nansum(np.square(a)))))
         if propagation_kernel is not None:
             e.set(L.PROP_KERNEL, propagation_kernel)
-        e.set(L.TARGET, target)          # one target broadcasts to the whole batch
+        e.set(L.TARGET, normalize_targets(target, dtype))   # one target broadcasts to the whole batch
         e.reset_weights()
         e.set(L.PHASE, phases)
         if spot_index is not None:
@@ -66,11 +82,12 @@ class HologramBatch:
         self.flags["fixed_phase"] = bool(st.fixed_phase)
         return self
 
-    def time_iterations(self, method, n_iter, **flags):
+    def time_iterations(self, method, n_iter, spot_window=3, **flags):
         """Milliseconds for n_iter loop bodies, HIP events on the engine stream."""
         if self.flags is None:
             self.flags = batch_flags(method, **flags)
-        st = make_step(self.flags, self.iter, false_run=self.false_run, mraf_enabled=self.mraf)
+        st = make_step(self.flags, self.iter, false_run=self.false_run, mraf_enabled=self.mraf,
+                       spot_window=spot_window)
         ms = self.engine.iterate_timed(st, n_iter)
         self.iter, self.false_run = st.iter, st.false_run
         self.flags["fixed_phase"] = bool(st.fixed_phase)
@@ -78,6 +95,10 @@ class HologramBatch:
 
     def phases(self):
         return self.engine.get(L.PHASE)
+
+    def phases_into_device(self, dev_ptr, nbytes):
+        """Copy the [n, Sh, Sw] phase masks into caller-owned DEVICE memory (e.g. a torch tensor handed to RCCL)."""
+        self.engine.get_into_device(L.PHASE, dev_ptr, nbytes)
 
     def close(self):
         self.engine.close()
@@ -120,19 +141,37 @@ def optimize_batch_distributed(shape, slm_shape, target, phases, method="WGS-Leo
     n = phases.shape[0]
     lo, hi = shard_range(n, rank, world)
     use_cuda = dist.get_backend() == "nccl"
-    if compute is None:
-        if device is None:
-            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        compute = lambda *a, **k: optimize_batch(*a, device=device, **k)   # noqa: E731
-    local = np.asarray(compute(shape, slm_shape, target, phases[lo:hi], method, maxiter, dtype=dtype, **kw),
-                       dtype=dtype) if hi > lo else np.zeros((0,) + tuple(slm_shape), dtype=dtype)
     # equal-sized contributions for all_gather: pad to the largest shard
     per = (n + world - 1) // world
-    buf = np.zeros((per,) + tuple(slm_shape), dtype=dtype)
-    buf[: hi - lo] = local
-    t = torch.from_numpy(buf)
-    if use_cuda:
-        t = t.cuda()
+    if compute is None and use_cuda:
+        # the engine's phase masks go device -> device into the tensor RCCL sends: no host bounce
+        if device is None:
+            device = torch.cuda.current_device()
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        t = torch.zeros((per,) + tuple(slm_shape), dtype=tdt, device=torch.device("cuda", device))
+        if hi > lo:
+            ctor = {k: kw.pop(k) for k in ("amp", "propagation_kernel", "spot_index", "spot_amp") if k in kw}
+            tg = np.asarray(target)
+            hb = HologramBatch(shape, slm_shape, tg[lo:hi] if tg.ndim == 3 else tg, phases[lo:hi], dtype=dtype,
+                               device=device, **ctor)
+            try:
+                hb.optimize(method, maxiter, **kw)
+                torch.cuda.synchronize(device)
+                hb.phases_into_device(t.data_ptr(), (hi - lo) * int(np.prod(slm_shape)) * np.dtype(dtype).itemsize)
+            finally:
+                hb.close()
+    else:
+        if compute is None:
+            if device is None:
+                device = 0
+            compute = lambda *a, **k: optimize_batch(*a, device=device, **k)   # noqa: E731
+        local = np.asarray(compute(shape, slm_shape, target, phases[lo:hi], method, maxiter, dtype=dtype, **kw),
+                           dtype=dtype) if hi > lo else np.zeros((0,) + tuple(slm_shape), dtype=dtype)
+        buf = np.zeros((per,) + tuple(slm_shape), dtype=dtype)
+        buf[: hi - lo] = local
+        t = torch.from_numpy(buf)
+        if use_cuda:
+            t = t.cuda()
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     res = np.empty((n,) + tuple(slm_shape), dtype=dtype)

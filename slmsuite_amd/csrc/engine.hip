@@ -50,6 +50,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 struct EngineBase {
+    int device = 0;      // HIP device ordinal of this engine; every C-ABI entry makes it current first
     virtual ~EngineBase() {}
     virtual int init(const hgs_config& c) = 0;
     virtual int set_array(int which, const void* host, size_t nbytes) = 0;
@@ -120,7 +121,12 @@ template <typename R> struct Engine : EngineBase {
     bool dil_valid = false;
     int n_active_max = 0, n_active_min = 0;
     bool sparse_dirty = true;
+    // engine policy (hgs_set_option); the grid-size tuning knobs are read from the environment once, in init()
     int opt_sparse = 1;                    // HGS_OPT_SPARSE_COLUMNS
+    int opt_stepwise = 0;                  // HGS_OPT_FORCE_STEPWISE
+    int opt_tile = 1;                      // HGS_OPT_TILE_KERNEL
+    int opt_separable = 1;                 // HGS_OPT_SEPARABLE
+    int opt_sep_min = 32;                  // smallest spot count the matrix-core form is used for
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
     int* stats_dxy = nullptr;         // hgs_stats group 1: floor(spot_knm)
@@ -179,6 +185,13 @@ template <typename R> struct Engine : EngineBase {
         if (stream) hipStreamDestroy(stream);
     }
 
+    // host -> device on the engine stream, complete on return (ordered against in-flight kernels of this
+    // engine; the caller's buffer may be reused immediately)
+    int h2d(void* dst, const void* src, size_t nbytes) {
+        HIPCHK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
     template <typename T> int dalloc(T** p, size_t n) {
         HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
         HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), stream));
@@ -198,12 +211,13 @@ template <typename R> struct Engine : EngineBase {
         h[N / 2].x = -1; h[N / 2].y = 0;
         h[3 * N / 4].x = 0; h[3 * N / 4].y = 1;
         HIPCHK(hipMalloc(reinterpret_cast<void**>(dev), N * sizeof(C)));
-        HIPCHK(hipMemcpy(*dev, h.data(), N * sizeof(C), hipMemcpyHostToDevice));
+        if (int e_ = h2d(*dev, h.data(), N * sizeof(C))) return e_;
         return 0;
     }
 
     int init(const hgs_config& c) override {
         cfg = c;
+        device = c.device;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
             return fail(HGS_ERR_DEVICE, "no HIP device available (the engine has no CPU fallback)");
@@ -324,9 +338,9 @@ template <typename R> struct Engine : EngineBase {
                                  : (px == 2) ? 3 : (px == 1) ? 4 : 5;
                 for (int n = 0; n < N; ++n) c6[(size_t)slot * N + n] += coeff_host[(size_t)m * N + n];
             }
-            HIPCHK(hipMemcpy(coeff, c6.data(), c6.size() * sizeof(R), hipMemcpyHostToDevice));
+            if (int e_ = h2d(coeff, c6.data(), c6.size() * sizeof(R))) return e_;
         } else {
-            HIPCHK(hipMemcpy(coeff, coeff_host.data(), (size_t)M * N * sizeof(R), hipMemcpyHostToDevice));
+            if (int e_ = h2d(coeff, coeff_host.data(), (size_t)M * N * sizeof(R))) return e_;
         }
         return sep_refresh();
     }
@@ -408,7 +422,7 @@ template <typename R> struct Engine : EngineBase {
         return 0;
     }
     bool use_sep() const {
-        return c_sep && env_int("HGS_C_SEPARABLE", 1) && cfg.n_spots >= env_int("HGS_C_SEP_MIN", 32);
+        return c_sep && opt_separable && cfg.n_spots >= opt_sep_min;
     }
     int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int K, int lda, int ldb, int split, int k_per,
                      size_t strideA, size_t strideB) {
@@ -619,7 +633,7 @@ template <typename R> struct Engine : EngineBase {
             case HGS_AMP: {
                 if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "amp: bad size %zu", nbytes);
                 if (!amp) HIPCHK(hipMalloc(reinterpret_cast<void**>(&amp), S * sizeof(R)));
-                HIPCHK(hipMemcpy(amp, host, nbytes, hipMemcpyHostToDevice));
+                if (int e_ = h2d(amp, host, nbytes)) return e_;
                 has_amp = true;
                 const R* h = (const R*)host;
                 double s = 0;
@@ -639,7 +653,7 @@ template <typename R> struct Engine : EngineBase {
             case HGS_PROP_KERNEL: {
                 if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "propagation kernel: bad size %zu", nbytes);
                 if (!kern) HIPCHK(hipMalloc(reinterpret_cast<void**>(&kern), S * sizeof(R)));
-                HIPCHK(hipMemcpy(kern, host, nbytes, hipMemcpyHostToDevice));
+                if (int e_ = h2d(kern, host, nbytes)) return e_;
                 has_kern = true;
                 farfield_valid = false;
                 return 0;
@@ -667,7 +681,7 @@ template <typename R> struct Engine : EngineBase {
             case HGS_YGRID: {
                 if (cfg.kind != 1) return fail(HGS_ERR_STATE, "grids belong to the compressed engine");
                 if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "grid: bad size %zu", nbytes);
-                HIPCHK(hipMemcpy(which == HGS_XGRID ? xg : yg, host, nbytes, hipMemcpyHostToDevice));
+                if (int e_ = h2d(which == HGS_XGRID ? xg : yg, host, nbytes)) return e_;
                 has_grid[which == HGS_XGRID ? 0 : 1] = true;
                 farfield_valid = false;
                 {   // product grid?  x depends on the column only, y on the row only
@@ -697,7 +711,7 @@ template <typename R> struct Engine : EngineBase {
                 const int32_t* h = (const int32_t*)host;
                 if (has_mono && std::equal(mono_host.begin(), mono_host.end(), h)) return 0;   // unchanged term set
                 mono_host.assign(h, h + 2 * cfg.n_monomials);
-                HIPCHK(hipMemcpy(mono, host, nbytes, hipMemcpyHostToDevice));
+                if (int e_ = h2d(mono, host, nbytes)) return e_;
                 has_mono = true;
                 farfield_valid = false;
                 return pack_coeff();
@@ -719,7 +733,7 @@ template <typename R> struct Engine : EngineBase {
                 for (int n = 0; n < cfg.n_spots; ++n)
                     if (h[n] < hw || h[n] >= g.Pw || h[cfg.n_spots + n] < 0 || h[cfg.n_spots + n] >= g.Ph)
                         return fail(HGS_ERR_ARG, "spot %d outside the computational grid", n);
-                HIPCHK(hipMemcpy(spot_xy, host, nbytes, hipMemcpyHostToDevice));
+                if (int e_ = h2d(spot_xy, host, nbytes)) return e_;
                 spot_xy_host.assign(h, h + 2 * cfg.n_spots);
                 has_spots = true;
                 return 0;
@@ -729,7 +743,7 @@ template <typename R> struct Engine : EngineBase {
                 if (cfg.kind == 1 && which == HGS_SPOT_AMP) return fail(HGS_ERR_ARG, "compressed targets are set with HGS_TARGET");
                 if (cfg.n_spots <= 0) return fail(HGS_ERR_STATE, "engine was created with n_spots = 0");
                 if (nbytes != (size_t)cfg.n_spots * sizeof(double)) return fail(HGS_ERR_ARG, "spot amplitudes: bad size");
-                HIPCHK(hipMemcpy(which == HGS_SPOT_AMP ? spot_amp : ext_amp, host, nbytes, hipMemcpyHostToDevice));
+                if (int e_ = h2d(which == HGS_SPOT_AMP ? spot_amp : ext_amp, host, nbytes)) return e_;
                 return 0;
             }
         }
@@ -1084,7 +1098,7 @@ template <typename R> struct Engine : EngineBase {
     // off).  Everything else of the farfield is exactly zero and is neither computed nor moved.
     bool spot_sparse_ok(const hgs_step* st) {
         if (cfg.kind != 0 || st->mraf_enabled || st->method == HGS_GS || st->feedback == HGS_FB_PIXEL) return false;
-        if (!env_int("HGS_SPARSE", opt_sparse) || env_int("HGS_FORCE_STEPWISE", 0)) return false;
+        if (!opt_sparse || opt_stepwise) return false;
         if (refresh_sparse()) return false;
         return n_active_min > 0 && n_active_max * 4 <= g.Pw;
     }
@@ -1173,7 +1187,7 @@ template <typename R> struct Engine : EngineBase {
         if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
         if (n == 0) return 0;
         if (int e = check_step(st)) return e;
-        const bool fused = fused_ok(st) && !env_int("HGS_FORCE_STEPWISE", 0);
+        const bool fused = fused_ok(st) && !opt_stepwise;
         if (!fused && spot_sparse_ok(st)) return iterate_spot_sparse(st, n, hist);
         if (!fused) {
             for (int i = 0; i < n; ++i) {
@@ -1191,7 +1205,7 @@ template <typename R> struct Engine : EngineBase {
         // kernels.  phase_ff (WGS-Kim) is then stored on the active columns only: nothing else can be
         // read back by the loop.
         bool sparse_enabled = false;
-        if (env_int("HGS_SPARSE", opt_sparse) && !env_int("HGS_OLD_FUSED", 0)) {
+        if (opt_sparse) {
             if (int e = refresh_sparse()) return e;
             sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
         }
@@ -1268,9 +1282,7 @@ template <typename R> struct Engine : EngineBase {
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                         else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
-                    } else if (env_int("HGS_OLD_FUSED", 0)) {
-                        LCHK(launch_col<R>(g.Ph, C_FWD | C_CONS | C_INV, dim3(col_blocks, B), stream, a));
-                    } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && env_int("HGS_TILE", 1)) {
+                    } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && opt_tile) {
                         wpartial_n = tile_blocks;
                         const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;
                         if (extras) {
@@ -1363,8 +1375,7 @@ template <typename R> struct Engine : EngineBase {
             }
         }
         for (size_t k = 0; k < (size_t)n * 2 * B * 4; ++k) out[k] = NAN;
-        const bool fused = (fused_ok(st) || spot_sparse_ok(st)) && !env_int("HGS_FORCE_STEPWISE", 0) &&
-                           !env_int("HGS_OLD_FUSED", 0);
+        const bool fused = (fused_ok(st) || spot_sparse_ok(st)) && !opt_stepwise;
         if (!fused) {
             // general path: materialise, reduce, constrain -- one host read of a few doubles per iteration
             for (int i = 0; i < n; ++i) {
@@ -1550,6 +1561,10 @@ template <typename R> struct Engine : EngineBase {
     int set_option(int option, int value) override {
         switch (option) {
             case HGS_OPT_SPARSE_COLUMNS: opt_sparse = value ? 1 : 0; return 0;
+            case HGS_OPT_FORCE_STEPWISE: opt_stepwise = value ? 1 : 0; return 0;
+            case HGS_OPT_TILE_KERNEL: opt_tile = value ? 1 : 0; return 0;
+            case HGS_OPT_SEPARABLE: opt_separable = value ? 1 : 0; return 0;
+            case HGS_OPT_SEPARABLE_MIN_SPOTS: opt_sep_min = value > 0 ? value : 1; return 0;
         }
         return fail(HGS_ERR_ARG, "unknown option %d", option);
     }
@@ -1593,8 +1608,12 @@ int hgs_destroy(hgs_engine* e) {
     return 0;
 }
 
-#define ENG(e) \
-    if (!(e) || !(e)->impl) return hgs::fail(HGS_ERR_ARG, "null engine handle");
+// every entry point validates the handle and makes the engine's device current for the calling thread
+// (lazy allocations, event creation and launches all follow the current device)
+#define ENG(e)                                                                         \
+    if (!(e) || !(e)->impl) return hgs::fail(HGS_ERR_ARG, "null engine handle");       \
+    if (hipSetDevice((e)->impl->device) != hipSuccess)                                  \
+        return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", (e)->impl->device);
 
 int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes) { ENG(e) return e->impl->set_array(which, host, nbytes); }
 int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes) { ENG(e) return e->impl->get_array(which, host, nbytes, false); }
@@ -1618,6 +1637,7 @@ int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double*
             info[k].device != info[0].device)
             return hgs::fail(HGS_ERR_ARG, "multiplane: child %d differs in SLM shape, batch, precision or device", k);
     }
+    if (hipSetDevice(info[0].device) != hipSuccess) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", info[0].device);
     for (int k = 0; k < n; ++k) {
         if (int r = children[k]->impl->f2n_complex()) return r;
         if (int r = children[k]->impl->mp_info(&info[k])) return r;     // the nearfield buffer exists now

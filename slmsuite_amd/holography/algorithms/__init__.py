@@ -130,6 +130,8 @@ class Hologram:
         self._stale = set()    # names whose device copy is newer than the host copy
         self._upload = set()   # names whose host copy must reach the device before the next op
         self._n_spots_engine = 0
+        # engine policy applied whenever this hologram creates an engine: {L.OPT_*: value} (hgs_set_option)
+        self.engine_options = dict(kwargs.pop("engine_options", {}) or {})
 
         if amp is None:
             self.amp = 1 / np.sqrt(np.prod(self.slm_shape))              # scalar (:401-402)
@@ -189,6 +191,8 @@ class Hologram:
         e = self._engine
         if e is None:
             e = self._engine = Engine(self.shape, self.slm_shape, self.dtype, batch=1, n_spots=self._n_spots())
+            for opt, val in self.engine_options.items():
+                e.set_option(opt, val)
             if np.isscalar(self.amp):
                 e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
             else:
@@ -224,9 +228,20 @@ class Hologram:
         self._stale -= {"amp_ff", "phase_ff", "farfield"}
         self._upload.discard("phase_ff")
         if self._engine is not None:
-            # phase_ff "None" on the device side: a fresh engine is the simplest faithful reset
-            self._engine.close()
-            self._engine = None
+            # phase_ff "None" on the device side: a fresh engine is the simplest faithful reset.  What only
+            # the device holds and must survive (the current phase when reset_phase is False) comes home first.
+            self._release_engine()
+
+    def _release_engine(self):
+        """Download every device-fresh array that outlives the engine, then destroy it."""
+        if self._engine is None:
+            return
+        for name in ("phase", "weights"):
+            if name in self._stale:
+                self._get_dev(name)
+        self._stale.clear()
+        self._engine.close()
+        self._engine = None
 
     def _get_random_phase(self):
         rng = np.random.default_rng()
@@ -1021,6 +1036,8 @@ class CompressedSpotHologram(FeedbackHologram):
             terms, _ = toolbox.zernike_monomial_weights(self.zernike_basis, self.spot_zernike)
             e = self._engine = Engine(self.slm_shape, self.slm_shape, self.dtype, batch=1, n_spots=len(self),
                                       kind=1, n_monomials=terms.shape[0])
+            for opt, val in self.engine_options.items():
+                e.set_option(opt, val)
             if np.isscalar(self.amp):
                 e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
             else:
@@ -1109,9 +1126,7 @@ class MultiplaneHologram(Hologram):
         # the children point to the same data (:73-76)
         for h in self.holograms:
             h.amp = self.amp
-            if h._engine is not None:                   # a new amplitude needs a fresh engine
-                h._engine.close()
-                h._engine = None
+            h._release_engine()                         # a new amplitude needs a fresh engine (state comes home first)
         self.phase = self._host["phase"]
         if weights is None:
             weights = np.ones(len(self), dtype=self.dtype)

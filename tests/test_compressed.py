@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden, rel_l2, phase_rel_l2, report
+from slmsuite_amd import _lib as L
 from slmsuite_amd import synth
 from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
 from slmsuite_amd.holography import toolbox
@@ -97,7 +98,7 @@ def test_compressed_double_precision_and_external_feedback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("D", [2, 3])
-def test_separable_matrix_core_path_matches_direct_kernels(D, monkeypatch):
+def test_separable_matrix_core_path_matches_direct_kernels(D):
     """
     Tilt (D = 2) and tilt + focus (D = 3) kernels factorise into Ex[n][x] * Ey[n][y]: both transforms run as
     complex GEMMs on the matrix cores.  Same hologram through the direct (regenerate-on-the-fly) kernels.
@@ -113,8 +114,8 @@ def test_separable_matrix_core_path_matches_direct_kernels(D, monkeypatch):
     kern = (0.3 * synth.seed_phase(53, slm_shape)).astype(np.float32)
 
     def run(sep):
-        monkeypatch.setenv("HGS_C_SEPARABLE", "1" if sep else "0")
-        h = CompressedSpotHologram(v, basis="kxy", spot_amp=amp, cameraslm=fs, propagation_kernel=kern)
+        h = CompressedSpotHologram(v, basis="kxy", spot_amp=amp, cameraslm=fs, propagation_kernel=kern,
+                                   engine_options={L.OPT_SEPARABLE: int(sep)})
         h.reset_phase(synth.seed_phase(50, slm_shape))
         h.optimize("WGS-Kim", maxiter=6, verbose=False, fix_phase_iteration=3)
         return h

@@ -618,10 +618,10 @@ def test_get_farfield_shape_kernel_affine():
 
 # ---- sparse targets: only the columns that hold a weight / target are transformed -------------------------
 @pytest.mark.parametrize("method,kw", [("WGS-Leonardo", {}), ("WGS-Kim", {"fix_phase_iteration": 3}), ("GS", {})])
-def test_sparse_column_path_matches_dense_path(method, kw, monkeypatch):
+def test_sparse_column_path_matches_dense_path(method, kw):
     """
     4096^2 pad, 300 spots at scattered positions (not a grid): the active-column path (default) against
-    the same engine with HGS_SPARSE=0.  Kim walks dense (phase_ff stored) -> sparse (fixed phase);
+    the same engine with HGS_OPT_SPARSE_COLUMNS = 0.  Kim walks dense (phase_ff stored) -> sparse (fixed phase);
     statistics ride along in both.
     """
     shape, slm = (4096, 4096), (1152, 1920)
@@ -631,8 +631,8 @@ def test_sparse_column_path_matches_dense_path(method, kw, monkeypatch):
     amp = 0.5 + synth.uniform01(78, (xy.shape[1],), 0)
 
     def run(sparse):
-        monkeypatch.setenv("HGS_SPARSE", "1" if sparse else "0")
-        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(79, slm))
+        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(79, slm),
+                         engine_options={L.OPT_SPARSE_COLUMNS: int(sparse)})
         h.optimize(method, maxiter=7, verbose=False, stat_groups=["computational"], **kw)
         h.optimize(method, maxiter=2, verbose=False, **kw)          # state persists; plain fused call
         return h
@@ -657,11 +657,11 @@ def test_sparse_column_path_matches_dense_path(method, kw, monkeypatch):
     ("WGS-Leonardo", "external_spot", {}),
     ("WGS-Kim", "computational", {"fix_phase_iteration": 3}),
 ])
-def test_sparse_spot_feedback_matches_general_path(method, feedback, kw, monkeypatch):
+def test_sparse_spot_feedback_matches_general_path(method, feedback, kw):
     """
     Spot feedback on a 4096^2 pad (scattered spots): the sparse path -- forward transform of the spot
     columns dilated by the integration window, N-vector rule, fused constraint + inverse over the spot
-    columns -- against the general (materialising) path of the same engine (HGS_SPARSE=0), with both
+    columns -- against the general (materialising) path of the same engine (HGS_OPT_SPARSE_COLUMNS = 0), with both
     statistics groups recorded in the loop and a plain call afterwards.
     """
     shape, slm = (4096, 4096), (1152, 1920)
@@ -671,8 +671,8 @@ def test_sparse_spot_feedback_matches_general_path(method, feedback, kw, monkeyp
     amp = 0.5 + synth.uniform01(88, (xy.shape[1],), 0)
 
     def run(sparse):
-        monkeypatch.setenv("HGS_SPARSE", "1" if sparse else "0")
-        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(89, slm))
+        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(89, slm),
+                         engine_options={L.OPT_SPARSE_COLUMNS: int(sparse)})
         if feedback == "external_spot":
             h.external_spot_amp = h.spot_amp * (1 + 0.2 * (synth.uniform01(90, (len(h),), 5) - 0.5))
         h.optimize(method, maxiter=6, verbose=False, feedback=feedback, stat_groups=["computational", "computational_spot"], **kw)
@@ -726,11 +726,11 @@ def test_batch_with_different_sparse_targets_full_size():
                                          ((2048, 2048), (1080, 1920), 45), ((1024, 2048), (500, 1000), 9)])
 @pytest.mark.parametrize("method,feedback", [("WGS-Kim", "computational"), ("WGS-Leonardo", "computational_spot"),
                                              ("WGS-Nogrette", "computational")])
-def test_sparse_paths_small_grids(shape, slm, n, method, feedback, monkeypatch):
+def test_sparse_paths_small_grids(shape, slm, n, method, feedback):
     """
     Column lists on grids where a workgroup pass handles 2 or 4 columns side by side (Ph < 4096): odd
     numbers of active columns leave lane groups past the end of the list, which must run on zeros
-    and store nothing.  Sparse path vs the same engine with HGS_SPARSE=0.
+    and store nothing.  Sparse path vs the same engine with HGS_OPT_SPARSE_COLUMNS = 0.
     """
     xs = 8 + 4 * np.floor((shape[1] / 4 - 4) * synth.uniform01(97, (n,), 0))
     ys = 8 + 4 * np.floor((shape[0] / 4 - 4) * synth.uniform01(97, (n,), 1))
@@ -738,8 +738,8 @@ def test_sparse_paths_small_grids(shape, slm, n, method, feedback, monkeypatch):
     kw = {"fix_phase_iteration": 2} if method == "WGS-Kim" else {}
 
     def run(sparse):
-        monkeypatch.setenv("HGS_SPARSE", "1" if sparse else "0")
-        h = SpotHologram(shape, xy, basis="knm", slm_shape=slm, phase=synth.seed_phase(98, slm))
+        h = SpotHologram(shape, xy, basis="knm", slm_shape=slm, phase=synth.seed_phase(98, slm),
+                         engine_options={L.OPT_SPARSE_COLUMNS: int(sparse)})
         h.optimize(method, maxiter=5, verbose=False, feedback=feedback, stat_groups=["computational", "computational_spot"], **kw)
         h.optimize(method, maxiter=2, verbose=False, feedback=feedback, **kw)
         return h
