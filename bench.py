@@ -2,30 +2,52 @@
 """
 Benchmark of the hologram optimize() hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|...] [--batch B]
 
-A *step* is one WGS iteration (nearfield -> farfield -> constraint/weight update -> nearfield) of
-BASELINE.json config 2: SpotHologram, 32x32 spots (pitch 64 px) on a 4096 x 4096 padded grid,
-SLM 1152 x 1920, WGS-Leonardo, fp32, synthetic seed phase, state resident in HBM.  Each rank owns
-``--batch`` independent holograms (weak scaling); the only collective is the final
-all-gather of the phase masks (reported as gather_ms, outside the timed region).
+A *step* is one loop body of optimize_gs (nearfield -> farfield -> constraint / weight update ->
+nearfield) of the named workload, state resident in HBM when the timed region starts.  The default
+workload is BASELINE.json config 2 (the configuration the metric is quoted on): SpotHologram, 32 x 32
+spots (pitch 64 px) on a 4096 x 4096 padded grid, SLM 1152 x 1920, WGS-Leonardo, fp32.  Each rank owns
+``--batch`` independent holograms (weak scaling; ``--workload cfg3`` = cfg 2 with 8 per
+GPU); the only collective is the final all-gather of the phase masks (reported as gather_ms, outside
+the timed region, fed straight from device memory).
 
-The headline is timed with the dense kernels forced (every farfield column transformed, as the
-canonical byte count assumes); the engine's default for spot targets -- transform only the columns
-that hold a spot, identical results -- is timed in an extra pass and reported as
-``engine_default_path``.
+Workloads (``--workload``):
+  cfg2       headline (above)                 cfg3      the same with --batch 8
+  cfg2dense  cfg 2 geometry, dense random image target (nothing to skip)
+  cfg4       CompressedSpotHologram, 1e4 spots, SLM 1152 x 1920, D = 2, WGS-Kim (cfg4d3: D = 3) -- MFMA bound
+  cfg5mraf   Hologram with MRAF (NaN noise box 3072^2, image 2048^2) on an 8192^2 pad; --dtype f32|f64,
+             --method GS|WGS-Leonardo
+  cfg5pad / hd / small   spot arrays on 8192^2 / 2048^2 (1080 x 1920 SLM) / 1024^2 pads
 
-Rank 0 prints one JSON line: metric/value (whole-job iterations/s), plus
-  roofline      the dominant kernel (fused column kernel) against the 8 TB/s HBM peak:
-                ALGORITHMIC bytes per launch (44 * P * r * batch) / its mean duration,
-                measured here with HIP events on the engine stream in a second pass of K steps;
-  cpu_baseline  the CPU oracle (NumPy restatement of the reference path, kind "port") timed on
-                this box's host cores on a bounded sample of the same workload (rank 0, N = 1).
+For spot workloads the headline is timed with the dense kernels forced (every farfield column
+transformed); the engine's default for spot targets -- transform only the columns that hold a spot,
+identical results -- is timed in an extra pass and reported as ``engine_default_path``.
+
+Rank 0 prints one JSON line: metric / value (whole-job iterations/s) plus
+  roofline      the dominant kernel against its bound.  HBM-bound kernels: ``achieved`` = the bytes this
+                kernel moves across the fabric per launch (its own loads + stores, stated in
+                ``bytes_model``) / its mean launch duration, measured here with HIP
+                events on the engine stream over a second pass of the K steps; ``frac`` = achieved / 8 TB/s.
+                ``canonical_equivalent`` restates the same duration against SURVEY 8(d)'s un-pruned byte
+                count (a throughput figure: it exceeds the peak when pruning skips bytes).  ``traffic`` is
+                measured in this run: bench.py re-runs a short pass of itself under
+                ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` (separate passes; FETCH_SIZE x 2 on
+                gfx950 as MI355X_MICROARCH.md prescribes) and reports the per-launch mean of the same kernel;
+                null (with ``traffic_note``) when rocprofv3 is unavailable or --pmc 0.
+                cfg4: bound "mfma", flop = 8 N S per GEMM launch against the 157.3 TFLOP/s fp32 matrix peak.
+  cpu_baseline  the CPU oracle (NumPy restatement of the reference path, kind "port") timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N = 1).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,15 +55,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12  # bytes/s, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12          # bytes/s, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12   # flop/s, dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MALL_BYTES = 256 * 2 ** 20
 
-WORKLOADS = {
+SPOT_WORKLOADS = {
     # name: (padded shape, slm shape, spot grid, pitch)
     "cfg2": ((4096, 4096), (1152, 1920), (32, 32), (64, 64)),
+    "cfg3": ((4096, 4096), (1152, 1920), (32, 32), (64, 64)),
     "small": ((1024, 1024), (288, 480), (16, 16), (32, 32)),
     "hd": ((2048, 2048), (1080, 1920), (16, 16), (64, 64)),        # a 1920x1080 SLM at padding_order = 1
     "cfg5pad": ((8192, 8192), (1152, 1920), (32, 32), (128, 128)),
 }
+IMAGE_WORKLOADS = {"cfg2dense": ((4096, 4096), (1152, 1920)), "cfg5mraf": ((8192, 8192), (1152, 1920))}
+COMPRESSED_WORKLOADS = {"cfg4": 2, "cfg4d3": 3}
+ALL_WORKLOADS = sorted(list(SPOT_WORKLOADS) + list(IMAGE_WORKLOADS) + list(COMPRESSED_WORKLOADS))
 
 
 def parse():
@@ -49,10 +77,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1, help="independent holograms per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--method", default="WGS-Leonardo")
-    ap.add_argument("--cpu-iters", type=int, default=16, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--batch", type=int, default=None, help="independent holograms per GPU (cfg3: 8)")
+    ap.add_argument("--workload", default="cfg2", choices=ALL_WORKLOADS)
+    ap.add_argument("--method", default=None)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--spots", type=int, default=10000, help="cfg4: number of spots")
+    ap.add_argument("--cpu-iters", type=int, default=None, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (self-test)")
     ap.add_argument("--sparse-columns", type=int, default=0,
@@ -60,33 +90,294 @@ def parse():
                          "force the dense kernels (every farfield column transformed) for the headline and "
                          "report the default path separately")
     ap.add_argument("--no-extra-pass", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--pmc", type=int, default=None, help="1: measure roofline.traffic with rocprofv3 PMC child passes "
+                                                          "(default: on for one rank, off otherwise)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--opt", action="append", default=[], help="engine option NAME=VALUE (hgs_set_option), e.g. "
+                                                               "TILE_KERNEL=0")
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 8 if a.workload == "cfg3" else 1
+    if a.method is None:
+        a.method = "WGS-Kim" if a.workload in COMPRESSED_WORKLOADS else "WGS-Leonardo"
+    return a
 
 
-def build_problem(workload, rank, batch):
+# ---------------------------------------------------------------------------------------------------
+# problems: each exposes warm(n), run(n) -> milliseconds (HIP events on the engine stream), engine
+# ---------------------------------------------------------------------------------------------------
+class GridProblem:
+    """DFT-grid workloads through HologramBatch (one engine, --batch holograms in grid.y)."""
+
+    def __init__(self, args, rank, local_rank):
+        from slmsuite_amd import synth
+        from slmsuite_amd.batch import HologramBatch
+        from slmsuite_amd.holography.algorithms import SpotHologram
+        self.args = args
+        self.np_dtype = np.float32 if args.dtype == "f32" else np.float64
+        w = args.workload
+        self.flags = {}
+        if w in SPOT_WORKLOADS:
+            self.shape, self.slm, grid, pitch = SPOT_WORKLOADS[w]
+            host = SpotHologram.make_rectangular_array(self.shape, grid, pitch, basis="knm", slm_shape=self.slm,
+                                                       phase=synth.seed_phase(2, self.slm), dtype=self.np_dtype)
+            target, kw = host.target, dict(spot_index=host.spot_knm_rounded, spot_amp=host.spot_amp)
+            self.n_targets = grid[0] * grid[1]
+            self.sparse_target = True
+            self.desc = f"SpotHologram {grid} spots, pitch {pitch}"
+        else:
+            self.shape, self.slm = IMAGE_WORKLOADS[w]
+            n = self.shape[0]
+            if w == "cfg5mraf":
+                target = np.zeros(self.shape, dtype=self.np_dtype)
+                a, b = (n - 3072) // 2, (n + 3072) // 2
+                target[a:b, a:b] = np.nan
+                a, b = (n - 2048) // 2, (n + 2048) // 2
+                target[a:b, a:b] = synth.random_target(5, (b - a, b - a), 0.2, 1.0, dtype=self.np_dtype)
+                self.flags = {"mraf_factor": 0.5}
+                self.n_targets = 2048 * 2048
+                self.desc = "Hologram MRAF (mraf_factor 0.5; NaN noise box 3072^2, image 2048^2)"
+            else:
+                target = synth.random_target(11, self.shape, 0.2, 1.0, dtype=self.np_dtype)
+                self.n_targets = n * n
+                self.desc = "Hologram, dense random image target"
+            kw = {}
+            self.sparse_target = False
+        phases = np.stack([synth.seed_phase(1000 * rank + 2 + i, self.slm, dtype=self.np_dtype) for i in range(args.batch)])
+        self.hb = HologramBatch(self.shape, self.slm, target, phases, dtype=self.np_dtype, device=local_rank, **kw)
+        self.engine = self.hb.engine
+        self.mraf = self.hb.mraf
+
+    def warm(self, n):
+        self.hb.time_iterations(self.args.method, max(1, n), **self.flags)
+
+    def run(self, n):
+        return self.hb.time_iterations(self.args.method, n, **self.flags)
+
+    def phases_device(self, torch, device):
+        t = torch.empty((self.args.batch,) + tuple(self.slm), dtype=torch.float32 if self.args.dtype == "f32" else torch.float64,
+                        device=torch.device("cuda", device))
+        self.hb.phases_into_device(t.data_ptr(), t.numel() * t.element_size())
+        return t
+
+    def close(self):
+        self.hb.close()
+
+    # ---- byte models (DESIGN.md section 4) ----
+    def bytes_models(self):
+        Ph, Pw = self.shape
+        Sh, Sw = self.slm
+        P, S = Ph * Pw, Sh * Sw
+        r = 4 if self.args.dtype == "f32" else 8
+        c = 2 * r
+        B = self.args.batch
+        m = self.args.method
+        wgs = m != "GS"
+        gh = Sh * Pw * c                              # half-transformed field: SLM rows only
+        w_write = (P * r) if not self.sparse_target else self.n_targets * 16 * r   # changed 16-value lane groups only
+        col = 2 * gh + P * r + (P * r if (wgs or self.mraf) else 0) + (w_write if wgs else 0)
+        passes = 1
+        if self.mraf and wgs:
+            # two column passes: forward + weight rule (reads GH, w, t; writes w), then forward + rebuild + inverse
+            col = (gh + 2 * P * r + w_write) + (2 * gh + 2 * P * r)
+            passes = 2
+        row = 2 * gh                                  # MODE 2 (between fused iterations): H read, G written
+        canon_col = (4 * P * c + (3 if wgs else 1) * P * r)
+        canon_iter = ((15 if wgs else 13) * P + 2 * S) * r
+        ws = gh + P * r * (2 if (wgs or self.mraf) else 1)           # GH + weights (+ target)
+        return dict(col=col * B, col_passes=passes, row=row * B, canon_col=canon_col * B, canon_iter=canon_iter * B,
+                    working_set=ws * B,
+                    col_model=f"GH tile read + write (2 x Sh*Pw*{c} B) + weights read (P*{r}) + "
+                              f"{'target read (P*%d) + ' % r if (wgs or self.mraf) else ''}"
+                              f"weight writes where a weight changed ({w_write} B)"
+                              + ("; MRAF with a weight update = two column passes" if passes == 2 else ""),
+                    row_model=f"H read + G written, SLM rows only (2 x Sh*Pw*{c} B); the phase itself is only "
+                              "written by the last row launch of a call")
+
+
+class CompressedProblem:
+    """cfg 4: CompressedSpotHologram at SLM size, separable bases on the matrix cores."""
+
+    def __init__(self, args, rank, local_rank):
+        from slmsuite_amd import synth
+        from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
+        from slmsuite_amd.holography.algorithms import CompressedSpotHologram
+        if args.batch != 1:
+            raise SystemExit("cfg4 runs one hologram per GPU")
+        if local_rank != 0:
+            raise SystemExit("cfg4 is a single-GPU workload")
+        self.args = args
+        self.D = COMPRESSED_WORKLOADS[args.workload]
+        self.slm = (1152, 1920)
+        self.N = args.spots
+        self.v = compressed_spots(self.D, self.N)
+        slm = SimpleSLM(self.slm, pitch_um=(8, 8), wav_um=0.78)
+        self.h = CompressedSpotHologram(self.v, basis="kxy", cameraslm=SimpleFourierSLM(slm),
+                                        dtype=np.float32 if args.dtype == "f32" else np.float64)
+        self.h.reset_phase(synth.seed_phase(4, self.slm))
+        self.engine = self.h._get_engine()
+        self.desc = f"CompressedSpotHologram {self.N} spots, D = {self.D}"
+        self.warmed = False
+
+    def warm(self, n):
+        self.h.optimize(self.args.method, maxiter=max(1, n), verbose=False)
+        self.engine = self.h._get_engine()
+
+    def run(self, n):
+        e = self.h._get_engine()
+        st = self.h._make_step()
+        ms = e.iterate_timed(st, n)
+        self.h.iter = st.iter
+        self.h.flags["fixed_phase"] = bool(st.fixed_phase)
+        self.h._mark_device_fresh(["phase", "weights"])
+        return ms
+
+    def close(self):
+        self.h._release_engine()
+
+
+def compressed_spots(D, N):
     from slmsuite_amd import synth
-    from slmsuite_amd.holography.algorithms import SpotHologram
-    shape, slm, grid, pitch = WORKLOADS[workload]
-    host = SpotHologram.make_rectangular_array(shape, grid, pitch, basis="knm", slm_shape=slm,
-                                               phase=synth.seed_phase(2, slm))
-    phases = np.stack([synth.seed_phase(1000 * rank + 2 + i, slm) for i in range(batch)])
-    return shape, slm, host, phases
+    v = synth.uniform01(4, (D, N), 9) * 2 - 1
+    v[:2] *= 0.02
+    if D == 3:
+        v[2] *= 1e-6
+    return v
 
 
-def cpu_baseline(workload, iters):
-    """The CPU oracle on a bounded sample: `iters` loop bodies of the same workload, one core."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on a bounded sample of the same workload
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(args):
     from oracle import hgs_oracle as orc          # checker / baseline only; never the product path
     from slmsuite_amd import synth
-    shape, slm, grid, pitch = WORKLOADS[workload]
-    o = orc.OracleSpotHologram(shape, orc.rectangular_array(shape, grid, pitch), slm_shape=slm,
-                               phase=synth.seed_phase(2, slm))
-    o.optimize("WGS-Leonardo", maxiter=1, populate=False)      # warm the caches / first-touch pages
+    w = args.workload
+    dt = np.float32 if args.dtype == "f32" else np.float64
+    cores_note = f"NumPy {np.__version__}, {os.cpu_count()} host cores visible, 1 used"
+    if w in SPOT_WORKLOADS:
+        iters = args.cpu_iters if args.cpu_iters is not None else (16 if SPOT_WORKLOADS[w][0][0] <= 4096 else 4)
+        if iters <= 0:
+            return None
+        shape, slm, grid, pitch = SPOT_WORKLOADS[w]
+        o = orc.OracleSpotHologram(shape, orc.rectangular_array(shape, grid, pitch), slm_shape=slm,
+                                   phase=synth.seed_phase(2, slm), dtype=dt)
+        flags = {}
+        sample = f"{iters} {args.method} loop bodies of {w} (one hologram)"
+    elif w in IMAGE_WORKLOADS:
+        iters = args.cpu_iters if args.cpu_iters is not None else (12 if w == "cfg2dense" else 3)
+        if iters <= 0:
+            return None
+        shape, slm = IMAGE_WORKLOADS[w]
+        n = shape[0]
+        if w == "cfg5mraf":
+            t = np.zeros(shape, dtype=dt)
+            a, b = (n - 3072) // 2, (n + 3072) // 2
+            t[a:b, a:b] = np.nan
+            a, b = (n - 2048) // 2, (n + 2048) // 2
+            t[a:b, a:b] = synth.random_target(5, (b - a, b - a), 0.2, 1.0, dtype=dt)
+            flags = {"mraf_factor": 0.5}
+        else:
+            t = synth.random_target(11, shape, 0.2, 1.0, dtype=dt)
+            flags = {}
+        o = orc.OracleHologram(t, phase=synth.seed_phase(2, slm, dtype=dt), slm_shape=slm, dtype=dt)
+        sample = f"{iters} {args.method} loop bodies of {w} (one hologram)"
+    else:
+        # cfg 4: the oracle holds the dense N x S kernel matrix -- time a subset of the spots and scale
+        # linearly in N (both directions are N x S contractions)
+        iters = args.cpu_iters if args.cpu_iters is not None else 5
+        if iters <= 0:
+            return None
+        from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
+        from slmsuite_amd.holography import toolbox
+        D = COMPRESSED_WORKLOADS[w]
+        n_s = 96
+        slm_shape = (1152, 1920)
+        slm = SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78)
+        v = compressed_spots(D, args.spots)[:, :n_s]
+        zern, _ = toolbox.convert_vector_zernike(v, "kxy", SimpleFourierSLM(slm))
+        xg, yg = toolbox.process_grid(slm)
+        sc = slm.get_source_zernike_scaling()
+        sx, sy = (sc, sc) if np.isscalar(sc) else (sc[0], sc[1])
+        o = orc.OracleCompressedSpotHologram(zern, np.asarray(xg) * sx, np.asarray(yg) * sy,
+                                             phase=synth.seed_phase(4, slm_shape), dtype=dt)
+        o.kernel()                                  # the reference caches K too (_spots.py:595-636)
+        o.optimize(args.method, maxiter=1, populate=False)
+        t0 = time.perf_counter()
+        o.optimize(args.method, maxiter=iters, populate=False)
+        dtm = time.perf_counter() - t0
+        per = dtm / iters * (args.spots / n_s)
+        return {"value": 1.0 / per, "unit": "iterations/s", "cores": 1, "kind": "port",
+                "sample": f"{iters} {args.method} loop bodies on {n_s} of the {args.spots} spots (cached kernel matrix), "
+                          f"scaled linearly to {args.spots} spots ({cores_note}), {dtm:.1f} s"}
+    o.optimize(args.method, maxiter=1, populate=False, **flags)      # warm the caches / first-touch pages
     t0 = time.perf_counter()
-    o.optimize("WGS-Leonardo", maxiter=iters, populate=False)
-    dt = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{iters} WGS-Leonardo loop bodies of {workload} (NumPy {np.__version__}, "
-                      f"{os.cpu_count()} host cores visible, 1 used), {dt:.1f} s"}
+    o.optimize(args.method, maxiter=iters, populate=False, **flags)
+    dtm = time.perf_counter() - t0
+    return {"value": iters / dtm, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{sample} ({cores_note}), {dtm:.1f} s"}
+
+
+# ---------------------------------------------------------------------------------------------------
+# PMC traffic, measured in this run: child passes of this script under rocprofv3
+# ---------------------------------------------------------------------------------------------------
+def pmc_traffic(args, kernel_substrings):
+    """
+    Mean FETCH_SIZE / WRITE_SIZE per launch of the kernels whose name contains one of ``kernel_substrings``
+    (dict label -> substring).  Two child runs (the two counters do not fit one pass).  Returns
+    ({label: {"fetch": bytes, "write": bytes, "launches": n}}, note).
+    """
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--batch", str(args.batch),
+             "--method", args.method, "--dtype", args.dtype, "--steps", "12", "--warmup", "3", "--spots", str(args.spots),
+             "--sparse-columns", str(args.sparse_columns)]
+    for o in args.opt:
+        child += ["--opt", o]
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    out = {k: {"fetch": None, "write": None, "launches": 0} for k in kernel_substrings}
+    names = {}
+    for counter, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        d = tempfile.mkdtemp(prefix="hgs_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([exe, "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): " + p.stdout.decode(errors="replace")[-300:]
+            acc = {k: [0.0, 0] for k in kernel_substrings}
+            for path in files:
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        kn = row.get("Kernel_Name", "")
+                        for label, sub in kernel_substrings.items():
+                            if sub in kn:
+                                acc[label][0] += float(row.get("Counter_Value", 0) or 0)
+                                acc[label][1] += 1
+                                names[label] = kn
+            for label, (tot, n) in acc.items():
+                if n:
+                    # rocprofv3 reports KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950 (x 2, guide)
+                    out[label][key] = tot / n * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+                    out[label]["launches"] = n
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for label in out:
+        out[label]["kernel_name"] = names.get(label)
+    return out, ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this run (12 steps each); FETCH_SIZE x 2 "
+                 "(gfx950 half-count), WRITE_SIZE as reported; the fabric counters include Infinity-Cache hits")
+
+
+def apply_opts(engine, opts):
+    from slmsuite_amd import _lib as L
+    for o in opts:
+        name, val = o.split("=")
+        engine.set_option(getattr(L, "OPT_" + name.upper()), int(val))
 
 
 def main():
@@ -96,7 +387,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1 or args.force_dist:
+    if (world > 1 or args.force_dist) and not args.pmc_child:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -104,24 +395,30 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
 
     from slmsuite_amd import _lib as L
-    from slmsuite_amd.batch import HologramBatch
 
-    shape, slm, host, phases = build_problem(args.workload, rank, args.batch)
-    hb = HologramBatch(shape, slm, host.target, phases, device=local_rank,
-                       spot_index=host.spot_knm_rounded, spot_amp=host.spot_amp)
+    compressed = args.workload in COMPRESSED_WORKLOADS
+    prob = (CompressedProblem if compressed else GridProblem)(args, rank, local_rank)
+    apply_opts(prob.engine, args.opt)
+    spot = args.workload in SPOT_WORKLOADS
 
     def barrier():
-        hb.engine.sync()
+        prob.engine.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    hb.engine.set_option(L.OPT_SPARSE_COLUMNS, args.sparse_columns)
+    if spot:
+        prob.engine.set_option(L.OPT_SPARSE_COLUMNS, args.sparse_columns)
     # warmup (also takes the hologram past iteration 0 so every timed step updates weights)
-    hb.time_iterations(args.method, max(1, args.warmup))
+    prob.warm(args.warmup)
+    if args.pmc_child:                       # profiled child of pmc_traffic(): just launch the kernels
+        prob.run(args.steps)
+        prob.engine.sync()
+        prob.close()
+        return
     barrier()
     t0 = time.perf_counter()
-    ms_events = hb.time_iterations(args.method, args.steps)
+    ms_events = prob.run(args.steps)
     barrier()
     wall = time.perf_counter() - t0
     tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -132,87 +429,117 @@ def main():
     # roofline pass: same K steps again with per-launch HIP events on the engine stream
     prof = None
     if not args.no_roofline_pass:
-        hb.engine.profile_enable(True)
-        hb.time_iterations(args.method, args.steps)
-        prof = hb.engine.profile_read()
-        hb.engine.profile_enable(False)
+        prob.engine.profile_enable(True)
+        prob.run(args.steps)
+        prof = prob.engine.profile_read()
+        prob.engine.profile_enable(False)
 
-    # the engine's default for this workload: only the columns that hold a spot are transformed
-    sparse_ms = None
-    if not args.no_extra_pass and not args.sparse_columns:
-        hb.engine.set_option(L.OPT_SPARSE_COLUMNS, 1)
-        hb.time_iterations(args.method, max(1, args.warmup))
-        sparse_ms = hb.time_iterations(args.method, args.steps)
-        sprof = None
+    # the engine's default for spot targets: only the columns that hold a spot are transformed
+    sparse_ms, sprof = None, None
+    if spot and not args.no_extra_pass and not args.sparse_columns:
+        prob.engine.set_option(L.OPT_SPARSE_COLUMNS, 1)
+        prob.warm(args.warmup)
+        sparse_ms = prob.run(args.steps)
         if not args.no_roofline_pass:
-            hb.engine.profile_enable(True)
-            hb.time_iterations(args.method, args.steps)
-            sprof = hb.engine.profile_read()
-            hb.engine.profile_enable(False)
-        hb.engine.set_option(L.OPT_SPARSE_COLUMNS, 0)
+            prob.engine.profile_enable(True)
+            prob.run(args.steps)
+            sprof = prob.engine.profile_read()
+            prob.engine.profile_enable(False)
+        prob.engine.set_option(L.OPT_SPARSE_COLUMNS, 0)
 
-    # final gather of the phase masks over RCCL, timed separately
+    # final gather of the phase masks over RCCL, device memory -> RCCL, timed separately
     gather_ms = None
-    if dist is not None:
-        ph = torch.from_numpy(hb.phases()).cuda()
-        out = [torch.empty_like(ph) for _ in range(world)]
+    if dist is not None and not compressed:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        ph = prob.phases_device(torch, local_rank)
+        out = [torch.empty_like(ph) for _ in range(world)]
         dist.all_gather(out, ph)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
-        P = shape[0] * shape[1]
-        S = slm[0] * slm[1]
-        r = 4
         iters_total = world * args.batch * args.steps
         value = iters_total / wall
-        bytes_iter = (15 * P + 2 * S) * r            # canonical B_WGS
+        want_pmc = args.pmc if args.pmc is not None else (1 if (world == 1 and dist is None) else 0)
         roof = None
-        if prof is not None and prof["col_fused"]["launches"] > 0:
-            col = prof["col_fused"]
-            dur = col["ms"] * 1e-3 / col["launches"]
-            alg = 44 * P * args.batch                  # 4*P*c + 3*P*r bytes per launch
-            achieved = alg / dur
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc) and args.workload == "cfg2" and args.batch == 1 and args.method == "WGS-Leonardo":
-                try:
-                    traffic = json.load(open(pmc)).get("col_fused_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            rowk = prof["row"]
-            roof = {"bound": "hbm", "kernel": "fused column kernel (col_tile_kernel<float,N,PHASE,6> / col_fused_kernel)",
-                    "achieved": achieved / 1e9,
-                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                    "launch_us": dur * 1e6, "launches": col["launches"],
-                    "algorithmic_bytes_per_launch": alg,
-                    "row_kernel_us": rowk["ms"] * 1e3 / max(1, rowk["launches"]),
-                    "iteration": {"algorithmic_bytes": bytes_iter * args.batch,
-                                  "achieved": bytes_iter * args.batch * (args.steps / (ms_events * 1e-3)) / 1e9,
-                                  "frac": bytes_iter * args.batch * (args.steps / (ms_events * 1e-3)) / HBM_PEAK,
-                                  # what the pruned/fused design actually moves per iteration:
-                                  # GH read+write by both kernels, weights r/w, target r, phase w
-                                  "designed_bytes": (4 * 8 * slm[0] * shape[1] + 3 * 4 * P + 4 * S) * args.batch},
+        if compressed and prof is not None:
+            # dominant kernel: the two complex GEMMs (cgemm_kouter), timed under col_fwd / col_inv together with
+            # their small helper kernels; flop per GEMM launch = 8 N S (complex MAC = 8 real flop)
+            S = prob.slm[0] * prob.slm[1]
+            flop_launch = 8.0 * prob.N * S
+            n_l = prof["col_fwd"]["launches"] + prof["col_inv"]["launches"]
+            dur = (prof["col_fwd"]["ms"] + prof["col_inv"]["ms"]) * 1e-3 / max(1, n_l)
+            ach = flop_launch / dur
+            roof = {"bound": "mfma", "kernel": "cgemm_kouter (complex fp32 GEMM, v_mfma_f32_32x32x2_f32) + its table/contraction helpers, "
+                                               "one timed unit per transform direction",
+                    "achieved": ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK,
+                    "traffic": None, "traffic_note": "matrix-core bound; HBM traffic not the limiter (tables 153 + 153 + 92 MB)",
+                    "flop_per_launch": flop_launch, "launch_us": dur * 1e6, "launches": n_l,
+                    "iteration": {"flop": 2 * flop_launch, "achieved": 2 * flop_launch * args.steps / (ms_events * 1e-3) / 1e12,
+                                  "frac": 2 * flop_launch * args.steps / (ms_events * 1e-3) / MFMA_F32_PEAK},
+                    "timing": "HIP events per transform on the engine stream, second pass of K steps"}
+        elif prof is not None and prof["col_fused"]["launches"] > 0:
+            bm = prob.bytes_models()
+            col, rowk = prof["col_fused"], prof["row"]
+            # MRAF + weight update launches two column passes per iteration: time and bytes are per iteration there
+            per = bm["col_passes"]
+            dur = col["ms"] * 1e-3 / col["launches"] * per
+            achieved = bm["col"] / dur
+            row_dur = rowk["ms"] * 1e-3 / max(1, rowk["launches"])
+            traffic, tnote, tr_row = None, "--pmc 0", None
+            if want_pmc:
+                subs = {"col": "col_tile_kernel" if "tile" in col_kernel_name(args, prob) else "col_fused_kernel",
+                        "row": "row_kernel<" + ("float" if args.dtype == "f32" else "double") + f", {prob.shape[1]}, 2>"}
+                res, tnote = pmc_traffic(args, subs)
+                if res is not None and res["col"]["fetch"] is not None and res["col"]["write"] is not None:
+                    traffic = (res["col"]["fetch"] + res["col"]["write"]) * per
+                    tr_row = None if res["row"]["fetch"] is None else res["row"]["fetch"] + res["row"]["write"]
+                    tnote += f"; kernel = {res['col']['kernel_name']}"
+                elif res is not None:
+                    tnote = "kernel not found in the PMC pass: " + json.dumps(res)
+            iter_s = args.steps / (ms_events * 1e-3)
+            roof = {"bound": "hbm", "kernel": col_kernel_name(args, prob),
+                    "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                    "traffic": traffic, "traffic_note": tnote,
+                    "bytes_per_launch": bm["col"], "bytes_model": bm["col_model"],
+                    "launch_us": dur * 1e6, "launches": col["launches"] // per,
+                    "canonical_equivalent": {"bytes_per_launch": bm["canon_col"], "achieved": bm["canon_col"] / dur / 1e9,
+                                             "frac_of_peak": bm["canon_col"] / dur / HBM_PEAK,
+                                             "note": "SURVEY 8(d) un-pruned count 4*P*c + 3*P*r per column launch; a throughput "
+                                                     "equivalent, NOT bytes moved (rows outside the SLM are never stored)"},
+                    "working_set_bytes": bm["working_set"],
+                    "infinity_cache_resident": bool(bm["working_set"] <= MALL_BYTES),
+                    "infinity_cache_note": "FETCH_SIZE/WRITE_SIZE count fabric requests including Infinity-Cache (256 MiB) hits; "
+                                           "when the working set fits, true HBM-pin traffic is lower than `traffic`",
+                    "row_kernel": {"launch_us": row_dur * 1e6, "bytes_per_launch": bm["row"], "bytes_model": bm["row_model"],
+                                   "achieved": bm["row"] / row_dur / 1e9, "frac": bm["row"] / row_dur / HBM_PEAK,
+                                   "traffic": tr_row},
+                    "iteration": {"moved_bytes": bm["col"] + bm["row"],
+                                  "achieved": (bm["col"] + bm["row"]) * iter_s / 1e9,
+                                  "frac": (bm["col"] + bm["row"]) * iter_s / HBM_PEAK,
+                                  "canonical_bytes": bm["canon_iter"],
+                                  "canonical_equivalent_frac": bm["canon_iter"] * iter_s / HBM_PEAK},
                     "timing": "HIP events per launch on the engine stream, second pass of K steps"}
-        cpu = None
-        if world == 1 and args.cpu_iters > 0:
-            cpu = cpu_baseline(args.workload, args.cpu_iters)
+        cpu = cpu_baseline(args) if world == 1 else None
+        shape_txt = "" if compressed else f" padded to {prob.shape[0]}x{prob.shape[1]}"
         line = {
-            "metric": "WGS iterations/sec (4096^2 padded field)", "value": value, "unit": "iterations/s",
+            "metric": "WGS iterations/sec (4096^2 padded field)" if args.workload in ("cfg2", "cfg3") else
+                      f"{args.method} iterations/sec ({args.workload})",
+            "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: SpotHologram {WORKLOADS[args.workload][2]} spots, "
-                                   f"SLM {slm[0]}x{slm[1]} padded to {shape[0]}x{shape[1]}, {args.method}, fp32",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {prob.desc}, SLM {prob.slm[0]}x{prob.slm[1]}{shape_txt}, "
+                                   f"{args.method}, {'fp32' if args.dtype == 'f32' else 'fp64'}",
                        "holograms_per_gpu": args.batch, "parallelism": f"independent holograms x{world}"},
             "event_ms_per_step": ms_events / args.steps, "gather_ms": gather_ms,
-            "engine": hb.engine.version(),
+            "engine": prob.engine.version(),
             "roofline": roof, "cpu_baseline": cpu,
-            "column_mode": "sparse-aware (engine default)" if args.sparse_columns else
-                           "dense kernels forced (HGS_OPT_SPARSE_COLUMNS=0): all 4096 columns transformed",
         }
+        if spot:
+            line["column_mode"] = ("sparse-aware (engine default)" if args.sparse_columns else
+                                   "dense kernels forced (HGS_OPT_SPARSE_COLUMNS=0): every farfield column transformed")
         if sparse_ms is not None:
             line["engine_default_path"] = {
                 "what": "same workload with the engine default HGS_OPT_SPARSE_COLUMNS=1: only the farfield columns "
@@ -223,9 +550,21 @@ def main():
                 "row_kernel_us": None if sprof is None else sprof["row"]["ms"] * 1e3 / max(1, sprof["row"]["launches"]),
             }
         print(json.dumps(line))
-    hb.close()
+    prob.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def col_kernel_name(args, prob):
+    """Which fused column kernel the dense path launches for this geometry (engine.hip, iterate())."""
+    Ph = prob.shape[0]
+    T = Ph // 16
+    r0 = (Ph - prob.slm[0]) // 2
+    slots = (r0 + prob.slm[0] - 1) // T - r0 // T + 1
+    tile_off = any(o.upper().replace(" ", "") == "TILE_KERNEL=0" for o in args.opt)
+    if args.dtype == "f32" and Ph >= 4096 and slots <= 6 and not tile_off:
+        return f"col_tile_kernel<float, {Ph}, ...> (tile-resident fused column kernel)"
+    return f"col_fused_kernel<{'float' if args.dtype == 'f32' else 'double'}, {Ph}, ...> (per-column fused kernel)"
 
 
 if __name__ == "__main__":

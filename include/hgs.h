@@ -98,7 +98,8 @@ enum {
     /* kind 1 (CompressedSpotHologram); TARGET/WEIGHTS/PHASE_FF/FARFIELD/AMP_FF are [batch][n_spots] */
     HGS_XGRID = 13,       /* [slm_h][slm_w] real   slm.grid[0] * zernike scaling (_spots.py:614-618) */
     HGS_YGRID = 14,       /* [slm_h][slm_w] real   slm.grid[1] * zernike scaling                     */
-    HGS_MONOMIALS = 15,   /* int32 [n_monomials][2] (px, py)   phase._zernike_get_cantor terms       */
+    HGS_MONOMIALS = 15,   /* int32 [n_monomials][2] (px, py)   phase._zernike_get_cantor terms; the pseudo-term
+                             (-1, 0) is the vortex plate w * atan2(y, x), w > 0 only (phase.py:1783-1790)     */
     HGS_SPOT_COEFF = 16   /* real [n_monomials][n_spots]       ... and weights (phase.py:850-920)    */
 };
 

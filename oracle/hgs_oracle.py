@@ -658,13 +658,18 @@ def monomial_weights(basis, spot_zernike):
     """
     a = np.asarray(spot_zernike, dtype=float)
     acc = {}
+    special_terms, special_weights = [], []
     for d, idx in enumerate(np.ravel(basis)):
-        if int(idx) < 0:
-            raise NotImplementedError("vortex pseudo-index -1")
+        if int(idx) < 0:        # special (non-polynomial) indices ride behind the monomials, phase.py:909-918
+            special_terms.append((int(idx), 0))
+            special_weights.append(a[d])
+            continue
         for key, c in zernike_cartesian(int(idx)).items():
             acc[key] = acc.get(key, 0) + c * a[d]
     keys = sorted(acc, key=lambda k: cantor_pairing(*k))
-    return np.array(keys, dtype=int).reshape(-1, 2), np.array([acc[k] for k in keys], dtype=float).reshape(len(keys), -1)
+    terms = list(keys) + special_terms
+    rows = [acc[k] for k in keys] + special_weights
+    return np.array(terms, dtype=int).reshape(-1, 2), np.array(rows, dtype=float).reshape(len(terms), -1)
 
 
 def compressed_kernel(xg, yg, terms, weights, ctype):
@@ -679,6 +684,14 @@ def compressed_kernel(xg, yg, terms, weights, ctype):
     out = np.zeros((N,) + x.shape, dtype=ctype)
     w = weights.astype(ctype)
     for m, (px, py) in enumerate(terms):
+        if px < 0:              # phase.py:1783-1792: the vortex plate, positive charges only
+            if not (px == -1 and py == 0):
+                raise ValueError(f"Unrecognized terms {(px, py)} for index {m}.")
+            lg = np.arctan2(np.real(y), np.real(x))
+            for n in range(N):
+                if w[m, n] > 0:
+                    out[n] += w[m, n] * lg
+            continue
         mono = np.ones_like(x)
         for _ in range(px):
             mono *= x

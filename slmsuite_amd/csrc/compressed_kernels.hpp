@@ -52,7 +52,8 @@ constexpr int C_NC = 64;     // spots per cross-wave reduction round
 
 // Phase polynomial of spot n.  DEG 1/2: the host repacks the monomial weights into the canonical
 // order [1, x, y, x^2, xy, y^2] (coeff6[k][n], zero where a monomial is absent) so the evaluation is a
-// short Horner form with wave-uniform coefficients; DEG 0: arbitrary monomial list.
+// short Horner form with wave-uniform coefficients; DEG 0: arbitrary monomial list, including the
+// non-polynomial pseudo-term (-1, 0) (vortex plate).
 template <typename R, int DEG> struct SpotPoly {
     R c[6];
     __device__ __forceinline__ void load(const CArgs<R>& a, int n) {
@@ -77,6 +78,10 @@ template <typename R, int DEG> struct SpotPoly {
             for (int m = 0; m < a.M; ++m) {
                 const R cm = a.coeff[(size_t)m * a.N + n];
                 const int px = a.mono[2 * m], py = a.mono[2 * m + 1];
+                if (px < 0) {      // pseudo-term (-1, 0): vortex plate, positive charges only (phase.py:1783-1790)
+                    if (px == -1 && cm > (R)0) phi += cm * Math<R>::atan2(y, x);
+                    continue;
+                }
                 R v = 1;
                 for (int k = 0; k < px; ++k) v *= x;
                 for (int k = 0; k < py; ++k) v *= y;

@@ -327,9 +327,12 @@ template <typename R> struct Engine : EngineBase {
         const int M = cfg.n_monomials, N = cfg.n_spots;
         c_degree = 0;
         for (int m = 0; m < M; ++m) c_degree = std::max(c_degree, mono_host[2 * m] + mono_host[2 * m + 1]);
-        for (int m = 0; m < M; ++m)
-            if (mono_host[2 * m] < 0 || mono_host[2 * m + 1] < 0)
-                return fail(HGS_ERR_UNSUPPORTED, "negative monomial powers (vortex pseudo-term) are not supported");
+        for (int m = 0; m < M; ++m) {
+            const int px = mono_host[2 * m], py = mono_host[2 * m + 1];
+            if (px == -1 && py == 0) { c_degree = std::max(c_degree, 3); continue; }   // vortex plate: general kernels
+            if (px < 0 || py < 0)
+                return fail(HGS_ERR_ARG, "unrecognized term (%d, %d): the only pseudo-term is the vortex plate (-1, 0)", px, py);
+        }
         if (c_degree <= 2) {
             std::vector<R> c6((size_t)6 * N, (R)0);
             for (int m = 0; m < M; ++m) {

@@ -247,6 +247,32 @@ class Hologram:
         rng = np.random.default_rng()
         return rng.uniform(-np.pi, np.pi, self.slm_shape).astype(self.dtype)
 
+    def _get_target_moments_knm_norm(self):
+        """Centre and standard deviation of the target in knm pixels / shape (_hologram.py:480-500)."""
+        center, std = toolbox.image_center_and_std(self.target, nansum=True)
+        shape = np.flip(self.shape).astype(float)
+        return center / shape, std / shape
+
+    def _get_quadratic_initial_phase(self, scaling=1):
+        """
+        Lens + blaze that roughly spreads the source over the target (_hologram.py:502-527): the blaze steers to
+        the target's centroid, the lens matches its standard deviation to that of the source amplitude.
+        Needs an array-valued ``amp`` (the reference's image moments cannot take the scalar form either).
+        """
+        if np.isscalar(self.amp) or np.ndim(self.amp) != 2:
+            raise ValueError("quadratic_phase needs an array-valued source amplitude (amp= or an SLM)")
+        _, std_amp = toolbox.image_center_and_std(self.amp)
+        slm_shape = np.flip(self.slm_shape).astype(float)
+        std_amp = std_amp / slm_shape
+        center_knm_norm, std_knm_norm = self._get_target_moments_knm_norm()
+        h, w = self.slm_shape
+        x = ((np.arange(w, dtype=float) - float(w - 1) / 2).astype(self.dtype) / w).reshape(1, w)
+        y = ((np.arange(h, dtype=float) - float(h - 1) / 2).astype(self.dtype) / h).reshape(h, 1)
+        grid = (np.broadcast_to(x, (h, w)).astype(self.dtype), np.broadcast_to(y, (h, w)).astype(self.dtype))
+        with np.errstate(divide="ignore"):
+            f = np.reciprocal(scaling * slm_shape * std_knm_norm / std_amp)
+        return np.array(toolbox.blaze(grid, slm_shape * center_knm_norm) + toolbox.lens(grid, f), dtype=self.dtype)
+
     def reset_phase(self, custom_phase=None, random_phase=None, quadratic_phase=None):
         if custom_phase is not None:
             custom_phase = np.array(custom_phase, dtype=self.dtype)
@@ -260,7 +286,7 @@ class Hologram:
             random_phase = self.flags.get("random_phase", 1)
         ph = np.zeros(self.slm_shape, dtype=self.dtype)
         if quadratic_phase:
-            raise NotImplementedError("quadratic_phase preconditioning is outside the optimize() path of this build")
+            ph += self._get_quadratic_initial_phase(quadratic_phase)
         if random_phase:
             ph += random_phase * self._get_random_phase()
         self.phase = ph

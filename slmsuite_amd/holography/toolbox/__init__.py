@@ -229,18 +229,77 @@ def zernike_monomial_weights(indices, weights):
     """
     (terms [M,2] int, monomial weights [M,N]) such that sum_d weights[d,n] Z_indices[d](x, y) =
     sum_m out[m,n] x^terms[m,0] y^terms[m,1]; monomials in ascending Cantor order
-    (phase._zernike_get_cantor, phase.py:850-920).
+    (phase._zernike_get_cantor, phase.py:850-920).  Negative (special) indices are not polynomials: they
+    are appended after the monomials as pseudo-terms (index, 0) carrying their own weights (:909-918); the
+    only one the kernels know is -1, the vortex plate  w * atan2(y, x)  for w > 0 (phase.py:1783-1790).
     """
     a = np.asarray(weights, dtype=float)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
     acc = {}
+    special = []
     for d, idx in enumerate(np.ravel(indices)):
         if int(idx) < 0:
-            raise NotImplementedError("the vortex pseudo-index -1 is outside this build")
+            if int(idx) != -1:
+                raise ValueError(f"Unrecognized terms {(int(idx), 0)} for index {d}.")     # phase.py:1792
+            special.append(((int(idx), 0), a[d]))
+            continue
         for key, c in zernike_cartesian(int(idx)).items():
             acc[key] = acc.get(key, 0) + c * a[d]
     keys = sorted(acc, key=lambda k: (k[0] + k[1]) * (k[0] + k[1] + 1) // 2 + k[1])
-    return (np.array(keys, dtype=np.int32).reshape(-1, 2),
-            np.array([acc[k] for k in keys], dtype=float).reshape(len(keys), -1))
+    terms = [k for k in keys] + [k for k, _ in special]
+    rows = [acc[k] for k in keys] + [w for _, w in special]
+    return (np.array(terms, dtype=np.int32).reshape(-1, 2),
+            np.array(rows, dtype=float).reshape(len(terms), -1))
+
+
+def image_center_and_std(image, nansum=False):
+    """
+    (centre [x, y], standard deviation [x, y]) of one image in pixels on the CENTRED pixel grid
+    (x - (w - 1)/2): first moments and square roots of the second central moments of the image
+    normalised to unit sum, in float64 (analysis.image_positions / image_variances,
+    analysis/__init__.py:646-790, with the image_moment pixel-grid branch :531-545).
+    """
+    img = np.array(image, dtype=float)
+    if img.ndim != 2:
+        raise ValueError("moments need a 2-D image (the reference cannot unpack a scalar amplitude either)")
+    total = (np.nansum if nansum else np.sum)(img)
+    img = np.zeros_like(img) if total == 0 else img / total
+    add = np.nansum if nansum else np.sum
+    h, w = img.shape
+    x = (np.arange(w) - float(w - 1) / 2).reshape(1, w)
+    y = (np.arange(h) - float(h - 1) / 2).reshape(h, 1)
+    cx, cy = add(img * x), add(img * y)
+    vx, vy = add(img * np.square(x - cx)), add(img * np.square(y - cy))
+    return np.array([cx, cy]), np.sqrt(np.array([vx, vy]))
+
+
+def blaze(grid, vector):
+    """2 pi (kx x + ky y) on normalised grids (toolbox.phase.blaze, phase.py:20-75, same branch structure)."""
+    x_grid, y_grid = process_grid(grid)
+    vector = np.asarray(vector, dtype=np.float64)      # float64 scalars promote the products to float64 (NEP 50)
+    if vector[0] == 0 and vector[1] == 0:
+        return np.zeros_like(x_grid)
+    if vector[1] == 0:
+        return (2 * np.pi * vector[0]) * x_grid
+    if vector[0] == 0:
+        return (2 * np.pi * vector[1]) * y_grid
+    return (2 * np.pi * vector[0]) * x_grid + (2 * np.pi * vector[1]) * y_grid
+
+
+def lens(grid, f):
+    """pi (x^2 / fx + y^2 / fy) (toolbox.phase.lens, phase.py:397-452); scalar f = isotropic."""
+    x_grid, y_grid = process_grid(grid)
+    f = np.squeeze(np.array([f, f] if np.isscalar(f) else f, dtype=np.float64))   # float64 scalars: the sum is
+    if f.size != 2:                                                               # formed in float64 (NEP 50)
+        raise ValueError(f"Expected two terms in focal list. Found {f}.")
+    if np.any(f == 0):
+        raise ValueError(f"Cannot interpret a focal length of zero. Found {f}.")
+    if np.isfinite(f[0]) and np.isfinite(f[1]):
+        return (np.pi / f[0]) * np.square(x_grid) + (np.pi / f[1]) * np.square(y_grid)
+    if np.isfinite(f[1]):
+        return (np.pi / f[1]) * np.square(y_grid)
+    return np.zeros_like(x_grid)       # (the reference's x-only branch is unreachable, :447)
 
 
 def process_grid(grid):

@@ -1,0 +1,207 @@
+"""
+BASELINE.json configurations at their configured sizes (MI355X): cfg 2 through BOTH column paths (the
+engine default over the active-column list AND the dense kernels the bench headline times), its error
+distribution over eight seeds next to the reference's own sensitivity to a one-ulp change of the input,
+cfg 3 (eight holograms per engine at 4096^2), cfg 4 (CompressedSpotHologram, 1e4 spots at 1152 x 1920,
+checked against float64 direct summation on a sample of spots / pixels).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2, phase_rel_l2, report
+from oracle import hgs_oracle as orc
+from slmsuite_amd import _lib as L
+from slmsuite_amd import synth
+from slmsuite_amd.batch import HologramBatch
+from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
+from slmsuite_amd.holography.algorithms import CompressedSpotHologram, SpotHologram
+
+pytestmark = pytest.mark.gpu
+
+SHAPE, SLM = (4096, 4096), (1152, 1920)
+PATHS = {"default": {}, "dense": {L.OPT_SPARSE_COLUMNS: 0}, "dense-per-column": {L.OPT_SPARSE_COLUMNS: 0, L.OPT_TILE_KERNEL: 0}}
+
+
+def cfg2_hologram(seed, path, phase=None):
+    return SpotHologram.make_rectangular_array(SHAPE, (32, 32), (64, 64), basis="knm", slm_shape=SLM,
+                                               phase=synth.seed_phase(seed, SLM) if phase is None else phase,
+                                               engine_options=PATHS[path])
+
+
+# ---- cfg 2: every column path against the recorded reference run -------------------------------------------
+@pytest.mark.parametrize("path", list(PATHS))
+def test_cfg2_leonardo_every_column_path_matches_reference(path):
+    """
+    The headline (WGS-Leonardo x 50, seed 2) through the engine default (col_fused_kernel over the active
+    columns), the dense tile-resident kernel bench.py times (col_tile_kernel) and the dense per-column kernel:
+    each directly against tests/golden/cfg2_summary.npz (recorded from the reference).  north_star tolerance
+    1e-5 relative L2 on the farfield amplitude at the spots.
+    """
+    meta, gold = load_golden("cfg2_summary")
+    h = cfg2_hologram(2, path)
+    h.optimize("WGS-Leonardo", maxiter=50, verbose=False)
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    amp_ff = h.amp_ff
+    errs = dict(spot_amp=rel_l2(amp_ff[ky, kx], gold["spot_ampff"]),
+                spot_weights=rel_l2(h.weights[ky, kx], gold["spot_weights"]),
+                amp_sub=rel_l2(amp_ff[::16, ::16], gold["ampff_sub"]),
+                phase_sub=phase_rel_l2(h.phase[::6, ::6], gold["phase_sub"]))
+    report(f"cfg2 WGS-Leonardo 50 it vs reference [{path} column path]", **errs)
+    assert errs["spot_amp"] < 1e-5
+    assert errs["spot_weights"] < 3e-4 and errs["amp_sub"] < 3e-4 and errs["phase_sub"] < 6e-4
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+def test_cfg2_kim_every_column_path_matches_reference(path):
+    meta, gold = load_golden("cfg2kim_summary")
+    h = cfg2_hologram(9, path)
+    h.optimize("WGS-Kim", maxiter=30, verbose=False)
+    assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    errs = dict(spot_amp=rel_l2(h.amp_ff[ky, kx], gold["spot_ampff"]),
+                spot_weights=rel_l2(h.weights[ky, kx], gold["spot_weights"]),
+                amp_sub=rel_l2(h.amp_ff[::16, ::16], gold["ampff_sub"]),
+                phase_sub=phase_rel_l2(h.phase[::6, ::6], gold["phase_sub"]))
+    report(f"cfg2 WGS-Kim 30 it vs reference [{path} column path]", **errs)
+    assert errs["spot_amp"] < 1e-5 and errs["amp_sub"] < 1e-4 and errs["spot_weights"] < 1e-4
+    assert errs["phase_sub"] < 3e-4
+
+
+def test_cfg2_error_distribution_over_seeds():
+    """
+    Eight seed phases (tests/golden/cfg2_seeds.npz: the reference's end state from each seed, and from the same
+    seed perturbed by about one fp32 ulp).  The engine's distance to the reference is reported next to the
+    distance the reference itself moves under that perturbation -- the floor for any fp32 implementation whose
+    rounding is not bit-identical to NumPy's.
+    """
+    meta, gold = load_golden("cfg2_seeds")
+    rows = []
+    for i, seed in enumerate(meta["seeds"]):
+        ref, refp = gold["spot_ampff"][i], gold["spot_ampff_perturbed"][i]
+        floor = rel_l2(refp, ref)
+        row = dict(seed=seed, reference_1ulp=floor)
+        for path in ("default", "dense"):
+            h = cfg2_hologram(seed, path)
+            h.optimize("WGS-Leonardo", maxiter=50, verbose=False)
+            ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+            row[path] = rel_l2(h.amp_ff[ky, kx], ref)
+            h._release_engine()
+        report("cfg2 seed sweep", **row)
+        rows.append(row)
+    for path in ("default", "dense"):
+        v = np.array([r[path] for r in rows])
+        fl = np.array([r["reference_1ulp"] for r in rows])
+        report(f"cfg2 seed sweep summary [{path}]", median=np.median(v), max=v.max(), median_floor=np.median(fl), max_floor=fl.max())
+        assert np.median(v) < 1e-5
+        # no seed may sit far outside what a one-ulp change of the input does to the reference itself
+        assert np.all(v < np.maximum(1e-5, 3 * fl))
+
+
+# ---- cfg 3: eight holograms per engine at 4096^2 ------------------------------------------------------------
+@pytest.mark.parametrize("path", ["default", "dense"])
+def test_cfg3_batch_of_eight_matches_single_engines(path):
+    """BASELINE config 3's per-GPU shard: batch = 8 at the cfg 2 geometry against eight single engines."""
+    n, iters = 8, 12
+    host = cfg2_hologram(100, "default")
+    phases = np.stack([synth.seed_phase(100 + i, SLM) for i in range(n)])
+    hb = HologramBatch(SHAPE, SLM, host.target, phases, spot_index=host.spot_knm_rounded, spot_amp=host.spot_amp)
+    for opt, val in PATHS[path].items():
+        hb.engine.set_option(opt, val)
+    try:
+        hb.optimize("WGS-Leonardo", maxiter=iters)
+        got = hb.phases()
+        w = hb.engine.get(L.WEIGHTS)
+    finally:
+        hb.close()
+    ky, kx = host.spot_knm_rounded[1], host.spot_knm_rounded[0]
+    for i in range(n):
+        h = cfg2_hologram(100 + i, path)
+        h.optimize("WGS-Leonardo", maxiter=iters, verbose=False)
+        e_ph, e_w = phase_rel_l2(got[i], h.phase), rel_l2(w[i][ky, kx], h.weights[ky, kx])
+        report(f"cfg3 batch of 8 [{path}] hologram {i}", phase=e_ph, weights=e_w)
+        assert e_ph < 2e-6 and e_w < 2e-6
+        h._release_engine()
+    # the holograms are independent: different seeds must give different masks
+    assert phase_rel_l2(got[0], got[1]) > 0.5
+
+
+# ---- cfg 4: CompressedSpotHologram at its configured size ---------------------------------------------------
+def _cfg4_spots(D, N):
+    v = synth.uniform01(4, (D, N), 9) * 2 - 1
+    v[:2] *= 0.02
+    if D == 3:
+        v[2] *= 1e-6
+    return v
+
+
+def _kernel_phase(h, spots, pix):
+    """phi_n(p) in float64 for the given spot / flat pixel indices, from the oracle's monomial tables."""
+    terms, wts = orc.monomial_weights(h.zernike_basis, h.spot_zernike)
+    x = h._xg.ravel()[pix].astype(np.float64)
+    y = h._yg.ravel()[pix].astype(np.float64)
+    phi = np.zeros((len(spots), len(pix)))
+    for m, (px, py) in enumerate(terms):
+        phi += wts[m, spots][:, None] * (x ** int(px) * y ** int(py))[None, :]
+    return phi
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("sep", [1, 0])
+def test_cfg4_full_size_against_direct_summation(D, sep):
+    """
+    N = 1e4 spots, S = 1152 x 1920 (BASELINE config 4), WGS-Kim across the phase-fixing iteration.  One more loop
+    body is then taken operator by operator and checked against float64 DIRECT (non-separable) summation on
+    the host: the farfield of 64 random spots over all 2.2 M pixels, and the new phase at 1,000 random pixels
+    over all 1e4 spots -- for the matrix-core (separable) form and for the direct kernels.
+    """
+    N = 10000
+    slm = SimpleSLM(SLM, pitch_um=(8, 8), wav_um=0.78)
+    h = CompressedSpotHologram(_cfg4_spots(D, N), basis="kxy", cameraslm=SimpleFourierSLM(slm),
+                               engine_options={L.OPT_SEPARABLE: sep})
+    h.reset_phase(synth.seed_phase(4, SLM))
+    h.optimize("WGS-Kim", maxiter=12 if sep else 11, verbose=False)       # phase fixes at iteration 10
+    assert h.flags["fixed_phase"] and h.stats["flags"]["fixed_phase"][:10] == [False] * 10
+    e = h._get_engine()
+    S = SLM[0] * SLM[1]
+    rng = np.random.default_rng(44)
+    spots = np.sort(rng.choice(N, 64, replace=False))
+    pix = np.sort(rng.choice(S, 1000, replace=False))
+
+    # forward: ff_n = sum_p amp e^{i phase_p} e^{-i phi_n(p)} / sqrt(S), then ff /= ||ff||  (_spots.py:767-824)
+    phase = h.phase.astype(np.float64).ravel()
+    e.nearfield2farfield()
+    ff = e.get(L.FARFIELD)[0].astype(np.complex128)
+    assert abs(np.sqrt(np.sum(np.abs(ff) ** 2)) - 1) < 1e-5
+    ref = np.zeros(len(spots), dtype=np.complex128)
+    allp = np.arange(S)
+    for c0 in range(0, S, 1 << 18):                # chunks of pixels: 64 x 262144 float64 at a time
+        pp = allp[c0:c0 + (1 << 18)]
+        ref += np.sum(np.exp(1j * (phase[pp][None, :] - _kernel_phase(h, spots, pp))), axis=1)
+    ref *= float(h.amp) / np.sqrt(S)
+    got = ff[spots]
+    scale = np.real(np.vdot(ref, got)) / np.real(np.vdot(ref, ref))         # the positive factor 1 / ||ff||
+    err_ff = rel_l2(got, scale * ref)
+
+    # constraint: farfield = weights * exp(i phase_ff) with the FIXED phase (_hologram.py:1601-1605)
+    st = h._make_step()
+    pff_before = e.get(L.PHASE_FF)[0].copy()
+    e.farfield_constraint(st)
+    assert st.fixed_phase == 1
+    ffc = e.get(L.FARFIELD)[0].astype(np.complex128)
+    wts = e.get(L.WEIGHTS)[0].astype(np.float64)
+    np.testing.assert_array_equal(e.get(L.PHASE_FF)[0], pff_before)
+    err_cons = rel_l2(ffc, wts * np.exp(1j * pff_before.astype(np.float64)))
+
+    # inverse: nf_p = sum_n ff_n e^{+i phi_n(p)} / sqrt(S), phase = atan2(nf)  (_spots.py:887-914)
+    e.farfield2nearfield()
+    ph_new = e.get(L.PHASE)[0].ravel()[pix]
+    nf = np.zeros(len(pix), dtype=np.complex128)
+    alln = np.arange(N)
+    for c0 in range(0, N, 2000):
+        nn = alln[c0:c0 + 2000]
+        nf += np.sum(ffc[nn][:, None] * np.exp(1j * _kernel_phase(h, nn, pix)), axis=0)
+    err_ph = phase_rel_l2(ph_new, np.angle(nf))
+    report(f"cfg4 full size D={D} {'matrix-core' if sep else 'direct'} path vs float64 direct summation",
+           farfield_64_spots=err_ff, constraint=err_cons, phase_1000_pixels=err_ph)
+    assert err_ff < 2e-5 and err_cons < 1e-6 and err_ph < 1e-4
+    h._release_engine()

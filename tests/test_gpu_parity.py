@@ -584,6 +584,24 @@ def test_in_pass_statistics_full_size_and_batch():
     assert 0 < u[0] < u[-1] <= 1
 
 
+def test_get_farfield_matches_reference_fixture():
+    """get_farfield at other shapes / another depth / through the affine resample, recorded from the reference
+    (tests/golden/get_farfield.npz, _hologram.py:853-931)."""
+    meta, gold = load_golden("get_farfield")
+    slm = tuple(meta["slm_shape"])
+    h = Hologram(tuple(meta["shape"]), amp=gold["amp"].copy(), phase=synth.seed_phase(meta["seed"], slm), slm_shape=slm)
+    aff = dict(M=gold["M"], b=gold["b"])
+    kern = gold["kern"]
+    cases = dict(ff_default=h.get_farfield(), ff_64x256_kern=h.get_farfield((64, 256), propagation_kernel=kern),
+                 ff_256_affine=h.get_farfield((256, 256), propagation_kernel=0, affine=aff),
+                 ff_128_kern_affine=h.get_farfield((128, 128), propagation_kernel=kern, affine=aff))
+    errs = {k: rel_l2(v, gold[k]) for k, v in cases.items()}
+    report("get_farfield vs reference fixture", **errs)
+    for k, v in cases.items():
+        assert v.shape == gold[k].shape and np.iscomplexobj(v)
+        assert errs[k] < (1e-5 if "affine" in k else 2e-6), k
+
+
 def test_get_farfield_shape_kernel_affine():
     """Hologram.get_farfield (_hologram.py:853-931): other DFT shapes, a depth kernel, the affine resample."""
     from scipy.ndimage import affine_transform

@@ -168,3 +168,80 @@ def test_convert_vector_knm_roundtrip():
     back = toolbox.convert_vector(knm, "knm", "kxy", Slm(), (4096, 4096))
     np.testing.assert_allclose(back, v, atol=1e-15)
     np.testing.assert_allclose(toolbox.convert_vector((0, 0), "kxy", "knm", Slm(), (4096, 4096)).ravel(), [2048, 2048])
+
+
+def test_quadratic_initial_phase_matches_reference():
+    """reset_phase(quadratic_phase=...) (_hologram.py:480-527, :581-601) against values recorded from the reference."""
+    meta, gold = load_golden("quadratic_phase")
+    slm = tuple(meta["slm_shape"])
+    h = Hologram(gold["target"].copy(), amp=gold["amp"].copy(), phase=synth.seed_phase(31, slm), slm_shape=slm)
+    c, sd = h._get_target_moments_knm_norm()
+    np.testing.assert_allclose(c, gold["center_knm_norm"], rtol=1e-12)
+    np.testing.assert_allclose(sd, gold["std_knm_norm"], rtol=1e-12)
+    np.testing.assert_allclose(h._get_quadratic_initial_phase(1), gold["q1"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(h._get_quadratic_initial_phase(1.7), gold["q17"], rtol=2e-6, atol=1e-6)
+    h.reset_phase(quadratic_phase=True, random_phase=0)
+    np.testing.assert_allclose(h.phase, gold["phase_quadratic"], rtol=2e-6, atol=1e-6)
+    assert h.phase.dtype == np.float32
+    # the flag form, added to a scaled random phase
+    h.flags["quadratic_phase"] = 1.7
+    h.reset_phase(random_phase=0)
+    np.testing.assert_allclose(h.phase, gold["q17"], rtol=2e-6, atol=1e-6)
+    # the scalar (uniform) amplitude has no image moments -- the reference fails there too
+    g = Hologram(gold["target"].copy(), phase=synth.seed_phase(31, slm), slm_shape=slm)
+    with pytest.raises(ValueError):
+        g.reset_phase(quadratic_phase=True)
+
+
+class _StubEngine:
+    """Stands in for the HIP engine in host-logic tests: holds arrays, counts closes."""
+
+    def __init__(self, arrays):
+        self.arrays = dict(arrays)
+        self.closed = False
+
+    def get(self, which):
+        return [self.arrays[which].copy()]
+
+    def set(self, which, arr):
+        self.arrays[which] = np.array(arr, copy=True)
+
+    def reset_weights(self):
+        pass
+
+    def close(self):
+        self.closed = True
+
+
+def test_reset_keeps_the_optimised_phase():
+    """
+    Hologram.reset(reset_phase=False) keeps the CURRENT phase (_hologram.py:442-478).  After optimize() the
+    current phase lives on the device only; it must come home before the engine is destroyed.
+    """
+    h = Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
+    stub = _StubEngine({L.PHASE: np.full((64, 64), 7.0, np.float32), L.WEIGHTS: h.weights.copy()})
+    h._engine = stub
+    h._mark_device_fresh(["phase", "weights"])          # what optimize_gs leaves behind
+    h.reset(reset_phase=False)
+    assert stub.closed and h._engine is None
+    assert np.all(h.phase == 7.0)
+    # reset_phase=True replaces it
+    h._engine = stub2 = _StubEngine({L.PHASE: np.full((64, 64), 9.0, np.float32), L.WEIGHTS: h.weights.copy()})
+    h._mark_device_fresh(["phase"])
+    h.reset(reset_phase=True)
+    assert stub2.closed and not np.any(h.phase == 9.0)
+
+
+def test_batch_targets_are_normalised_like_set_target():
+    from slmsuite_amd.batch import normalize_targets
+    t = synth.random_target(3, (2, 32, 32), 0.0, 5.0)
+    t[0, 3, 4] = -t[0, 3, 4]
+    t[1, 5, 6] = np.nan
+    n = normalize_targets(t)
+    assert n.dtype == np.float32 and np.all(n[~np.isnan(n)] >= 0) and np.isnan(n[1, 5, 6])
+    for i in range(2):
+        assert abs(float(np.sqrt(np.nansum(n[i].astype(np.float64) ** 2))) - 1) < 1e-6
+    h = Hologram(t[0], phase=synth.seed_phase(1, (32, 32)))
+    np.testing.assert_allclose(n[0], h.target, rtol=3e-7)
+    # unit-norm input passes through bit-identically
+    np.testing.assert_array_equal(normalize_targets(h.target), h.target)

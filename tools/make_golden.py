@@ -7,7 +7,8 @@ Runs only in the build container (the reference never travels to the GPU box; th
 fixtures do).  Nothing from the reference is copied: fixtures hold inputs and outputs only.
 
     python tools/make_golden.py            # small fixtures (seconds)
-    python tools/make_golden.py --cfg2     # additionally the 4096^2 config-2 summary (~3 min)
+    python tools/make_golden.py --cfg2     # additionally the 4096^2 config-2 summaries: cfg2 (~3 min), cfg2kim
+                                           # (~2 min), cfg2seeds (16 runs, ~12 min on 4 cores); --only NAME picks one
 """
 import argparse
 import json
@@ -343,6 +344,99 @@ def gen_cfg2(alg):
                               method="WGS-Leonardo", sub_ampff=16, sub_phase=6, wall_s=dt), out)
 
 
+def gen_misc_cases(alg):
+    """
+    Off-loop rows of SURVEY 8(a)-18 recorded from the reference: the quadratic initial phase (_hologram.py:480-527,
+    581-601) and get_farfield at other shapes, another depth and through an affine resample (:853-931).
+    """
+    slm = (48, 80)
+    yy, xx = np.mgrid[0:128, 0:128]
+    target = np.exp(-(((xx - 75.5) / 14.0) ** 2 + ((yy - 52.0) / 9.0) ** 2)).astype(np.float32)
+    target[100:110, 20:40] = np.nan                       # a noise region: the moments use nansum
+    amp = synth.gaussian_amp(slm, frac=0.4)
+    h = alg.Hologram(target.copy(), amp=amp.copy(), phase=synth.seed_phase(31, slm), slm_shape=slm)
+    out = dict(target=target, amp=amp, q1=np.array(h._get_quadratic_initial_phase(1)),
+               q17=np.array(h._get_quadratic_initial_phase(1.7)))
+    c, sd = h._get_target_moments_knm_norm()
+    out.update(center_knm_norm=np.array(c), std_knm_norm=np.array(sd))
+    h.reset_phase(quadratic_phase=True, random_phase=0)
+    out["phase_quadratic"] = np.array(h.phase)
+    save("quadratic_phase", dict(kind="quadratic_phase", slm_shape=slm, shape=(128, 128)), out)
+
+    # get_farfield: shape variants, a depth kernel, an affine resample (scipy order-3 spline, in place on the farfield)
+    h = alg.Hologram((128, 128), amp=amp.copy(), phase=synth.seed_phase(32, slm), slm_shape=slm)
+    kern = (0.4 * synth.seed_phase(33, slm)).astype(np.float32)
+    aff = dict(M=np.array([[1.02, 0.01], [-0.02, 0.97]]), b=np.array([3.5, -2.25]))
+    out = dict(amp=amp, kern=kern, M=aff["M"], b=aff["b"],
+               ff_default=np.array(h.get_farfield()),
+               ff_64x256_kern=np.array(h.get_farfield((64, 256), propagation_kernel=kern)),
+               ff_256_affine=np.array(h.get_farfield((256, 256), propagation_kernel=0, affine=aff)),
+               ff_128_kern_affine=np.array(h.get_farfield((128, 128), propagation_kernel=kern, affine=aff)))
+    save("get_farfield", dict(kind="get_farfield", slm_shape=slm, shape=(128, 128), seed=32), out)
+
+
+def gen_cfg2kim(alg):
+    """cfg 2 geometry with WGS-Kim (phase fixed at iteration 10), 30 it, seed 9 -> cfg2kim_summary.npz."""
+    from slmsuite.holography import analysis
+    shape, slm = (4096, 4096), (1152, 1920)
+    h = alg.SpotHologram.make_rectangular_array(shape, array_shape=(32, 32), array_pitch=(64, 64), basis="knm",
+                                                slm_shape=slm, phase=synth.seed_phase(9, slm).copy())
+    h.optimize("WGS-Kim", maxiter=30, verbose=False, stat_groups=[])
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    fb = np.sqrt(analysis.take(np.square(h.amp_ff), h.spot_knm, h.spot_integration_width_knm, centered=True, integrate=True))
+    st = alg.Hologram._calculate_stats(fb, h.spot_amp, xp=np, efficiency_compensation=False,
+                                       total=np.sum(np.square(h.amp_ff)))
+    out = dict(spot_ampff=np.array(h.amp_ff[ky, kx]), spot_weights=np.array(h.weights[ky, kx]),
+               ampff_sub=np.array(h.amp_ff[::16, ::16]), phase_sub=np.array(h.phase[::6, ::6]),
+               fixed_history=np.array([bool(x) for x in h.stats["flags"]["fixed_phase"]]),
+               uniformity=np.array(st["uniformity"]), efficiency=np.array(st["efficiency"]))
+    save("cfg2kim_summary", dict(kind="cfg2kim", seed=9, shape=shape, slm_shape=slm, maxiter=30, method="WGS-Kim",
+                                 sub_ampff=16, sub_phase=6), out)
+
+
+CFG2_SEEDS = (2, 10, 11, 12, 13, 14, 15, 16)
+
+
+def _cfg2_seed_run(job):
+    """One reference run of cfg 2 (WGS-Leonardo x 50) from seed phase `seed`, optionally perturbed by ~1 ulp."""
+    seed, perturbed = job
+    alg, _, _ = import_reference()
+    shape, slm = (4096, 4096), (1152, 1920)
+    p0 = synth.seed_phase(seed, slm)
+    if perturbed:
+        # the same perturbation tests/test_conditioning.py applies: relative 1e-7 * N(0,1), i.e. <= ~2 ulp
+        rng = np.random.default_rng(1000 + seed)
+        p0 = (p0.astype(np.float64) * (1 + 1e-7 * rng.standard_normal(p0.shape))).astype(np.float32)
+    h = alg.SpotHologram.make_rectangular_array(shape, array_shape=(32, 32), array_pitch=(64, 64), basis="knm",
+                                                slm_shape=slm, phase=p0.copy())
+    h.optimize("WGS-Leonardo", maxiter=50, verbose=False, stat_groups=[])
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    return seed, perturbed, np.array(h.amp_ff[ky, kx]), np.array(h.weights[ky, kx])
+
+
+def gen_cfg2_seeds(alg):
+    """
+    cfg 2 from eight seed phases, each also from the seed perturbed by about one fp32 ulp: the spot amplitudes the
+    reference ends on, and how far its OWN result moves under a 1-ulp change of the input (the floor under which no
+    fp32 implementation that is not bit-identical to NumPy can be expected to land).  ~2.5 min per run, 4 at a time.
+    """
+    import multiprocessing as mp
+    jobs = [(s, p) for s in CFG2_SEEDS for p in (False, True)]
+    with mp.get_context("spawn").Pool(4) as pool:
+        res = pool.map(_cfg2_seed_run, jobs)
+    n = len(CFG2_SEEDS)
+    amp = np.zeros((n, 1024), np.float32); amp_p = np.zeros_like(amp)
+    w = np.zeros_like(amp); w_p = np.zeros_like(amp)
+    for seed, pert, a, ww in res:
+        i = CFG2_SEEDS.index(seed)
+        (amp_p if pert else amp)[i] = a
+        (w_p if pert else w)[i] = ww
+    save("cfg2_seeds", dict(kind="cfg2_seeds", seeds=list(CFG2_SEEDS), shape=(4096, 4096), slm_shape=(1152, 1920),
+                            maxiter=50, method="WGS-Leonardo",
+                            perturbation="phase * (1 + 1e-7 * N(0,1)), default_rng(1000 + seed), rounded to fp32"),
+         dict(spot_ampff=amp, spot_ampff_perturbed=amp_p, spot_weights=w, spot_weights_perturbed=w_p))
+
+
 def make_fourier_slm(res_wh=(64, 48)):
     """SimulatedSLM + SimulatedCamera + analytic Fourier calibration (SURVEY 8c recipe)."""
     from slmsuite.hardware.slms.simulated import SimulatedSLM
@@ -370,7 +464,10 @@ def gen_compressed_cases(alg):
              ("3d50", 3, 50, "kxy", None, "WGS-Leonardo", {}),
              ("2d300", 2, 300, "kxy", None, "WGS-Kim", dict(fix_phase_iteration=4)),
              ("zern5", 5, 24, [2, 1, 4, 3, 5], None, "WGS-Nogrette", {}),
-             ("mraf2d", 2, 40, "kxy", "mraf", "WGS-Leonardo", dict(mraf_factor=0.5))]
+             ("mraf2d", 2, 40, "kxy", "mraf", "WGS-Leonardo", dict(mraf_factor=0.5)),
+             # ANSI tilt x, tilt y and the vortex pseudo-index -1 (phase.py:1783-1790): fractional charges, the
+             # negative ones of which the NumPy path ignores
+             ("vortex", 3, 30, [2, 1, -1], None, "WGS-Leonardo", {})]
     for tag, D, N, basis, special, method, kw in cases:
         seed = 500 + N + D
         v = (synth.uniform01(seed, (D, N), 7) * 2 - 1)
@@ -379,7 +476,7 @@ def gen_compressed_cases(alg):
             if D == 3:
                 v[2] *= 2e-6
         else:
-            v *= np.array([12, 12, 2, 1.5, 1.5])[:, None]
+            v *= np.array([12, 12, 2, 1.5, 1.5])[:D, None]
         spot_amp = None
         if special == "mraf":
             spot_amp = np.full(N, 1.0)
@@ -434,9 +531,12 @@ def main():
         "compressed": lambda: gen_compressed_cases(alg),
         "multiplane": lambda: gen_multiplane_cases(alg),
         "fourier": lambda: gen_fourier_cases(alg),
+        "misc": lambda: gen_misc_cases(alg),
     }
     if args.cfg2:
         steps["cfg2"] = lambda: gen_cfg2(alg)
+        steps["cfg2kim"] = lambda: gen_cfg2kim(alg)
+        steps["cfg2seeds"] = lambda: gen_cfg2_seeds(alg)
     for name, fn in steps.items():
         if args.only and name != args.only:
             continue
