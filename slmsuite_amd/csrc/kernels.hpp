@@ -39,6 +39,14 @@
 #ifndef HGS_FUSED_OCC
 #define HGS_FUSED_OCC 2
 #endif
+// Ablation hooks for tools/microbench/ablate.hip (all 0 in the product build): compile the weight/target
+// loads (WT) or the GH tile loads and stores (GH) out of col_tile_kernel to see what they cost.
+#ifndef HGS_ABL_WT
+#define HGS_ABL_WT 0
+#endif
+#ifndef HGS_ABL_GH
+#define HGS_ABL_GH 0
+#endif
 
 namespace hgs {
 
@@ -939,6 +947,11 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
                                                R (&wr)[16], R (&tr)[16]) {
     static_for<0, 16>([&](auto m_) {
         constexpr int m = m_;
+        if (HGS_ABL_WT) {
+            wr[m] = (R)1e-3;
+            tr[m] = (j == 7 && m == 3) ? (R)0.03 : (R)0;
+            return;
+        }
         wr[m] = wc[lane_pos<T>(j, m)];
         tr[m] = upd ? tc[lane_pos<T>(j, m)] : (R)0;
     });
@@ -994,6 +1007,10 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
             float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+            if (HGS_ABL_GH) {
+                lo = make_float4((float)j * 1e-4f, (float)m, 0.5f, (float)ct * 1e-3f);
+                hi = make_float4(0.25f, (float)j * 2e-4f, (float)m * 0.1f, 1.f);
+            } else
             if (r >= 0 && r < g.Sh) {
                 const float4* q = reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
                 lo = q[0];
@@ -1132,7 +1149,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
-            if (r >= 0 && r < g.Sh) {
+            if (HGS_ABL_GH ? (gtx[m][0] == 123.456f) : (r >= 0 && r < g.Sh)) {
                 float4* q = reinterpret_cast<float4*>(gh + (unsigned)r * 4u);
                 q[0] = make_float4(gtx[m][0], gty[m][0], gtx[m][1], gty[m][1]);
                 q[1] = make_float4(gtx[m][2], gty[m][2], gtx[m][3], gty[m][3]);

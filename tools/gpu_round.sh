@@ -1,13 +1,14 @@
 #!/bin/bash
-# One GPU visit: parity tests, smoke, bench.  Everything lands in gpurun_out/.
+# One GPU visit: parity tests, smoke, bench (headline + the other configs).  Everything lands in gpurun_out/.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import torch; print(torch.cuda.get_device_name(0))" > gpurun_out/device.txt 2>&1
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> gpurun_out/device.txt
-timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1
+rm -f gpurun_out/parity_report.jsonl
+timeout ${PYTEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=15 ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
-tail -60 gpurun_out/pytest_gpu.log
+tail -70 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
 tail -5 gpurun_out/smoke.log
-timeout 600 python bench.py --steps ${BENCH_STEPS:-100} --warmup 10 > gpurun_out/bench.log 2>&1; echo "bench exit $?" >> gpurun_out/bench.log
+timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?" >> gpurun_out/bench.log
 tail -5 gpurun_out/bench.log

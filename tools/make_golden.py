@@ -395,6 +395,7 @@ def gen_cfg2kim(alg):
 
 
 CFG2_SEEDS = (2, 10, 11, 12, 13, 14, 15, 16)
+CFG2_CURVE_ITERS = (5, 10, 20, 30, 40)
 
 
 def _cfg2_seed_run(job):
@@ -409,9 +410,17 @@ def _cfg2_seed_run(job):
         p0 = (p0.astype(np.float64) * (1 + 1e-7 * rng.standard_normal(p0.shape))).astype(np.float32)
     h = alg.SpotHologram.make_rectangular_array(shape, array_shape=(32, 32), array_pitch=(64, 64), basis="knm",
                                                 slm_shape=slm, phase=p0.copy())
-    h.optimize("WGS-Leonardo", maxiter=50, verbose=False, stat_groups=[])
     ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
-    return seed, perturbed, np.array(h.amp_ff[ky, kx]), np.array(h.weights[ky, kx])
+    curve = {}
+
+    def snap(hh):       # fires after the forward transform of body k: amp_ff = |FFT(phase_k)|
+        if hh.iter in CFG2_CURVE_ITERS:
+            curve[hh.iter] = np.array(hh.amp_ff[ky, kx])
+        return False
+
+    h.optimize("WGS-Leonardo", maxiter=50, verbose=False, stat_groups=[], callback=snap)
+    return seed, perturbed, np.array(h.amp_ff[ky, kx]), np.array(h.weights[ky, kx]), \
+        np.stack([curve[k] for k in CFG2_CURVE_ITERS])
 
 
 def gen_cfg2_seeds(alg):
@@ -427,14 +436,17 @@ def gen_cfg2_seeds(alg):
     n = len(CFG2_SEEDS)
     amp = np.zeros((n, 1024), np.float32); amp_p = np.zeros_like(amp)
     w = np.zeros_like(amp); w_p = np.zeros_like(amp)
-    for seed, pert, a, ww in res:
+    cur = np.zeros((n, len(CFG2_CURVE_ITERS), 1024), np.float32); cur_p = np.zeros_like(cur)
+    for seed, pert, a, ww, cv in res:
         i = CFG2_SEEDS.index(seed)
         (amp_p if pert else amp)[i] = a
         (w_p if pert else w)[i] = ww
+        (cur_p if pert else cur)[i] = cv
     save("cfg2_seeds", dict(kind="cfg2_seeds", seeds=list(CFG2_SEEDS), shape=(4096, 4096), slm_shape=(1152, 1920),
-                            maxiter=50, method="WGS-Leonardo",
+                            maxiter=50, method="WGS-Leonardo", curve_iters=list(CFG2_CURVE_ITERS),
                             perturbation="phase * (1 + 1e-7 * N(0,1)), default_rng(1000 + seed), rounded to fp32"),
-         dict(spot_ampff=amp, spot_ampff_perturbed=amp_p, spot_weights=w, spot_weights_perturbed=w_p))
+         dict(spot_ampff=amp, spot_ampff_perturbed=amp_p, spot_weights=w, spot_weights_perturbed=w_p,
+              curve_ampff=cur, curve_ampff_perturbed=cur_p))
 
 
 def make_fourier_slm(res_wh=(64, 48)):
