@@ -32,8 +32,35 @@
 #ifndef HGS_ABL_TRANS
 #define HGS_ABL_TRANS 0
 #endif
+// Wave-priority experiments (A/B builds): 0 none; 1 static, by the parity of the hardware wave slot (the two waves
+// sharing a SIMD get different priorities); 2 raised around the butterflies, lowered around the exchanges
+#ifndef HGS_PRIO
+#define HGS_PRIO 0
+#endif
+// Timeline instrumentation for tools/microbench/trace.hip: lane 0 of every wave stamps s_memtime at phase
+// boundaries into dynamic LDS at byte offset HGS_TRACE_OFF (128 events per wave); 0 in the product build.
+#ifndef HGS_TRACE
+#define HGS_TRACE 0
+#endif
+#ifndef HGS_TRACE_OFF
+#define HGS_TRACE_OFF 40960
+#endif
 
 namespace hgs {
+
+#if HGS_TRACE
+__device__ __forceinline__ void trace_event(int& n, int ev) {
+    extern __shared__ __attribute__((aligned(16))) char trace_smem[];
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0 && n < 128)
+        reinterpret_cast<unsigned long long*>(trace_smem + HGS_TRACE_OFF)[(threadIdx.x >> 6) * 128 + n] =
+            (t & 0x00ffffffffffffffull) | ((unsigned long long)ev << 56);
+    ++n;
+}
+#define HGS_T(n, ev) trace_event(n, ev)
+#else
+#define HGS_T(n, ev) ((void)0)
+#endif
 
 // Complex numbers are 2-vectors (x = re, y = im) held in an aligned VGPR pair, so that complex
 // add/sub are ONE packed instruction (v_pk_add_f32) and a complex multiply is two (v_pk_mul_f32 +
@@ -198,6 +225,49 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
     static __device__ __forceinline__ void run(Cx<R> (&v)[16]) {
         const Cx<R> z = mk<R>(0, 0);
         run_tw<false>(v, z, z, z);
+    }
+    // The mirror image (decimation in frequency): same 16-point transform, the stage twiddle W^(p k) of OUTPUT
+    // p = p1 + 4*p2 applied on the way out, again in split form: W^(p1 k) = bt[p1-1] between the two radix-4
+    // layers, W^(4 p2 k) = ot[p2-1] on the outputs.  With the conjugated direction this is exactly the
+    // transpose of run_tw<true> preceded by its pre-multiplication, i.e. what undoes a forward stage.
+    static __device__ __forceinline__ void run_tw_post(Cx<R> (&v)[16], Cx<R> ot1, Cx<R> ot2, Cx<R> ot3,
+                                                       Cx<R> bt1, Cx<R> bt2, Cx<R> bt3) {
+        // layer 1: DFT4 over r1 (r = 4 r1 + r2) for each r2 -> u[p1][r2] at v[4 p1 + r2]
+        dft4<DIR>(v[0], v[4], v[8], v[12]);
+        dft4<DIR>(v[1], v[5], v[9], v[13]);
+        dft4<DIR>(v[2], v[6], v[10], v[14]);
+        dft4<DIR>(v[3], v[7], v[11], v[15]);
+        // u[p1][r2] *= w16^(r2 p1)
+        v[5] = rot16<1, DIR>(v[5]);   v[6] = rot16<2, DIR>(v[6]);   v[7] = rot16<3, DIR>(v[7]);
+        v[9] = rot16<2, DIR>(v[9]);   v[10] = rot16<4, DIR>(v[10]); v[11] = rot16<6, DIR>(v[11]);
+        v[13] = rot16<3, DIR>(v[13]); v[14] = rot16<6, DIR>(v[14]); v[15] = rot16<9, DIR>(v[15]);
+        // ... *= W^(p1 k)
+        static_for<0, 4>([&](auto r2_) {
+            constexpr int r2 = r2_;
+            v[4 + r2] = DIR < 0 ? cmul(v[4 + r2], bt1) : cmulc(v[4 + r2], bt1);
+            v[8 + r2] = DIR < 0 ? cmul(v[8 + r2], bt2) : cmulc(v[8 + r2], bt2);
+            v[12 + r2] = DIR < 0 ? cmul(v[12 + r2], bt3) : cmulc(v[12 + r2], bt3);
+        });
+        // layer 2: DFT4 over r2 for each p1 -> V[p1 + 4 p2] at v[4 p1 + p2]
+        dft4<DIR>(v[0], v[1], v[2], v[3]);
+        dft4<DIR>(v[4], v[5], v[6], v[7]);
+        dft4<DIR>(v[8], v[9], v[10], v[11]);
+        dft4<DIR>(v[12], v[13], v[14], v[15]);
+        // ... *= W^(4 p2 k)
+        static_for<0, 4>([&](auto p1_) {
+            constexpr int p1 = p1_;
+            v[4 * p1 + 1] = DIR < 0 ? cmul(v[4 * p1 + 1], ot1) : cmulc(v[4 * p1 + 1], ot1);
+            v[4 * p1 + 2] = DIR < 0 ? cmul(v[4 * p1 + 2], ot2) : cmulc(v[4 * p1 + 2], ot2);
+            v[4 * p1 + 3] = DIR < 0 ? cmul(v[4 * p1 + 3], ot3) : cmulc(v[4 * p1 + 3], ot3);
+        });
+        // natural order
+        Cx<R> t;
+        t = v[1]; v[1] = v[4]; v[4] = t;
+        t = v[2]; v[2] = v[8]; v[8] = t;
+        t = v[3]; v[3] = v[12]; v[12] = t;
+        t = v[6]; v[6] = v[9]; v[9] = t;
+        t = v[7]; v[7] = v[13]; v[13] = t;
+        t = v[11]; v[11] = v[14]; v[14] = t;
     }
 };
 
@@ -385,6 +455,177 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
             this->template stage<DIR, s, DB>(v, lds, j);
         });
     }
+    // uniform entry points (see WgFftL for why the inverse comes in two flavours)
+    __device__ __forceinline__ void fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<-1>(v, lds, j); }
+    __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<+1>(v, lds, j); }
+    __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<+1>(v, lds, j); }
 };
+
+// ---- the 4096-point transform with a row-local first exchange ----------------------------------------
+// 256 lanes x 16 registers, three radix-16 stages.  Element n = n0 + 16 n1 + 256 n2 of the SPACE side (rows
+// of GH, SLM columns) is held by lane p = 16 n0 + n1 in register n2, i.e. lane p owns the elements
+// space_lane(p) + 256 m with space_lane(p) = (p >> 4) + 16 (p & 15); element k of the FREQUENCY side by lane
+// k % 256 in register k / 256, as in WgFft.  With the two hex digits of the lane index swapped on the space
+// side, the exchange between stage 0 and stage 1 is a 16 x 16 transpose inside each row of 16 lanes -- one
+// wave, no barrier, conflict-free at stride 17 -- and only the exchange between stage 1 and stage 2 crosses
+// waves.  The inverse is the exact mirror of the forward transform (decimation in frequency, post-twiddles,
+// Dft<16>::run_tw_post), so it maps the frequency layout back to the space layout and shares the forward
+// twiddle registers (conjugated).  tools/fft_local_model.py is the index model of both directions.
+//
+// LDS: one image of 16 row regions of 272 elements (the same 34,816 bytes as WgFft).  Hazards: forward writes
+// (local and cross-wave) touch only the writing wave's own regions, its cross-wave gather reads every region
+// and is bracketed by two barriers; the inverse scatters into every region (one barrier, then reads its own
+// region).  An inverse therefore needs every wave to be done with the previous transform's LDS reads: true
+// after a forward transform (it ends with a barrier) or at kernel start; after another inverse pass
+// LEAD = true (one more barrier).  Fused forward -> inverse passes cost 3 barriers instead of 8.
+__device__ __forceinline__ void wave_lds_order() {
+    // LDS operations of one wave execute in issue order; only the compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename R, bool RESIDENT = true> struct WgFftL {
+    static constexpr int N = 4096, T = 256, E = 16, ROW = 272;
+    static constexpr int NTW = RESIDENT ? 12 : 1;
+    Cx<R> tw[NTW];
+    const Cx<R>* table_ = nullptr;
+    int tr_n = 0;       // HGS_TRACE event counter (dead otherwise)
+
+    static __host__ __device__ __forceinline__ int space_lane(int p) { return (p >> 4) + 16 * (p & 15); }
+
+    // twiddle IDX of stage s (1 or 2): IDX 0..2 = W^(4 q k), 3..5 = W^(q k), q = IDX % 3 + 1;
+    // stage 1: W_256, k = p & 15; stage 2: W_4096, k = p
+    template <int s, int IDX> __device__ __forceinline__ Cx<R> twv(int p) const {
+        if constexpr (RESIDENT) {
+            return tw[(s - 1) * 6 + IDX];
+        } else {
+            constexpr int q = (IDX < 3 ? 4 : 1) * (IDX % 3 + 1);
+            return s == 1 ? table_[(q * (p & 15) * 16) & (N - 1)] : table_[(q * p) & (N - 1)];
+        }
+    }
+    __device__ __forceinline__ void init(const Cx<R>* __restrict__ table, int p) {
+        table_ = table;
+        if (HGS_PRIO == 1) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));     // wave slot within the SIMD
+            if (hw & 1u) __builtin_amdgcn_s_setprio(1);
+        }
+        if constexpr (RESIDENT) {
+            static_for<0, 6>([&](auto i_) {
+                constexpr int i = i_;
+                constexpr int q = (i < 3 ? 4 : 1) * (i % 3 + 1);
+                tw[i] = table[(q * (p & 15) * 16) & (N - 1)];
+                tw[6 + i] = table[(q * p) & (N - 1)];
+            });
+        }
+    }
+
+    template <int DIR, int s> __device__ __forceinline__ void butterfly_pre(Cx<R> (&v)[16], int p) {
+        if (HGS_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+        static_for<1, 4>([&](auto r2_) {
+            constexpr int r2 = r2_;
+            const Cx<R> w = this->template twv<s, r2 - 1>(p);
+            static_for<0, 4>([&](auto r1_) {
+                constexpr int r = r1_ + 4 * r2;
+                v[r] = DIR < 0 ? cmul(v[r], w) : cmulc(v[r], w);
+            });
+        });
+        Dft<16, DIR, R>::template run_tw<true>(v, this->template twv<s, 3>(p), this->template twv<s, 4>(p),
+                                               this->template twv<s, 5>(p));
+        if (HGS_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    }
+    template <int DIR, int s> __device__ __forceinline__ void butterfly_post(Cx<R> (&v)[16], int p) {
+        Dft<16, DIR, R>::run_tw_post(v, this->template twv<s, 0>(p), this->template twv<s, 1>(p), this->template twv<s, 2>(p),
+                                     this->template twv<s, 3>(p), this->template twv<s, 4>(p), this->template twv<s, 5>(p));
+    }
+
+    // forward (DIR = -1 with the table as stored; DIR = +1 gives the conjugate transform in the same flow):
+    // space layout in, frequency layout out
+    template <int DIR> __device__ __forceinline__ void forward_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
+        Cx<R>* rowb = lds + ROW * (p >> 4);
+        HGS_T(tr_n, 10);
+        Dft<16, DIR, R>::run(v);
+        HGS_T(tr_n, 11);
+        {   // 16 x 16 transpose inside the row of 16 lanes
+            Cx<R>* w = rowb + 17 * (p & 15);
+            static_for<0, 16>([&](auto i_) { constexpr int i = i_; w[i] = v[i]; });
+            wave_lds_order();
+            const Cx<R>* r = rowb + (p & 15);
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = r[17 * m]; });
+        }
+        HGS_T(tr_n, 12);
+        butterfly_pre<DIR, 1>(v, p);
+        HGS_T(tr_n, 13);
+        {   // cross-wave exchange: lane (row n0, k_a) register k_b -> lane k_a + 16 k_b register n0
+            Cx<R>* w = rowb + (p & 15);
+            static_for<0, 16>([&](auto r_) { constexpr int r = r_; w[16 * r] = v[r]; });
+            __syncthreads();
+            const Cx<R>* g = lds + p;
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = g[ROW * m]; });
+            __syncthreads();
+        }
+        HGS_T(tr_n, 14);
+        butterfly_pre<DIR, 2>(v, p);
+        HGS_T(tr_n, 15);
+    }
+    // the mirror: frequency layout in, space layout out
+    template <int DIR, bool LEAD> __device__ __forceinline__ void mirror_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
+        Cx<R>* rowb = lds + ROW * (p >> 4);
+        HGS_T(tr_n, 20);
+        butterfly_post<DIR, 2>(v, p);
+        HGS_T(tr_n, 21);
+        {
+            if constexpr (LEAD) __syncthreads();
+            Cx<R>* g = lds + p;
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; g[ROW * m] = v[m]; });
+            __syncthreads();
+            const Cx<R>* r = rowb + (p & 15);
+            static_for<0, 16>([&](auto r_) { constexpr int rr = r_; v[rr] = r[16 * rr]; });
+        }
+        HGS_T(tr_n, 22);
+        butterfly_post<DIR, 1>(v, p);
+        HGS_T(tr_n, 23);
+        {
+            wave_lds_order();
+            Cx<R>* w = rowb + (p & 15);
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; w[17 * m] = v[m]; });
+            wave_lds_order();
+            const Cx<R>* r = rowb + 17 * (p & 15);
+            static_for<0, 16>([&](auto i_) { constexpr int i = i_; v[i] = r[i]; });
+        }
+        HGS_T(tr_n, 24);
+        Dft<16, DIR, R>::run(v);
+        HGS_T(tr_n, 25);
+    }
+
+    // DIR = -1: space -> frequency (forward DFT); DIR = +1: frequency -> space (inverse DFT, unnormalised).
+    // LEAD: see the hazard note above (only meaningful for DIR = +1).
+    template <int DIR, bool LEAD = true> __device__ __forceinline__ void run(Cx<R> (&v)[16], Cx<R>* lds, int p) {
+        if constexpr (DIR < 0) forward_flow<-1>(v, lds, p);
+        else mirror_flow<+1, LEAD>(v, lds, p);
+    }
+    __device__ __forceinline__ void fwd(Cx<R> (&v)[16], Cx<R>* lds, int p) { forward_flow<-1>(v, lds, p); }
+    __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, true>(v, lds, p); }
+    // the previous LDS user of every wave was this workgroup's forward transform (or nothing)
+    __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, false>(v, lds, p); }
+};
+
+// Which workgroup transform a kernel uses for length N, and where lane j's elements sit on the space side
+// (frequency side: always j + m * N/16).
+#ifndef HGS_LOCAL_FFT
+#define HGS_LOCAL_FFT 1
+#endif
+template <typename R, int N, bool RESIDENT> struct FftSel {
+    using type = WgFft<R, N, RESIDENT>;
+    static constexpr bool local = false;
+    static __host__ __device__ __forceinline__ int space_lane(int j) { return j; }
+};
+#if HGS_LOCAL_FFT
+template <typename R, bool RESIDENT> struct FftSel<R, 4096, RESIDENT> {
+    using type = WgFftL<R, RESIDENT>;
+    static constexpr bool local = true;
+    static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL<R, RESIDENT>::space_lane(j); }
+};
+#endif
 
 }  // namespace hgs

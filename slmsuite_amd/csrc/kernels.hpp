@@ -27,9 +27,6 @@
 #ifndef HGS_ROW_TW_RESIDENT
 #define HGS_ROW_TW_RESIDENT true
 #endif
-#ifndef HGS_TILE_DB
-#define HGS_TILE_DB false
-#endif
 #ifndef HGS_ROW_PHASOR
 #define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
 #endif
@@ -387,15 +384,19 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
         __syncthreads();
     }
 
-    WgFft<R, N, HGS_ROW_TW_RESIDENT> fft;
+    using Sel = FftSel<R, N, HGS_ROW_TW_RESIDENT>;
+    typename Sel::type fft;
     fft.init(a.tw, j);
 
-    const R sgn = (j & 1) ? (R)-1 : (R)1;  // (-1)^(j + m*T), T even
+    // lane j owns elements j + m*T of the frequency side (GH columns) and js + m*T of the space side (SLM columns)
+    const int js = Sel::space_lane(j);
+    const R sgn = (j & 1) ? (R)-1 : (R)1;    // (-1)^(j + m*T), T even: frequency side
+    const R sgs = (js & 1) ? (R)-1 : (R)1;   // space side
     // GH element (r, k = j + m*T) sits at ((k>>2)*Sh + r)*4 + (k&3) = lane part + m * (T*Sh)
     Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw;
     const unsigned gh_lane = (unsigned)(j >> 2) * g.Sh * 4u + (unsigned)(j & 3);
     const unsigned gh_step = (unsigned)T * g.Sh;
-    const int c_lane = j - g.c0;   // SLM column of element m is c_lane + m*T
+    const int c_lane = js - g.c0;  // SLM column of element m is c_lane + m*T
     // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list);
     // lane_mask[b][16][Pw/16] holds the 16-bit mask of lane j of a length-Pw row transform
     // The loads of the H row are predicated on the mask, so its fetch is on the critical path of every
@@ -451,8 +452,10 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                 if (valid && ((lmask >> m) & 1u)) h = (ghr + (size_t)m * gh_step)[gh_lane];
                 v[m] = h * sgn;
             });
-            fft.template run<+1>(v, lds, j);
-            const R sc = sgn * a.scale;
+            // (MODE 2: the previous user of the LDS image was the forward transform of the row before)
+            if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
+            else fft.inv(v, lds, j);
+            const R sc = sgs * a.scale;
             if constexpr (MODE == 1) {
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
@@ -487,27 +490,27 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
                     if constexpr (MODE == 2 && HGS_ROW_PHASOR) {
                         // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
-                        nf = (p2 > (R)0) ? v[m] * (amv * M::rsqrt(p2)) : mk<R>(amv * sgn, 0);
+                        nf = (p2 > (R)0) ? v[m] * (amv * M::rsqrt(p2)) : mk<R>(amv * sgs, 0);
                     } else if constexpr (MODE == 2) {
                         // the reference's own arithmetic: phase rounded to working precision, then exp(i phase)
-                        const R scs = sgn * a.scale;
+                        const R scs = sgs * a.scale;
                         R p = M::atan2(v[m].y * scs, v[m].x * scs);
                         if (kn != nullptr) { p -= kn[c]; p += kn[c]; }
                         R s, co;
                         M::sincos(p, &s, &co);
-                        nf = mk<R>(amv * sgn * co, amv * sgn * s);
+                        nf = mk<R>(amv * sgs * co, amv * sgs * s);
                     } else {
                         R p = ph[c];
                         if (kn != nullptr) p += kn[c];
                         R s, co;
                         M::sincos(p, &s, &co);
-                        nf = mk<R>(amv * sgn * co, amv * sgn * s);
+                        nf = mk<R>(amv * sgs * co, amv * sgs * s);
                     }
                 }
                 v[m] = nf;
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
-            fft.template run<-1>(v, lds, j);
+            fft.fwd(v, lds, j);
             if (valid) {
                 const R sc = sgn * a.scale;
                 static_for<0, 16>([&](auto m_) {
@@ -579,14 +582,17 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
 
-    WgFft<R, N> fft;
+    using Sel = FftSel<R, N, true>;
+    typename Sel::type fft;
     fft.init(a.tw, j);
+    const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const R sgs = (js & 1) ? (R)-1 : (R)1;
     const size_t P = (size_t)g.Ph * g.Pw;
     const R wsc = (MODE & C_CONS) ? a.wscale[b] : (R)1;
     const R sc = sgn * a.scale;
     double acc_w = 0, acc_f = 0;
-    const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
+    const int r_lane = js - g.r0;  // SLM row of element m is r_lane + m*T
 
     // column schedule: tiles of 4 columns strided over the grid, or (col_list != nullptr)
     // just the listed columns -- sparse targets, see ColArgs::col_list
@@ -623,9 +629,9 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                     const int r = r_lane + m * T;
                     Cx<R> x = mk<R>(0, 0);
                     if (r >= 0 && r < g.Sh && vcol) x = gh[(unsigned)r * 4u + (unsigned)c4];
-                    v[m] = x * sgn;
+                    v[m] = x * sgs;
                 });
-                fft.template run<-1>(v, lds, j);
+                fft.fwd(v, lds, j);
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sc; });
             }
             if constexpr (MODE & C_STORE) {
@@ -690,11 +696,13 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
             }
             if constexpr (MODE & C_INV) {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgn; });
-                fft.template run<+1>(v, lds, j);
+                if constexpr (MODE & C_FWD) fft.inv_after_fwd(v, lds, j);
+                else fft.inv(v, lds, j);
+                const R scs = sgs * a.scale;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
                     const int r = r_lane + m * T;
-                    if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u + (unsigned)c4] = v[m] * sc;
+                    if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u + (unsigned)c4] = v[m] * scs;
                 });
             }
         }
@@ -737,14 +745,18 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
 
-    WgFft<R, N> fft;
+    using Sel = FftSel<R, N, true>;
+    typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
+    const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const R sgs = (js & 1) ? (R)-1 : (R)1;
+    const R scs = sgs * a.scale;
     const size_t P = (size_t)g.Ph * g.Pw;
     const R wsc = a.wscale[b];
     const R sc = sgn * a.scale;
-    const int r_lane = j - g.r0;   // SLM row of element m is r_lane + m*T
+    const int r_lane = js - g.r0;  // SLM row of element m is r_lane + m*T
     const int ntiles = g.Pw / 4;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     // listed mode: pass q of this workgroup handles the CPAR list entries of group blockIdx.x + q*gridDim.x;
@@ -815,8 +827,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         col_of(q, ct, c4);
         const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
         const bool vcol = col_valid(q);
-        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgn; });
-        fft.template run<-1>(v, lds, j);
+        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
+        fft.fwd(v, lds, j);
 
         // ---- constraint + weight update on F = sc * v ----
         R* wc = a.w + cb;
@@ -900,12 +912,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             issue_g(q + 1, gn);
         }
         if (!cp.weights_only) {
-            fft.template run<+1>(v, lds, j);
+            fft.inv_after_fwd(v, lds, j);
             Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 const int r = r_lane + m * T;
-                if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * sc;
+                if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * scs;
             });
         }
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
@@ -968,18 +980,21 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     const int j = threadIdx.x;
     const int b = blockIdx.y;
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem);
-    double* scratch = reinterpret_cast<double*>(lds + (HGS_TILE_DB ? 2 : 1) * lds_elems<N>());
+    double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
 
-    WgFft<R, N> fft;
+    using Sel = FftSel<R, N, true>;
+    typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
+    const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const R sgs = (js & 1) ? (R)-1 : (R)1;
     const size_t P = (size_t)g.Ph * g.Pw;
     const R wsc = a.wscale[b];
     // shift-theorem factor of this lane, with the (-1)^k sign and the ortho scale folded in
     Cx<R> om = a.tw[((m0 * (j & 15)) & 15) * (N / 16)];
     om = om * (sgn * a.scale);
-    const int r_lane = j + m0 * T - g.r0;   // SLM row of slot m is r_lane + m*T
+    const int r_lane = js + m0 * T - g.r0;  // SLM row of slot m is r_lane + m*T
     const int ntiles = g.Pw / 4;
     R acc_w = 0;
 
@@ -1002,6 +1017,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
 #pragma unroll 1
     for (int ct = blockIdx.x; ct < ntiles; ct += gridDim.x) {
+        HGS_T(fft.tr_n, 1);
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
@@ -1021,6 +1037,10 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         }
         if (ct == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
             issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
+#if HGS_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        HGS_T(fft.tr_n, 2);
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c) * g.Ph;
@@ -1033,17 +1053,22 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                         xr = (c == cc) ? gtx[m < NR ? m : 0][cc] : xr;
                         xi = (c == cc) ? gty[m < NR ? m : 0][cc] : xi;
                     }
-                    v[m] = mk<R>(xr * sgn, xi * sgn);
+                    v[m] = mk<R>(xr * sgs, xi * sgs);
                 } else {
                     v[m] = mk<R>(0, 0);
                 }
             }
-            fft.template run<-1, HGS_TILE_DB>(v, lds, j);
+            fft.fwd(v, lds, j);
 
             R* wc = a.w + cb;
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
             bool w_changed = false;
             // phase_ff of this lane's 16 pixels: 64 contiguous bytes, read (PHASE 2) / written (PHASE 1) as such
+            HGS_T(fft.tr_n, 3);
+#if HGS_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HGS_T(fft.tr_n, 4);
             R pf[PHASE != 0 ? 16 : 1];
             if constexpr (PHASE == 2)
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; pf[m] = pfc[lane_pos<T>(j, m)]; });
@@ -1133,11 +1158,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, upd, j, wr, tr);
             }
 
+            HGS_T(fft.tr_n, 5);
             if (EXTRAS && cp.weights_only) continue;
-            fft.template run<+1, HGS_TILE_DB>(v, lds, j);
+            fft.inv_after_fwd(v, lds, j);
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
-                const Cx<R> h = v[m] * (sgn * a.scale);
+                const Cx<R> h = v[m] * (sgs * a.scale);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     gtx[m][cc] = (c == cc) ? h.x : gtx[m][cc];
@@ -1146,6 +1172,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
         }
         if (EXTRAS && cp.weights_only) continue;
+        HGS_T(fft.tr_n, 6);
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
@@ -1156,11 +1183,20 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
         }
     }
+    HGS_T(fft.tr_n, 7);
     if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
     if (cp.do_update) {
         const double s = block_sum((double)acc_w, scratch);
         if (j == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }
+#if HGS_TRACE
+    __syncthreads();
+    {   // dump this workgroup's events: wpartial doubles as the destination in the microbenchmark
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fpartial) + (size_t)blockIdx.x * 512;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + HGS_TRACE_OFF);
+        for (int i = j; i < 512; i += blockDim.x) dst[i] = src[i];
+    }
+#endif
 }
 
 // =====================================================================================================

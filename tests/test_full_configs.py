@@ -131,7 +131,8 @@ def test_cfg3_batch_of_eight_matches_single_engines(path):
         h.optimize("WGS-Leonardo", maxiter=iters, verbose=False)
         e_ph, e_w = phase_rel_l2(got[i], h.phase), rel_l2(w[i][ky, kx], h.weights[ky, kx])
         report(f"cfg3 batch of 8 [{path}] hologram {i}", phase=e_ph, weights=e_w)
-        assert e_ph < 2e-6 and e_w < 2e-6
+        # (the weight-norm partial sums are folded over a different number of workgroups in the batch engine)
+        assert e_ph < 5e-6 and e_w < 5e-6
         h._release_engine()
     # the holograms are independent: different seeds must give different masks
     assert phase_rel_l2(got[0], got[1]) > 0.5
@@ -186,10 +187,11 @@ def test_cfg4_full_size_against_direct_summation(D, sep):
     assert abs(np.sqrt(np.sum(np.abs(ff) ** 2)) - 1) < 1e-5
     ref = np.zeros(len(spots), dtype=np.complex128)
     allp = np.arange(S)
+    amp = np.full(S, float(h.amp)) if np.isscalar(h.amp) else np.asarray(h.amp, dtype=np.float64).ravel()
     for c0 in range(0, S, 1 << 18):                # chunks of pixels: 64 x 262144 float64 at a time
         pp = allp[c0:c0 + (1 << 18)]
-        ref += np.sum(np.exp(1j * (phase[pp][None, :] - _kernel_phase(h, spots, pp))), axis=1)
-    ref *= float(h.amp) / np.sqrt(S)
+        ref += np.sum(amp[pp][None, :] * np.exp(1j * (phase[pp][None, :] - _kernel_phase(h, spots, pp))), axis=1)
+    ref *= 1 / np.sqrt(S)
     got = ff[spots]
     scale = np.real(np.vdot(ref, got)) / np.real(np.vdot(ref, ref))         # the positive factor 1 / ||ff||
     err_ff = rel_l2(got, scale * ref)
