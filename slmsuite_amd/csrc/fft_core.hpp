@@ -43,7 +43,7 @@
 #define HGS_TRACE 0
 #endif
 #ifndef HGS_TRACE_OFF
-#define HGS_TRACE_OFF 40960
+#define HGS_TRACE_OFF 49152
 #endif
 
 namespace hgs {
@@ -161,6 +161,25 @@ __device__ __forceinline__ void dft4(V& v0, V& v1, V& v2, V& v3) {
     v3 = csub_rot4<DIR>(a1, d);
 }
 
+// 4-point DFT of which only the first K inputs are non-zero (the others are not read): K = 4 is dft4
+template <int DIR, int K, typename V>
+__device__ __forceinline__ void dft4_lead(V& v0, V& v1, V& v2, V& v3) {
+    static_assert(K >= 1 && K <= 4, "dft4_lead");
+    if constexpr (K == 4) {
+        dft4<DIR>(v0, v1, v2, v3);
+    } else if constexpr (K == 1) {
+        v1 = v0; v2 = v0; v3 = v0;
+    } else {
+        V a0 = v0, a1 = v0;
+        if constexpr (K == 3) { a0 = v0 + v2; a1 = v0 - v2; }
+        const V b = v1;
+        v0 = a0 + b;
+        v2 = a0 - b;
+        v1 = cadd_rot4<DIR>(a1, b);
+        v3 = csub_rot4<DIR>(a1, b);
+    }
+}
+
 // R-point DFT, v[r] natural order in, V[p] natural order out (in place).
 template <int RADIX, int DIR, typename R> struct Dft;
 
@@ -225,6 +244,33 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
     static __device__ __forceinline__ void run(Cx<R> (&v)[16]) {
         const Cx<R> z = mk<R>(0, 0);
         run_tw<false>(v, z, z, z);
+    }
+    // The same transform when only the first NZ inputs are non-zero (zero-padded fields: the rows outside the SLM):
+    // the first radix-4 layer shrinks to the non-zero inputs (NZ = 6: 8 packed operations instead of 32).
+    template <int NZ> static __device__ __forceinline__ void run_lead(Cx<R> (&v)[16]) {
+        static_assert(NZ >= 4 && NZ <= 16, "run_lead: at least one non-zero input per radix-4 butterfly");
+        if constexpr (NZ == 16) {
+            run(v);
+        } else {
+            dft4_lead<DIR, (NZ - 0 + 3) / 4>(v[0], v[4], v[8], v[12]);
+            dft4_lead<DIR, (NZ - 1 + 3) / 4>(v[1], v[5], v[9], v[13]);
+            dft4_lead<DIR, (NZ - 2 + 3) / 4>(v[2], v[6], v[10], v[14]);
+            dft4_lead<DIR, (NZ - 3 + 3) / 4>(v[3], v[7], v[11], v[15]);
+            v[5] = rot16<1, DIR>(v[5]);   v[6] = rot16<2, DIR>(v[6]);   v[7] = rot16<3, DIR>(v[7]);
+            v[9] = rot16<2, DIR>(v[9]);   v[10] = rot16<4, DIR>(v[10]); v[11] = rot16<6, DIR>(v[11]);
+            v[13] = rot16<3, DIR>(v[13]); v[14] = rot16<6, DIR>(v[14]); v[15] = rot16<9, DIR>(v[15]);
+            dft4<DIR>(v[0], v[1], v[2], v[3]);
+            dft4<DIR>(v[4], v[5], v[6], v[7]);
+            dft4<DIR>(v[8], v[9], v[10], v[11]);
+            dft4<DIR>(v[12], v[13], v[14], v[15]);
+            Cx<R> t;
+            t = v[1]; v[1] = v[4]; v[4] = t;
+            t = v[2]; v[2] = v[8]; v[8] = t;
+            t = v[3]; v[3] = v[12]; v[12] = t;
+            t = v[6]; v[6] = v[9]; v[9] = t;
+            t = v[7]; v[7] = v[13]; v[13] = t;
+            t = v[11]; v[11] = v[14]; v[14] = t;
+        }
     }
     // The mirror image (decimation in frequency): same 16-point transform, the stage twiddle W^(p k) of OUTPUT
     // p = p1 + 4*p2 applied on the way out, again in split form: W^(p1 k) = bt[p1-1] between the two radix-4
@@ -457,6 +503,8 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
     }
     // uniform entry points (see WgFftL for why the inverse comes in two flavours)
     __device__ __forceinline__ void fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<-1>(v, lds, j); }
+    // (registers NZ.. of the input are zero: only WgFftL prunes its first stage for it)
+    template <int NZ> __device__ __forceinline__ void fwd_lead(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<-1>(v, lds, j); }
     __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<+1>(v, lds, j); }
     __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<+1>(v, lds, j); }
 };
@@ -541,10 +589,10 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
 
     // forward (DIR = -1 with the table as stored; DIR = +1 gives the conjugate transform in the same flow):
     // space layout in, frequency layout out
-    template <int DIR> __device__ __forceinline__ void forward_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
+    template <int DIR, int NZ = 16> __device__ __forceinline__ void forward_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
         Cx<R>* rowb = lds + ROW * (p >> 4);
         HGS_T(tr_n, 10);
-        Dft<16, DIR, R>::run(v);
+        Dft<16, DIR, R>::template run_lead<NZ>(v);
         HGS_T(tr_n, 11);
         {   // 16 x 16 transpose inside the row of 16 lanes
             Cx<R>* w = rowb + 17 * (p & 15);
@@ -605,6 +653,8 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         else mirror_flow<+1, LEAD>(v, lds, p);
     }
     __device__ __forceinline__ void fwd(Cx<R> (&v)[16], Cx<R>* lds, int p) { forward_flow<-1>(v, lds, p); }
+    // registers NZ.. of the input are zero
+    template <int NZ> __device__ __forceinline__ void fwd_lead(Cx<R> (&v)[16], Cx<R>* lds, int p) { forward_flow<-1, NZ>(v, lds, p); }
     __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, true>(v, lds, p); }
     // the previous LDS user of every wave was this workgroup's forward transform (or nothing)
     __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, false>(v, lds, p); }

@@ -361,7 +361,7 @@ template <typename R> struct RowArgs {
 };
 
 template <typename R, int N, int MODE>
-__global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs<R> a) {
+__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) void row_kernel(RowArgs<R> a) {
     using M = Math<R>;
     constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(RowCfg<N>::WG, HGS_ROW_OCC) void row_kernel(RowArgs
         __syncthreads();
     }
 
-    using Sel = FftSel<R, N, HGS_ROW_TW_RESIDENT>;
+    // (fp64: 64 data registers per lane already; the stage twiddles are fetched per use instead of kept)
+    using Sel = FftSel<R, N, (sizeof(R) == 8 ? false : HGS_ROW_TW_RESIDENT)>;
     typename Sel::type fft;
     fft.init(a.tw, j);
 
@@ -745,7 +746,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
 
-    using Sel = FftSel<R, N, true>;
+    // fp64 doubles every register: keep the weight/target prefetch, drop the resident stage twiddles and the
+    // prefetch of the next column's G (both spilled to scratch otherwise: 662 spilled VGPRs at 8192)
+    constexpr bool LEAN = sizeof(R) == 8;
+    using Sel = FftSel<R, N, !LEAN>;
     typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         StatAcc<R>::slot_init(stat_slot);
     }
 
-    Cx<R> v[16], gn[16];
+    Cx<R> v[16], gn[LEAN ? 1 : 16];
     R wr[16], tr[16];
 
     auto col_of = [&](int q, int& ct, int& c4) {
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
 
     if (ncols > 0) {
         issue_g(0, v);
-        issue_wt(0);
+        if constexpr (!LEAN) issue_wt(0);
     }
 #pragma unroll 1
     for (int q = 0; q < ncols; ++q) {
@@ -829,6 +833,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const bool vcol = col_valid(q);
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
         fft.fwd(v, lds, j);
+        if constexpr (LEAN) issue_wt(q);      // fp64: loaded at the point of use (register budget)
 
         // ---- constraint + weight update on F = sc * v ----
         R* wc = a.w + cb;
@@ -908,8 +913,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         }
         // ---- prefetch the next column while this one is transformed back ----
         if (q + 1 < ncols) {
-            issue_wt(q + 1);
-            issue_g(q + 1, gn);
+            if constexpr (!LEAN) {
+                issue_wt(q + 1);
+                issue_g(q + 1, gn);
+            }
         }
         if (!cp.weights_only) {
             fft.inv_after_fwd(v, lds, j);
@@ -920,7 +927,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * scs;
             });
         }
-        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
+        if constexpr (!LEAN) {
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
+        } else if (q + 1 < ncols) {
+            issue_g(q + 1, v);
+        }
     }
     if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
     if (cp.do_update) {
@@ -970,6 +981,11 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
 }
 
 // EXTRAS = false compiles the MRAF / Nogrette / forward-only branches out (2.7 us of the 58 us dense launch)
+// dynamic LDS of col_tile_kernel: transform image + reduction scratch
+template <typename R, int N> constexpr size_t col_tile_lds_bytes() {
+    return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
+}
+
 template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true>
 __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
     using M = Math<R>;
@@ -1058,7 +1074,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     v[m] = mk<R>(0, 0);
                 }
             }
-            fft.fwd(v, lds, j);
+            fft.template fwd_lead<NR>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
 
             R* wc = a.w + cb;
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;

@@ -71,7 +71,7 @@ template <> int LAUNCH_FUSED<HGS_REAL>(int N, int phase, dim3 grid, hipStream_t 
 #ifdef HGS_REAL_IS_FLOAT
 template <int N, int PHASE>
 static int launch_tile_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-    constexpr size_t lds = (size_t)lds_elems<N>() * sizeof(Cx<float>) + SCRATCH_DOUBLES * sizeof(double);
+    constexpr size_t lds = col_tile_lds_bytes<float, N>();
     auto k = col_tile_kernel<float, N, PHASE, 6, kStats, kExtras>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),

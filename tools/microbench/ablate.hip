@@ -30,10 +30,10 @@ int main() {
     RowArgs<float> ra{}; ra.g = g; ra.phase = phase; ra.amp_scalar = 1e-3f; ra.gh = gh; ra.tw = tw; ra.scale = 1.f / 64; ra.wscale = wscale; ra.xcd_map = 1;
     ColArgs<float> ca{}; ca.g = g; ca.gh = gh; ca.w = w; ca.t = t; ca.wscale = wscale; ca.wpartial = wp; ca.tw = tw; ca.scale = 1.f / 64;
     ca.cp.method = M_LEONARDO; ca.cp.do_update = 1; ca.cp.p_exp = 0.8f; ca.cp.inv_fnorm = 1.f; ca.cp.log2_inv_fnorm = 0.f;
-    const size_t lds = lds_elems<4096>() * 8 + 128;
+    const size_t lds = lds_elems<4096>() * 8 + 128, tlds = col_tile_lds_bytes<float, 4096>();
     hipLaunchKernelGGL((row_kernel<float, 4096, 0>), dim3(1152), dim3(256), lds, 0, ra);
     printf("ABL trans=%d xchg=%d bfly=%d : row<2> %.1f us   col_tile %.1f us\n", HGS_ABL_TRANS, HGS_ABL_XCHG, HGS_ABL_BFLY,
            timeit([&] { hipLaunchKernelGGL((row_kernel<float, 4096, 2>), dim3(1152), dim3(256), lds, 0, ra); }),
-           timeit([&] { hipLaunchKernelGGL((col_tile_kernel<float, 4096, 0, 6>), dim3(512), dim3(256), lds, 0, ca, 5); }));
+           timeit([&] { hipLaunchKernelGGL((col_tile_kernel<float, 4096, 0, 6>), dim3(512), dim3(256), tlds, 0, ca, 5); }));
     return 0;
 }
