@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 evidence for one round: kernel-trace stats + PMC passes (separate runs, as the guide prescribes).
 # usage (on the GPU box, from the repo root): bash tools/profile.sh <tag> [bench args]
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
-BENCH="python $ROOTDIR/bench.py --steps 40 --warmup 5 --cpu-iters 0 --no-roofline-pass $@"
+BENCH="python $ROOTDIR/bench.py --steps 40 --warmup 5 --cpu-iters 0 --no-roofline-pass --pmc 0 $@"
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $ROOTDIR/$OUT/stats -o stats -- $BENCH > $ROOTDIR/$OUT/stats.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $ROOTDIR/$OUT/pmc_sq -o pmc -- $BENCH > $ROOTDIR/$OUT/pmc_sq.log 2>&1

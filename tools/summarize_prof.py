@@ -49,7 +49,7 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
 if agg:
     print("## PMC counters (mean per dispatch)\n")
     for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
-        if not any(s in k for s in ("col_", "row_kernel")):
+        if not any(s in k for s in ("col_", "row_kernel", "cgemm", "sep_", "c_n2f", "c_f2n")):
             continue
         print(f"### `{k}`\n")
         print("| counter | mean / dispatch | dispatches |")
