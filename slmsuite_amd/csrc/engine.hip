@@ -16,6 +16,8 @@
 #include "compressed_kernels.hpp"
 #include "cgemm.hpp"
 #include "compressed_sep.hpp"
+#include "bluestein.hpp"
+#include <complex>
 
 namespace hgs {
 
@@ -135,6 +137,11 @@ template <typename R> struct Engine : EngineBase {
     struct StatCtx { int groups = 0, width = 1; double* dev_out = nullptr; int* dxy = nullptr; };
     StatCtx* stat_ctx = nullptr;      // non-null while hgs_iterate_stats drives the fused loop
     size_t stat_nslots = 0;
+    // padded shapes that are not powers of two in [64, 8192]: Bluestein path (bluestein.hpp)
+    bool general = false;
+    int blue_M[2] = {0, 0};            // convolution lengths for x (rows, N = Pw) and y (columns, N = Ph)
+    C* blue_tab[2][2][3] = {};         // [x|y][forward|inverse][A, Bf, Cc]
+    C* blue_tw[2] = {nullptr, nullptr};
     // kind 1 (compressed)
     R* xg = nullptr;
     R* yg = nullptr;
@@ -181,6 +188,9 @@ template <typename R> struct Engine : EngineBase {
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
         for (void* p : ptrs)
             if (p) hipFree(p);
+        for (auto& d : blue_tab) for (auto& dir : d) for (C* t3 : dir) if (t3) hipFree(t3);
+        if (blue_tw[0]) hipFree(blue_tw[0]);
+        if (blue_tw[1] && blue_tw[1] != blue_tw[0]) hipFree(blue_tw[1]);
         for (auto& e : evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
         if (stream) hipStreamDestroy(stream);
     }
@@ -228,10 +238,15 @@ template <typename R> struct Engine : EngineBase {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (c.kind == 1) return init_compressed(c);
         if (c.kind != 0) return fail(HGS_ERR_ARG, "unknown engine kind %d", c.kind);
-        if (!is_pow2(c.pad_h) || !is_pow2(c.pad_w) || c.pad_h < 64 || c.pad_w < 64 || c.pad_h > 8192 ||
-            c.pad_w > 8192)
-            return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d) must be powers of two in [64, 8192]",
-                        c.pad_h, c.pad_w);
+        const bool fast = is_pow2(c.pad_h) && is_pow2(c.pad_w) && c.pad_h >= 64 && c.pad_w >= 64 && c.pad_h <= 8192 &&
+                          c.pad_w <= 8192;
+        if (!fast) {
+            // any other shape up to 4096 per axis runs through Bluestein's identity on the power-of-two transforms
+            if (c.pad_h < 2 || c.pad_w < 2 || c.pad_h > 4096 || c.pad_w > 4096)
+                return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d): powers of two in [64, 8192] or any shape with "
+                            "2 <= n <= 4096 per axis", c.pad_h, c.pad_w);
+            general = true;
+        }
         if (c.slm_h < 1 || c.slm_w < 1 || c.slm_h > c.pad_h || c.slm_w > c.pad_w)
             return fail(HGS_ERR_ARG, "slm shape (%d, %d) does not fit the padded shape (%d, %d)", c.slm_h,
                         c.slm_w, c.pad_h, c.pad_w);
@@ -240,9 +255,11 @@ template <typename R> struct Engine : EngineBase {
         g.r0 = (c.pad_h - c.slm_h) / 2;  // floor((P-S)/2)  toolbox.unpad
         g.c0 = (c.pad_w - c.slm_w) / 2;
         g.batch = B = c.batch;
+        g.lane_T = general ? 0 : g.Ph / 16;
         S = (size_t)g.Sh * g.Sw;
         P = (size_t)g.Ph * g.Pw;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (general) return init_general(c);
 
         // grid sizes: enough workgroups to fill the chip a few times over, balanced over the work
         const int fpw = row_fpw(g.Pw);
@@ -283,6 +300,151 @@ template <typename R> struct Engine : EngineBase {
         amp_norm2 = 1.0;
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
+    }
+
+    // ---- general padded shapes (Bluestein) ----------------------------------------------------------
+    static void host_fft(std::vector<std::complex<double>>& a) {      // in-place radix-2, forward sign
+        const size_t n = a.size();
+        for (size_t i = 1, j = 0; i < n; ++i) {
+            size_t bit = n >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) std::swap(a[i], a[j]);
+        }
+        for (size_t len = 2; len <= n; len <<= 1) {
+            const double ang = -2.0 * M_PI / (double)len;
+            for (size_t i = 0; i < n; i += len)
+                for (size_t k = 0; k < len / 2; ++k) {
+                    const std::complex<double> w(std::cos(ang * (double)k), std::sin(ang * (double)k));
+                    const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+                    a[i + k] = u + v;
+                    a[i + k + len / 2] = u - v;
+                }
+        }
+    }
+    // tables of one centred transform of length N (bluestein.hpp): dir = -1 forward, +1 inverse
+    int make_blue_tables(int N, int M, int dir, C** out3) {
+        using cd = std::complex<double>;
+        const long long h = N / 2;
+        const double sg = dir < 0 ? -1.0 : 1.0;
+        auto unit = [&](long long num, long long den, double sign) {     // exp(sign * 2 pi i * num / den), num reduced first
+            long long r = num % den;
+            if (r < 0) r += den;
+            const double a = sign * 2.0 * M_PI * (double)r / (double)den;
+            return cd(std::cos(a), std::sin(a));
+        };
+        std::vector<cd> chirp(N), A(N), Cc(N), bt(M, cd(0, 0));
+        for (long long n = 0; n < N; ++n) chirp[n] = unit(n * n, 2LL * N, sg);       // W^(n^2/2), W = exp(sg 2 pi i / N)
+        const double sc = 1.0 / std::sqrt((double)N);
+        for (long long n = 0; n < N; ++n) {
+            // forward: pre = W^(-n h), post = W^(h (k - h));  inverse (W -> conj W): pre = Wc^(n h), post = Wc^(-h (i + h))
+            const cd pre = dir < 0 ? unit(-n * h, N, -1.0) : unit(n * h, N, 1.0);
+            const cd post = dir < 0 ? unit(h * (n - h), N, -1.0) : unit(-h * (n + h), N, 1.0);
+            A[n] = pre * chirp[n];
+            Cc[n] = post * chirp[n] * sc;
+        }
+        bt[0] = std::conj(chirp[0]);
+        for (int d = 1; d < N; ++d) bt[d] = bt[M - d] = std::conj(chirp[d]);
+        host_fft(bt);
+        for (auto& v : bt) v /= (double)M;
+        auto up = [&](const std::vector<cd>& src, C** dst) -> int {
+            std::vector<C> hbuf(src.size());
+            for (size_t i = 0; i < src.size(); ++i) { hbuf[i].x = (R)src[i].real(); hbuf[i].y = (R)src[i].imag(); }
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(dst), hbuf.size() * sizeof(C)));
+            return h2d(*dst, hbuf.data(), hbuf.size() * sizeof(C));
+        };
+        if (int e = up(A, &out3[0])) return e;
+        if (int e = up(bt, &out3[1])) return e;
+        return up(Cc, &out3[2]);
+    }
+    int init_general(const hgs_config& c) {
+        auto conv_len = [](int N) { int M = 256; while (M < 2 * N - 1) M <<= 1; return M; };
+        blue_M[0] = conv_len(g.Pw);
+        blue_M[1] = conv_len(g.Ph);
+        ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
+        col_blocks = tile_blocks = row_blocks = 1;
+        if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
+        if (dalloc(&gh, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE;
+        if (dalloc(&nfbuf, B * S)) return HGS_ERR_DEVICE;
+        if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&wpartial, (size_t)B * n_cu * 3)) return HGS_ERR_DEVICE;
+        if (dalloc(&fpartial, (size_t)B * std::max(ew_blocks, n_cu * 3))) return HGS_ERR_DEVICE;
+        if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
+        if (dalloc(&sums, (size_t)4 * B)) return HGS_ERR_DEVICE;
+        if (dalloc(&wscale, (size_t)B)) return HGS_ERR_DEVICE;
+        if (int e = fill_wscale_one()) return e;
+        for (int d = 0; d < 2; ++d) {
+            const int N = d == 0 ? g.Pw : g.Ph;
+            if (d == 1 && blue_M[1] == blue_M[0]) blue_tw[1] = blue_tw[0];
+            else if (int e = make_twiddles(&blue_tw[d], blue_M[d])) return e;
+            if (int e = make_blue_tables(N, blue_M[d], -1, blue_tab[d][0])) return e;
+            if (int e = make_blue_tables(N, blue_M[d], +1, blue_tab[d][1])) return e;
+        }
+        if (c.n_spots > 0) {
+            if (dalloc(&spot_xy, (size_t)2 * c.n_spots)) return HGS_ERR_DEVICE;
+            if (dalloc(&spot_amp, (size_t)c.n_spots)) return HGS_ERR_DEVICE;
+            if (dalloc(&ext_amp, (size_t)c.n_spots)) return HGS_ERR_DEVICE;
+            if (dalloc(&spot_fb, (size_t)B * c.n_spots)) return HGS_ERR_DEVICE;
+        }
+        amp_scalar = 1.0 / std::sqrt((double)S);
+        amp_norm2 = 1.0;
+        HIPCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int blue_pass(int dim, int dir, const C* in, size_t in_line, size_t in_batch, int in_stride, int in_start, int in_len,
+                  C* out, size_t out_line, size_t out_batch, int out_stride, int out_start, int out_len, int lines) {
+        BlueArgs<R> a{};
+        a.in = in; a.out = out; a.in_line = in_line; a.out_line = out_line; a.in_batch = in_batch; a.out_batch = out_batch;
+        a.in_stride = in_stride; a.out_stride = out_stride; a.in_start = in_start; a.in_len = in_len;
+        a.out_start = out_start; a.out_len = out_len; a.N = dim == 0 ? g.Pw : g.Ph;
+        C** t3 = blue_tab[dim][dir < 0 ? 0 : 1];
+        a.A = t3[0]; a.Bf = t3[1]; a.Cc = t3[2]; a.tw = blue_tw[dim];
+        LCHK(launch_bluestein<R>(blue_M[dim], dim3(lines, B), stream, a));
+        return 0;
+    }
+    int n2f_general(int store_pff) {
+        if (int e = need_ff()) return e;
+        if (store_pff) { if (int e = need_pff()) return e; }
+        int r = timed(HGS_K_ROW, [&]() -> int {
+            hipLaunchKernelGGL(gen_build_nearfield<R>, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, (const R*)phase,
+                               has_amp ? (const R*)amp : (const R*)nullptr, has_kern ? (const R*)kern : (const R*)nullptr,
+                               (R)amp_scalar, S, nfbuf);
+            HIPCHK(hipGetLastError());
+            // rows: nearfield block (zero outside the SLM columns) -> G[r][kx]
+            return blue_pass(0, -1, nfbuf, g.Sw, S, 1, g.c0, g.Sw, gh, g.Pw, (size_t)g.Sh * g.Pw, 1, 0, g.Pw, g.Sh);
+        });
+        if (r) return r;
+        r = timed(HGS_K_COL_FWD, [&]() -> int {
+            // columns: G[:, kx] (zero outside the SLM rows) -> farfield, column-major
+            if (int e = blue_pass(1, -1, gh, 1, (size_t)g.Sh * g.Pw, g.Pw, g.r0, g.Sh, ff, g.Ph, P, 1, 0, g.Ph, g.Pw)) return e;
+            hipLaunchKernelGGL(gen_amp_store<R>, dim3(ew_blocks, B), dim3(256), 0, stream, (const C*)ff, aff,
+                               store_pff ? pff : (R*)nullptr, P, fpartial);
+            HIPCHK(hipGetLastError());
+            return 0;
+        });
+        if (r) return r;
+        if (int e = reduce(fpartial, ew_blocks, sums + 0 * B)) return e;
+        if (store_pff) have_pff = true;
+        farfield_valid = true;
+        return 0;
+    }
+    int f2n_general(bool complex_only) {
+        if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
+        int r = timed(HGS_K_COL_INV, [&]() -> int {
+            return blue_pass(1, +1, ff, g.Ph, P, 1, 0, g.Ph, gh, 1, (size_t)g.Sh * g.Pw, g.Pw, g.r0, g.Sh, g.Pw);
+        });
+        if (r) return r;
+        farfield_valid = false;
+        return timed(HGS_K_ROW, [&]() -> int {
+            if (int e = blue_pass(0, +1, gh, g.Pw, (size_t)g.Sh * g.Pw, 1, 0, g.Pw, nfbuf, g.Sw, S, 1, g.c0, g.Sw, g.Sh)) return e;
+            if (!complex_only) {
+                hipLaunchKernelGGL(gen_extract_phase<R>, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, (const C*)nfbuf,
+                                   has_kern ? (const R*)kern : (const R*)nullptr, S, phase);
+                HIPCHK(hipGetLastError());
+            }
+            return 0;
+        });
     }
 
     int init_compressed(const hgs_config& c) {
@@ -601,7 +763,7 @@ template <typename R> struct Engine : EngineBase {
         }
         dim3 grid((g.Pw + 31) / 32, (g.Ph + 31) / 32, B);
         hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, (const E*)st, dst, g.Ph, g.Pw,
-                           (const R*)nullptr, cfg.kind == 0 ? g.Ph / 16 : 0, 1);
+                           (const R*)nullptr, cfg.kind == 0 ? g.lane_T : 0, 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
@@ -613,7 +775,7 @@ template <typename R> struct Engine : EngineBase {
         E* st = reinterpret_cast<E*>(staging);
         dim3 grid((g.Ph + 31) / 32, (g.Pw + 31) / 32, B);
         hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, src, st, g.Pw, g.Ph, scale,
-                           cfg.kind == 0 ? g.Ph / 16 : 0, 0);
+                           cfg.kind == 0 ? g.lane_T : 0, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(dst, st, all, dst_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -881,6 +1043,7 @@ template <typename R> struct Engine : EngineBase {
 
     int n2f(int store_pff) override {
         if (cfg.kind == 1) return n2f_compressed(store_pff);
+        if (general) return n2f_general(store_pff);
         if (int e = need_ff()) return e;
         if (store_pff) { if (int e = need_pff()) return e; }
         if (int e = run_row(0, false)) return e;
@@ -899,6 +1062,7 @@ template <typename R> struct Engine : EngineBase {
 
     int f2n() override {
         if (cfg.kind == 1) return f2n_compressed();
+        if (general) return f2n_general(false);
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
         int r = timed(HGS_K_COL_INV, [&]() -> int {
             LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(col_blocks, B), stream, col_args()));
@@ -914,6 +1078,7 @@ template <typename R> struct Engine : EngineBase {
     int f2n_complex() override {
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
         if (!nfbuf) { if (dalloc(&nfbuf, B * S)) return HGS_ERR_DEVICE; }
+        if (general) return f2n_general(true);
         if (cfg.kind == 1) {
             int r = timed(HGS_K_COL_INV, [&]() -> int {
                 if (use_sep()) return sep_f2n(nfbuf);
@@ -1090,7 +1255,7 @@ template <typename R> struct Engine : EngineBase {
 
     bool fused_ok(const hgs_step* st) const {
         // MRAF rides the fused kernels unless the zero region carries zero_weights feedback (:1613-1616)
-        return cfg.kind == 0 && !(st->mraf_enabled && st->zero_mode) && st->feedback == HGS_FB_PIXEL;
+        return cfg.kind == 0 && !general && !(st->mraf_enabled && st->zero_mode) && st->feedback == HGS_FB_PIXEL;
     }
 
     // ---- spot feedback on sparse targets ("computational_spot" / "external_spot", _spots.py:1573-1624) ----
@@ -1100,7 +1265,7 @@ template <typename R> struct Engine : EngineBase {
     // field is formed and transformed back by the fused kernel over the spot columns (weight update
     // off).  Everything else of the farfield is exactly zero and is neither computed nor moved.
     bool spot_sparse_ok(const hgs_step* st) {
-        if (cfg.kind != 0 || st->mraf_enabled || st->method == HGS_GS || st->feedback == HGS_FB_PIXEL) return false;
+        if (cfg.kind != 0 || general || st->mraf_enabled || st->method == HGS_GS || st->feedback == HGS_FB_PIXEL) return false;
         if (!opt_sparse || opt_stepwise) return false;
         if (refresh_sparse()) return false;
         return n_active_min > 0 && n_active_max * 4 <= g.Pw;

@@ -49,6 +49,7 @@ namespace hgs {
 
 struct Geo {
     int Ph, Pw, Sh, Sw, r0, c0, batch;
+    int lane_T;     // Ph / 16 when the columns of the farfield-sized arrays are stored lane-major (below), 0 = natural
 };
 
 // Inside each column of the column-major farfield-sized arrays the Ph entries are stored
@@ -60,7 +61,7 @@ struct Geo {
 #define HGS_LANE_MAJOR 1
 #endif
 __host__ __device__ __forceinline__ int col_pos(int ky, int T) {
-    return HGS_LANE_MAJOR ? (ky % T) * 16 + ky / T : ky;
+    return (HGS_LANE_MAJOR && T > 0) ? (ky % T) * 16 + ky / T : ky;
 }
 template <int T> __device__ __forceinline__ unsigned lane_pos(int j, int m) {
     return HGS_LANE_MAJOR ? (unsigned)(j * 16 + m) : (unsigned)(j + m * T);
@@ -528,14 +529,12 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
 //   FWD   : G -> F            (column half of fft2, zero rows outside the SLM are never read)
 //   STORE : write F, |F| (and optionally atan2 F) to the column-major farfield arrays
 //           (_midloop_cleaning :953, _populate_results :948-949) + sum |F|^2 partial
-//   CONS  : farfield constraint + weight update inline (_gs_farfield_routines :1550-1605,
-//           _update_weights_generic :1822-1879), pixel feedback, no MRAF
 //   LOAD  : read the (already constrained) farfield array instead
 //   INV   : F -> H            (column half of ifft2; only the Sh SLM rows are produced)
 // grid = (<= Pw/4, batch), block = T*CPAR; a workgroup strides over tiles, the 4 columns of a tile
 // run CPAR at a time.
 // =====================================================================================================
-enum { C_FWD = 1, C_STORE = 2, C_CONS = 4, C_LOAD = 8, C_INV = 16 };
+enum { C_FWD = 1, C_STORE = 2, C_LOAD = 8, C_INV = 16 };
 
 template <int N> struct ColCfg {
     static constexpr int T = N / 16;
@@ -590,9 +589,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
     const size_t P = (size_t)g.Ph * g.Pw;
-    const R wsc = (MODE & C_CONS) ? a.wscale[b] : (R)1;
     const R sc = sgn * a.scale;
-    double acc_w = 0, acc_f = 0;
+    double acc_f = 0;
     const int r_lane = js - g.r0;  // SLM row of element m is r_lane + m*T
 
     // column schedule: tiles of 4 columns strided over the grid, or (col_list != nullptr)
@@ -652,45 +650,6 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
-            if constexpr (MODE & C_CONS) {
-                const CParams<R> cp = a.cp;
-                R* wc = a.w + cb;
-                const R* tc = a.t + cb;
-                R* pfc = a.pff ? a.pff + cb : nullptr;
-                static_for<0, 16>([&](auto m_) {
-                    constexpr int m = m_;
-                    const unsigned idx = lane_pos<T>(j, m);
-                    const Cx<R> F = v[m];
-                    R wv = wc[idx] * wsc;
-                    const R p2 = F.x * F.x + F.y * F.y;
-                    if (cp.do_update) {
-                        const R t = tc[idx];
-                        const R fb = M::sqrt(p2) * cp.inv_fnorm;
-                        const R fc = weight_factor<R>(cp.method, fb, t, cp.p_exp, cp.p_fac, (R)0);
-                        wv = wv * fc;
-                        if (is_nan(wv)) wv = (R)0.0001;   // :1873
-                        wc[idx] = wv;
-                        acc_w += (double)wv * (double)wv;
-                    }
-                    R co, si;
-                    if (cp.use_fixed) {
-                        M::sincos(pfc[idx], &si, &co);
-                    } else {
-                        // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 -> 1  (quirk A6)
-                        if (p2 > (R)0) {
-                            const R inv = M::rsqrt(p2);
-                            co = F.x * inv;
-                            si = F.y * inv;
-                        } else {
-                            co = 1;
-                            si = 0;
-                        }
-                        if (cp.store_phase) pfc[idx] = M::atan2(F.y, F.x);
-                    }
-                    v[m] = mk<R>(wv * co, wv * si);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
             if constexpr (MODE & C_LOAD) {
                 const Cx<R>* ffc = a.ff + cb;
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = ffc[lane_pos<T>(j, m)]; });
@@ -706,12 +665,6 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                     if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u + (unsigned)c4] = v[m] * scs;
                 });
             }
-        }
-    }
-    if constexpr (MODE & C_CONS) {
-        if (a.cp.do_update) {
-            const double s = block_sum(acc_w, scratch);
-            if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
         }
     }
     if constexpr (MODE & C_STORE) {
@@ -1430,7 +1383,7 @@ template <typename R> __device__ __forceinline__ R spot_window_value(const SpotA
     for (int dy = 0; dy < a.width; ++dy)
         for (int dx = 0; dx < a.width; ++dx) {
             const int x = kx + lo + dx, y = ky + lo + dy;
-            const R v = a.amp_ff[(size_t)b * P + (size_t)x * a.g.Ph + col_pos(y, a.g.Ph / 16)];
+            const R v = a.amp_ff[(size_t)b * P + (size_t)x * a.g.Ph + col_pos(y, a.g.lane_T)];
             const R v2 = v * v;  // cp.square in working precision, then astype(float) (:1592, take :202)
             s += (double)v2;
         }
@@ -1481,7 +1434,7 @@ template <typename R> __global__ void spot_update(SpotArgs<R> a) {
     acc = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int kx = a.spot_xy[n], ky = a.spot_xy[N + n];
-        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + col_pos(ky, a.g.Ph / 16);
+        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + col_pos(ky, a.g.lane_T);
         const R f = (a.feedback == 2) ? (R)a.ext_amp[n] : a.fb[(size_t)b * N + n];
         const R fc = weight_factor<R>(a.cp.method, f * inv_fn, (R)a.spot_amp[n], a.cp.p_exp, a.cp.p_fac, nog);
         R wv = a.w[idx] * fc;
@@ -1495,7 +1448,7 @@ template <typename R> __global__ void spot_update(SpotArgs<R> a) {
     const R wsc = (R)1 / (R)::sqrt(bc);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int kx = a.spot_xy[n], ky = a.spot_xy[N + n];
-        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + col_pos(ky, a.g.Ph / 16);
+        const size_t idx = (size_t)b * P + (size_t)kx * a.g.Ph + col_pos(ky, a.g.lane_T);
         a.w[idx] *= wsc;
     }
 }

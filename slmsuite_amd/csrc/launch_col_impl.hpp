@@ -21,7 +21,6 @@ static int launch_col_n(int mode, dim3 grid, hipStream_t s, const ColArgs<R>& a)
     switch (mode) {
         case (C_FWD | C_STORE): return launch_col_one<R, N, (C_FWD | C_STORE)>(grid, s, a);
         case (C_LOAD | C_INV): return launch_col_one<R, N, (C_LOAD | C_INV)>(grid, s, a);
-        case (C_FWD | C_CONS | C_INV): return launch_col_one<R, N, (C_FWD | C_CONS | C_INV)>(grid, s, a);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -14,7 +14,7 @@ template <typename F> float timeit(F f, int reps = 30) {
     float ms; hipEventElapsedTime(&ms, a, b); return ms / reps * 1e3f;
 }
 int main() {
-    Geo g{4096, 4096, 1152, 1920, 1472, 1088, 1};
+    Geo g{4096, 4096, 1152, 1920, 1472, 1088, 1, 256};
     const size_t S = (size_t)g.Sh * g.Sw, P = (size_t)g.Ph * g.Pw;
     float *phase, *w, *t, *wscale; v2f *gh, *tw; double* wp;
     hipMalloc(&phase, S * 4); hipMalloc(&w, P * 4); hipMalloc(&t, P * 4); hipMalloc(&gh, (size_t)g.Sh * g.Pw * 8);

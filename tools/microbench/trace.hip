@@ -8,7 +8,7 @@
 #include <algorithm>
 using namespace hgs;
 int main() {
-    Geo g{4096, 4096, 1152, 1920, 1472, 1088, 1};
+    Geo g{4096, 4096, 1152, 1920, 1472, 1088, 1, 256};
     const size_t P = (size_t)g.Ph * g.Pw;
     float *w, *t, *wscale; v2f *gh, *tw; double *wp, *fp;
     hipMalloc(&w, P * 4); hipMalloc(&t, P * 4); hipMalloc(&gh, (size_t)g.Sh * g.Pw * 8);
