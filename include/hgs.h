@@ -172,9 +172,11 @@ int hgs_sync(hgs_engine* e);
  *   complex GEMMs on the matrix cores when the basis and the grid factorise; 0 forces the direct kernels.
  * Options are per engine and take effect at the next call; nothing is read from the environment after
  * hgs_create (which reads the developer grid-size overrides HGS_ROW_BLOCKS / HGS_COL_BLOCKS / HGS_TILE_BLOCKS /
- * HGS_ROW_XCD once). */
+ * HGS_ROW_XCD once).
+ * HGS_OPT_ROCTX (default 0): roctx ranges (hgs_iterate, hgs_nearfield2farfield, hgs_farfield_constraint,
+ *   hgs_farfield2nearfield) for rocprofv3 --marker-trace; the roctx library is dlopen'ed on first use. */
 enum { HGS_OPT_SPARSE_COLUMNS = 1, HGS_OPT_FORCE_STEPWISE = 2, HGS_OPT_TILE_KERNEL = 3, HGS_OPT_SEPARABLE = 4,
-       HGS_OPT_SEPARABLE_MIN_SPOTS = 5 };
+       HGS_OPT_SEPARABLE_MIN_SPOTS = 5, HGS_OPT_ROCTX = 6 };
 int hgs_set_option(hgs_engine* e, int option, int value);
 
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */

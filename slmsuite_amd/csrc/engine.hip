@@ -18,6 +18,7 @@
 #include "compressed_sep.hpp"
 #include "bluestein.hpp"
 #include <complex>
+#include <dlfcn.h>
 
 namespace hgs {
 
@@ -44,6 +45,35 @@ static int fail(int code, const char* fmt, ...) {
             return fail(HGS_ERR_DEVICE, "kernel launch failed: %s (%s:%d)",                    \
                         hipGetErrorString((hipError_t)e_), __FILE__, __LINE__);                \
     } while (0)
+
+// roctx ranges around the operators (HGS_OPT_ROCTX): resolved at run time so that the library keeps its single
+// link dependency (libamdhip64); rocprofv3 --marker-trace shows them.  librocprofiler-sdk-roctx first (rocprofv3),
+// then the legacy libroctx64.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    bool load() {
+        if (tried) return push != nullptr;
+        tried = true;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return true;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+        return false;
+    }
+};
+static Roctx g_roctx;
+struct RoctxRange {
+    bool on;
+    RoctxRange(bool enabled, const char* name) : on(enabled && g_roctx.push != nullptr) { if (on) g_roctx.push(name); }
+    ~RoctxRange() { if (on) g_roctx.pop(); }
+};
 
 static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static int env_int(const char* name, int dflt) {
@@ -129,6 +159,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_tile = 1;                      // HGS_OPT_TILE_KERNEL
     int opt_separable = 1;                 // HGS_OPT_SEPARABLE
     int opt_sep_min = 32;                  // smallest spot count the matrix-core form is used for
+    int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
     int* stats_dxy = nullptr;         // hgs_stats group 1: floor(spot_knm)
@@ -1042,6 +1073,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int n2f(int store_pff) override {
+        RoctxRange range(opt_roctx, "hgs_nearfield2farfield");
         if (cfg.kind == 1) return n2f_compressed(store_pff);
         if (general) return n2f_general(store_pff);
         if (int e = need_ff()) return e;
@@ -1061,6 +1093,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int f2n() override {
+        RoctxRange range(opt_roctx, "hgs_farfield2nearfield");
         if (cfg.kind == 1) return f2n_compressed();
         if (general) return f2n_general(false);
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
@@ -1248,6 +1281,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int constraint(hgs_step* st) override {
+        RoctxRange range(opt_roctx, "hgs_farfield_constraint");
         if (int e = check_step(st)) return e;
         Plan p = plan_iteration(st, nullptr);
         return constraint_planned(st, p);
@@ -1352,6 +1386,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int iterate(hgs_step* st, int n, uint8_t* hist) override {
+        RoctxRange range(opt_roctx, "hgs_iterate");
         if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
         if (n == 0) return 0;
         if (int e = check_step(st)) return e;
@@ -1733,6 +1768,10 @@ template <typename R> struct Engine : EngineBase {
             case HGS_OPT_TILE_KERNEL: opt_tile = value ? 1 : 0; return 0;
             case HGS_OPT_SEPARABLE: opt_separable = value ? 1 : 0; return 0;
             case HGS_OPT_SEPARABLE_MIN_SPOTS: opt_sep_min = value > 0 ? value : 1; return 0;
+            case HGS_OPT_ROCTX:
+                if (value && !g_roctx.load()) return fail(HGS_ERR_UNSUPPORTED, "no roctx library (librocprofiler-sdk-roctx / libroctx64) found");
+                opt_roctx = value ? 1 : 0;
+                return 0;
         }
         return fail(HGS_ERR_ARG, "unknown option %d", option);
     }

@@ -806,3 +806,20 @@ def test_general_shape_spot_hologram_at_slm_size():
         assert errs["phase"] < 5e-5 and errs["spot_amp"] < 1e-5 and errs["weights"] < 2e-5
         for grp in ("computational", "computational_spot"):
             np.testing.assert_allclose(h.stats["stats"][grp]["uniformity"], o.stats["stats"][grp]["uniformity"], rtol=2e-3, atol=1e-6)
+
+
+def test_roctx_ranges_can_be_switched_on():
+    """HGS_OPT_ROCTX: the roctx library is resolved at run time; the operators run unchanged with ranges around them."""
+    e = Engine((64, 64), (32, 32))
+    try:
+        e.set_option(L.OPT_ROCTX, 1)
+    except NotImplementedError:
+        e.close()
+        pytest.skip("no roctx library on this box")
+    e.set(L.PHASE, synth.seed_phase(3, (32, 32)))
+    e.nearfield2farfield()
+    a = e.get(L.AMP_FF)[0]
+    e.set_option(L.OPT_ROCTX, 0)
+    e.nearfield2farfield()
+    np.testing.assert_array_equal(a, e.get(L.AMP_FF)[0])
+    e.close()

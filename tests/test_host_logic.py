@@ -245,3 +245,57 @@ def test_batch_targets_are_normalised_like_set_target():
     np.testing.assert_allclose(n[0], h.target, rtol=3e-7)
     # unit-norm input passes through bit-identically
     np.testing.assert_array_equal(normalize_targets(h.target), h.target)
+
+
+ASAN_SCRIPT = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from slmsuite_amd import _lib as L
+lib = L.load()
+h = C.c_void_p()
+# argument validation happens before any device work: these return status codes on every box
+assert lib.hgs_create(None, C.byref(h)) == L.HGS_ERR_ARG
+cfg = L.hgs_config(device=0, pad_h=64, pad_w=64, slm_h=32, slm_w=32, real_bytes=3, batch=1, n_spots=0, kind=0, n_monomials=0)
+assert lib.hgs_create(C.byref(cfg), C.byref(h)) == L.HGS_ERR_ARG and not h.value
+assert b"real_bytes" in lib.hgs_last_error()
+cfg.real_bytes = 4
+rc = lib.hgs_create(C.byref(cfg), C.byref(h))
+if rc == L.HGS_OK:                        # a GPU is present: walk a few more entry points through the sanitizer
+    import numpy as np
+    bad = np.zeros(7, np.float32)
+    assert lib.hgs_set_array(h, L.PHASE, bad.ctypes.data_as(C.c_void_p), bad.nbytes) == L.HGS_ERR_ARG
+    assert lib.hgs_set_array(h, 99, bad.ctypes.data_as(C.c_void_p), bad.nbytes) == L.HGS_ERR_ARG
+    ph = np.zeros((32, 32), np.float32)
+    assert lib.hgs_set_array(h, L.PHASE, ph.ctypes.data_as(C.c_void_p), ph.nbytes) == 0
+    assert lib.hgs_nearfield2farfield(h, 1) == 0 and lib.hgs_farfield2nearfield(h) == 0
+    assert lib.hgs_farfield2nearfield(h) == L.HGS_ERR_STATE          # farfield consumed
+    assert lib.hgs_destroy(h) == 0
+else:
+    assert rc == L.HGS_ERR_DEVICE and not h.value
+for fn in (lib.hgs_sync, lib.hgs_reset_weights, lib.hgs_farfield2nearfield):
+    assert fn(None) == L.HGS_ERR_ARG
+assert lib.hgs_destroy(None) == 0
+print("asan-ok")
+"""
+
+
+def test_asan_build_of_the_shim_is_clean():
+    """The C-ABI error paths through the AddressSanitizer build of engine.hip (make -C slmsuite_amd/csrc asan)."""
+    import subprocess
+    import sys
+    asan_lib = os.path.join(ROOT, "slmsuite_amd", "libhgs_asan.so")
+    if not os.path.exists(asan_lib):
+        pytest.skip("libhgs_asan.so not built")
+    rt = subprocess.run(["hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("ASan runtime not found")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", HGS_LIB=asan_lib)
+    p = subprocess.run([sys.executable, "-c", ASAN_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert "asan-ok" in p.stdout and p.returncode == 0, p.stderr[-2000:]
+    assert "AddressSanitizer" not in p.stderr, p.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_asan_shim_on_the_gpu():
+    """Same walk with a device present: uploads, both transforms and the state machine under the sanitizer."""
+    test_asan_build_of_the_shim_is_clean()
