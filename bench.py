@@ -175,7 +175,8 @@ class GridProblem:
         wgs = m != "GS"
         gh = Sh * Pw * c                              # half-transformed field: SLM rows only
         w_write = (P * r) if not self.sparse_target else self.n_targets * 16 * r   # changed 16-value lane groups only
-        col = 2 * gh + P * r + (P * r if (wgs or self.mraf) else 0) + (w_write if wgs else 0)
+        kim = m == "WGS-Kim"                          # after the fixing iteration the stored phase_ff is read back
+        col = 2 * gh + P * r + (P * r if (wgs or self.mraf) else 0) + (w_write if wgs else 0) + (P * r if kim else 0)
         passes = 1
         if self.mraf and wgs:
             # two column passes: forward + weight rule (reads GH, w, t; writes w), then forward + rebuild + inverse
@@ -189,6 +190,7 @@ class GridProblem:
                     working_set=ws * B,
                     col_model=f"GH tile read + write (2 x Sh*Pw*{c} B) + weights read (P*{r}) + "
                               f"{'target read (P*%d) + ' % r if (wgs or self.mraf) else ''}"
+                              f"{'phase_ff read (P*%d, fixed phase) + ' % r if kim else ''}"
                               f"weight writes where a weight changed ({w_write} B)"
                               + ("; MRAF with a weight update = two column passes" if passes == 2 else ""),
                     row_model=f"H read + G written, SLM rows only (2 x Sh*Pw*{c} B); the phase itself is only "
