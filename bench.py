@@ -391,6 +391,8 @@ def main():
     dist = None
     if (world > 1 or args.force_dist) and not args.pmc_child:
         import torch.distributed as dist
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)         # --force-dist outside a launcher: a one-rank group
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():

@@ -417,9 +417,24 @@ class Hologram:
         return ff
 
     # ---- statistics bookkeeping (_stats.py:118-223) ---------------------------------------------------------
+    @staticmethod
+    def _raw_stats(feedback_amp, target_amp):
+        """The two arrays ``raw_stats=True`` adds to a statistics group (_stats.py:104-114): the normalised feedback
+        power and its ratio to the normalised target power (NaN where the target is zero or NaN)."""
+        fp = np.square(np.asarray(feedback_amp, dtype=float))
+        fp = fp * (1 / np.sum(fp))
+        tp = np.square(np.asarray(target_amp, dtype=float))
+        tp = tp * (1 / np.nansum(tp))
+        mask = np.logical_and(tp != 0, np.logical_not(np.isnan(tp)))
+        ratio = np.full_like(tp, np.nan)
+        ratio[mask] = fp[mask] / tp[mask]
+        return {"raw_pwr": fp, "raw_pwr_ratio": ratio}
+
     def _calculate_stats_computational(self, stats, stat_groups=[]):
         if "computational" in stat_groups:
             stats["computational"] = self._get_engine().stats(0)[0]
+            if self.flags.get("raw_stats", False):      # host arrays, as the reference stores them (off the fast path)
+                stats["computational"].update(self._raw_stats(self.amp_ff, self.target))
 
     def _update_stats_dictionary(self, stats):
         it = self.iter
@@ -908,9 +923,17 @@ class SpotHologram(FeedbackHologram):
         if "computational_spot" in stat_groups:
             e = self._get_engine()
             if tuple(self.shape) == tuple(self.slm_shape):
-                stats["computational_spot"] = e.stats(1, 1, self.spot_knm_rounded)[0]
+                width, vectors = 1, self.spot_knm_rounded
             else:
-                stats["computational_spot"] = e.stats(1, self.spot_integration_width_knm, self.spot_knm)[0]
+                width, vectors = self.spot_integration_width_knm, self.spot_knm
+            stats["computational_spot"] = e.stats(1, width, vectors)[0]
+            if self.flags.get("raw_stats", False):
+                v = np.floor(np.asarray(vectors, dtype=float)).astype(int)       # analysis.take floors (quirk A18)
+                off = np.floor(np.arange(width) - (width - 1) / 2.0).astype(int)
+                ox, oy = np.meshgrid(off, off)
+                pwr = np.square(self.amp_ff)[oy.ravel()[None, :] + v[1][:, None], ox.ravel()[None, :] + v[0][:, None]]
+                fb = np.sqrt(np.sum(pwr.astype(float), axis=-1))
+                stats["computational_spot"].update(self._raw_stats(fb, self.spot_amp))
 
     def _update_stats(self, stat_groups=[]):
         stats = {}

@@ -823,3 +823,28 @@ def test_roctx_ranges_can_be_switched_on():
     e.nearfield2farfield()
     np.testing.assert_array_equal(a, e.get(L.AMP_FF)[0])
     e.close()
+
+
+def test_raw_stats_arrays():
+    """raw_stats=True: per-group raw_pwr / raw_pwr_ratio (_stats.py:104-114) and raw_farfield (:193-208) per iteration."""
+    shape, slm = (128, 128), (48, 80)
+    vec = orc.rectangular_array(shape, (4, 4), (16, 16))
+    h = SpotHologram(shape, vec, basis="knm", slm_shape=slm, phase=synth.seed_phase(61, slm))
+    o = orc.OracleSpotHologram(shape, vec, slm_shape=slm, phase=synth.seed_phase(61, slm))
+    amps = []
+    o.optimize("WGS-Leonardo", maxiter=3, callback=lambda oo: amps.append(oo.amp_ff.astype(float).copy()) and False)
+    h.optimize("WGS-Leonardo", maxiter=3, verbose=False, raw_stats=True, stat_groups=["computational", "computational_spot"])
+    assert len(h.stats["raw_farfield"]) == 3
+    tp = np.square(o.target.astype(float))
+    tp /= np.nansum(tp)
+    for k in range(3):
+        fp = np.square(amps[k])
+        fp /= fp.sum()
+        got = h.stats["stats"]["computational"]["raw_pwr"][k]
+        assert got.shape == shape and rel_l2(got, fp) < 2e-5
+        ratio = h.stats["stats"]["computational"]["raw_pwr_ratio"][k]
+        mask = tp != 0
+        assert np.all(np.isnan(ratio[~mask])) and rel_l2(ratio[mask], fp[mask] / tp[mask]) < 2e-5
+        assert rel_l2(np.abs(h.stats["raw_farfield"][k]), amps[k]) < 2e-5
+        spot = h.stats["stats"]["computational_spot"]["raw_pwr"][k]
+        assert spot.shape == (16,) and abs(spot.sum() - 1) < 1e-12

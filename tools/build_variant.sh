@@ -12,7 +12,7 @@ for tu in launch_row_f32 launch_fused_f32; do
 done
 wait
 OBJS=""
-for o in engine launch_row_f32 launch_col_f32 launch_row_f64 launch_col_f64 launch_fused_f32 launch_fused_f64 launch_fused_stats_f32 launch_fused_stats_f64 launch_tile_extras_f32 launch_tile_extras_stats_f32; do
+for o in $(grep '^OBJ' Makefile | sed 's/OBJ *= *//; s/\.o//g'); do
   if [ -f ../../build/ab_$NAME/$o.o ]; then OBJS="$OBJS ../../build/ab_$NAME/$o.o"; else OBJS="$OBJS $o.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhgs_$NAME.so $OBJS
