@@ -442,6 +442,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         first = 4 * ((idx >> 2) * 8 + xcd) + (idx & 3);
     }
+    HGS_T(fft.tr_n, 1);
 #pragma unroll 1
     for (int rbase = first; rbase < g.Sh; rbase += gridDim.x * FPW) {
         const int r = rbase + f;
@@ -462,6 +463,10 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
                 if (valid && ((lmask >> m) & 1u)) h = (ghr + (size_t)m * gh_step)[gh_lane];
                 v[m] = h * sgn;
             });
+#if HGS_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HGS_T(fft.tr_n, 2);
             // (MODE 2: the previous user of the LDS image was the forward transform of the row before)
             if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
             else fft.inv(v, lds, j);
@@ -520,7 +525,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
                 v[m] = nf;
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
+            HGS_T(fft.tr_n, 3);
             fft.fwd(v, lds, j);
+            HGS_T(fft.tr_n, 4);
             if (valid) {
                 const R sc = sgn * a.scale;
                 static_for<0, 16>([&](auto m_) {
@@ -528,8 +535,20 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
                     if ((smask >> m) & 1u) (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
                 });
             }
+#if HGS_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HGS_T(fft.tr_n, 5);
         }
     }
+#if HGS_TRACE
+    __syncthreads();
+    if (a.nf_out != nullptr && MODE == 2) {   // the microbenchmark passes its dump buffer through nf_out
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.nf_out) + (size_t)blockIdx.x * 512;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + HGS_TRACE_OFF);
+        for (int i = tid; i < 512; i += blockDim.x) dst[i] = src[i];
+    }
+#endif
 }
 
 // =====================================================================================================
