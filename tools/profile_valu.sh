@@ -1,7 +1,7 @@
 #!/bin/bash
 # VALU instruction-mix PMC passes for the two hot kernels
 OUT=gpurun_out/prof_valu; mkdir -p $OUT; export TMPDIR=/tmp; ROOTDIR=$(pwd)
-BENCH="python $ROOTDIR/bench.py --steps 30 --warmup 5 --cpu-iters 0 --no-roofline-pass"
+BENCH="python $ROOTDIR/bench.py --steps 30 --warmup 5 --cpu-iters 0 --no-roofline-pass --pmc 0"
 cd /tmp
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT -d $ROOTDIR/$OUT/p1 -o pmc -- $BENCH > $ROOTDIR/$OUT/p1.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVE_CYCLES -d $ROOTDIR/$OUT/p2 -o pmc -- $BENCH > $ROOTDIR/$OUT/p2.log 2>&1
