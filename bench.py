@@ -20,9 +20,9 @@ Workloads (``--workload``):
              --method GS|WGS-Leonardo
   cfg5pad / hd / small   spot arrays on 8192^2 / 2048^2 (1080 x 1920 SLM) / 1024^2 pads
 
-For spot workloads the headline is timed with the dense kernels forced (every farfield column
-transformed); the engine's default for spot targets -- transform only the columns that hold a spot,
-identical results -- is timed in an extra pass and reported as ``engine_default_path``.
+For spot workloads (and the MRAF target, whose frame outside the noise box is empty) the headline is
+timed with the dense kernels forced (every farfield column transformed); the engine's default for
+such targets -- transform only the columns that hold a non-zero target, identical results -- is timed in an extra pass and reported as ``engine_default_path``.
 
 Rank 0 prints one JSON line: metric / value (whole-job iterations/s) plus
   roofline      the dominant kernel against its bound.  HBM-bound kernels: ``achieved`` = the bytes this
@@ -403,7 +403,10 @@ def main():
     compressed = args.workload in COMPRESSED_WORKLOADS
     prob = (CompressedProblem if compressed else GridProblem)(args, rank, local_rank)
     apply_opts(prob.engine, args.opt)
-    spot = args.workload in SPOT_WORKLOADS
+    # targets with empty farfield columns (spot arrays; the zero frame outside an MRAF noise box): the engine would
+    # skip those columns, the byte model of the roofline counts all of them - time the dense kernels, report the
+    # default separately
+    spot = args.workload in SPOT_WORKLOADS or bool(getattr(prob, "mraf", False))
 
     def barrier():
         prob.engine.sync()
@@ -491,19 +494,27 @@ def main():
             dur = col["ms"] * 1e-3 / col["launches"] * per
             achieved = bm["col"] / dur
             row_dur = rowk["ms"] * 1e-3 / max(1, rowk["launches"])
-            traffic, tnote, tr_row = None, "--pmc 0", None
+            traffic, tnote, tr_row, kernel_ran = None, "--pmc 0", None, None
             if want_pmc:
-                subs = {"col": "col_tile_kernel" if "tile" in col_kernel_name(args, prob) else "col_fused_kernel",
+                # which fused column kernel ran is the engine's choice (tile-resident, per column, sparse list):
+                # count both and keep the one that was launched
+                subs = {"col_tile": "col_tile_kernel", "col_fused": "col_fused_kernel",
                         "row": "row_kernel<" + ("float" if args.dtype == "f32" else "double") + f", {prob.shape[1]}, 2>"}
                 res, tnote = pmc_traffic(args, subs)
+                if res is not None:
+                    res["col"] = max((res["col_tile"], res["col_fused"]), key=lambda r: r["launches"])
                 if res is not None and res["col"]["fetch"] is not None and res["col"]["write"] is not None:
                     traffic = (res["col"]["fetch"] + res["col"]["write"]) * per
                     tr_row = None if res["row"]["fetch"] is None else res["row"]["fetch"] + res["row"]["write"]
                     tnote += f"; kernel = {res['col']['kernel_name']}"
+                    if args.dtype != "f32":
+                        tnote += ("; the x 2 FETCH_SIZE correction is calibrated for 16-B-per-lane fp32 streams, fp64 access "
+                                  "widths are uncalibrated (guide) - treat this figure as indicative")
+                    kernel_ran = res["col"]["kernel_name"]
                 elif res is not None:
                     tnote = "kernel not found in the PMC pass: " + json.dumps(res)
             iter_s = args.steps / (ms_events * 1e-3)
-            roof = {"bound": "hbm", "kernel": col_kernel_name(args, prob),
+            roof = {"bound": "hbm", "kernel": kernel_ran or col_kernel_name(args, prob),
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                     "traffic": traffic, "traffic_note": tnote,
                     "bytes_per_launch": bm["col"], "bytes_model": bm["col_model"],
