@@ -27,6 +27,29 @@ __global__ __launch_bounds__(256) void row_copy(v2f* gh, float* phase, int xcd_m
 #pragma unroll
     for (int m = 0; m < 16; ++m) (ghr + (size_t)m * T * Sh)[lane] = v[m];
 }
+// the tile-layout pattern with the tile stride padded to ShP rows (Sh * 32 B = 9 * 4096 B puts the 16 pieces of one
+// wave access 36,864 B apart: same channel under a 4 KiB interleave)
+__global__ __launch_bounds__(256) void row_copy_pad(v2f* gh, float* phase, int ShP) {
+    const int j = threadIdx.x;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int r = 4 * ((idx >> 2) * 8 + xcd) + (idx & 3);
+    if (r >= Sh) return;
+    const unsigned lane = (unsigned)(j >> 2) * ShP * 4u + (unsigned)(j & 3);
+    v2f* ghr = gh + (size_t)r * 4;
+    v2f v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = (ghr + (size_t)m * T * ShP)[lane];
+    float acc = 0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { acc += v[m].x; v[m] = v[m] * 1.0001f; }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int c = j + m * T - C0;
+        if (c >= 0 && c < Sw) phase[(size_t)r * Sw + c] = acc + m;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) (ghr + (size_t)m * T * ShP)[lane] = v[m];
+}
 // same traffic, but each row is one contiguous 32 KiB run (what a row-major GH would give)
 __global__ __launch_bounds__(256) void row_copy_linear(v2f* gh, float* phase) {
     const int j = threadIdx.x, r = blockIdx.x;
@@ -83,11 +106,13 @@ template <typename F> float timeit(F f, int reps = 20) {
 }
 int main() {
     v2f* gh; float *phase, *w, *t, *sink;
-    hipMalloc(&gh, (size_t)Sh * Pw * 8); hipMalloc(&phase, (size_t)Sh * Sw * 4);
+    hipMalloc(&gh, (size_t)1280 * Pw * 8); hipMalloc(&phase, (size_t)Sh * Sw * 4);
     hipMalloc(&w, (size_t)Ph * Pw * 4); hipMalloc(&t, (size_t)Ph * Pw * 4); hipMalloc(&sink, 64);
     hipMemset(gh, 0, (size_t)Sh * Pw * 8); hipMemset(w, 0, (size_t)Ph * Pw * 4); hipMemset(t, 0, (size_t)Ph * Pw * 4);
     printf("row_copy (tile layout, xcd map)   %.1f us\n", timeit([&] { hipLaunchKernelGGL(row_copy, dim3(1152), dim3(256), 0, 0, gh, phase, 1); }));
     printf("row_copy (tile layout, no map)    %.1f us\n", timeit([&] { hipLaunchKernelGGL(row_copy, dim3(1152), dim3(256), 0, 0, gh, phase, 0); }));
+    for (int pad : {1152, 1156, 1160, 1168, 1184, 1216, 1280})
+        printf("row_copy, tile stride %4d rows     %.1f us\n", pad, timeit([&] { hipLaunchKernelGGL(row_copy_pad, dim3(1152), dim3(256), 0, 0, gh, phase, pad); }));
     printf("row_copy_linear (row-major)       %.1f us\n", timeit([&] { hipLaunchKernelGGL(row_copy_linear, dim3(1152), dim3(256), 0, 0, gh, phase); }));
     printf("col_copy 512 WG x 2 tiles         %.1f us\n", timeit([&] { hipLaunchKernelGGL(col_copy, dim3(512), dim3(256), 0, 0, gh, w, t, sink, 2); }));
     printf("col_copy 1024 WG x 1 tile         %.1f us\n", timeit([&] { hipLaunchKernelGGL(col_copy, dim3(1024), dim3(256), 0, 0, gh, w, t, sink, 1); }));
