@@ -950,9 +950,14 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
                                                R (&wr)[16], R (&tr)[16]) {
     static_for<0, 16>([&](auto m_) {
         constexpr int m = m_;
-        if (HGS_ABL_WT) {
+        if (HGS_ABL_WT == 1) {
             wr[m] = (R)1e-3;
             tr[m] = (j == 7 && m == 3) ? (R)0.03 : (R)0;
+            return;
+        }
+        if (HGS_ABL_WT == 2) {      // a column without spots (what all but 32 columns of cfg 2 look like): skipped rule
+            wr[m] = (R)0;
+            tr[m] = (R)0;
             return;
         }
         wr[m] = wc[lane_pos<T>(j, m)];
