@@ -41,9 +41,10 @@ typedef enum {
 
 /* Geometry of one engine.  Hologram.__init__ (_hologram.py:196-439): `shape` -> pad_h/pad_w,
  * `slm_shape` -> slm_h/slm_w, dtype (:391-398) -> real_bytes.  Powers of two in [64, 8192] run the fused
- * kernels; any other shape with 2 <= n <= 4096 per axis (the reference only warns about those, :378-384) runs
- * the same operators through Bluestein's identity on the power-of-two transforms (general operators only, no
- * fused loop).  Larger non-power-of-two shapes and 16384 return HGS_ERR_UNSUPPORTED.  The SLM block is
+ * kernels; any other shape (the reference only warns about those, :378-384) runs the same operators axis by
+ * axis on the workgroup transforms (general operators only, no fused loop): a power-of-two axis up to 16384
+ * (float64: 8192) directly, any other length in [2, 8192] (float64: [2, 4096]) through Bluestein's identity.
+ * Longer axes return HGS_ERR_UNSUPPORTED.  The SLM block is
  * centred (toolbox.unpad, toolbox/__init__.py:1699-1712). */
 typedef struct {
     int32_t device;      /* HIP device ordinal                                          */

@@ -10,6 +10,7 @@
 //     forward : pre[n] = W^(-n h),        post[k] = W^(h (k - h)) / sqrt(N),    W = exp(-2 pi i / N), h = N / 2 (floor)
 //     inverse : pre[m] = conj(W)^(m h),   post[i] = conj(W)^(-h (i + h)) / sqrt(N)
 // Tables are computed in double on the host (integer arguments reduced mod 2N before any floating point).
+// An axis whose length IS a power of two (256 ... 16384) skips the convolution (BlueArgs::plain): pre[] / post[] alone.
 // This path is functional, not tuned: it exists so that every shape the reference accepts runs on the GPU.
 #pragma once
 #include "kernels.hpp"
@@ -30,6 +31,8 @@ template <typename R> struct BlueArgs {
     const Cx<R>* Bf;          // [M]  FFT_M of the wrapped conj chirp, divided by M
     const Cx<R>* Cc;          // [N]  post[k] * c[k]
     const Cx<R>* tw;          // W_M table
+    int plain;                // N == M, a power of two: no convolution.  1: out[k] = Cc[k] FFT_N(x A)[k] (forward);
+                              // 2: the inverse direction through conj(FFT_N(conj(x A))) (A = pre, Cc = post / sqrt(N))
 };
 
 // grid = (lines, batch), block = M / 16
@@ -50,9 +53,23 @@ template <typename R, int M> __global__ __launch_bounds__(M / 16) void bluestein
         const int n = js + m * T;
         Cx<R> x = mk<R>(0, 0);
         if (n >= a.in_start && n < a.in_start + a.in_len) x = cmul(in[(size_t)(n - a.in_start) * a.in_stride], a.A[n]);
+        if (a.plain == 2) x.y = -x.y;
         v[m] = x;
     });
     fft.fwd(v, lds, j);
+    if (a.plain) {
+        // the transform itself: lane j holds outputs j + m T of the frequency side
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = m_;
+            const int k = j + m * T;
+            if (k >= a.out_start && k < a.out_start + a.out_len) {
+                Cx<R> y = v[m];
+                if (a.plain == 2) y.y = -y.y;
+                out[(size_t)(k - a.out_start) * a.out_stride] = cmul(y, a.Cc[k]);
+            }
+        });
+        return;
+    }
     static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = cmul(v[m], a.Bf[j + m * T]); });
     fft.inv_after_fwd(v, lds, j);
     static_for<0, 16>([&](auto m_) {

@@ -171,6 +171,7 @@ template <typename R> struct Engine : EngineBase {
     // padded shapes that are not powers of two in [64, 8192]: Bluestein path (bluestein.hpp)
     bool general = false;
     int blue_M[2] = {0, 0};            // convolution lengths for x (rows, N = Pw) and y (columns, N = Ph)
+    bool blue_plain[2] = {false, false};   // the axis is a power of two: M = N, no convolution
     C* blue_tab[2][2][3] = {};         // [x|y][forward|inverse][A, Bf, Cc]
     C* blue_tw[2] = {nullptr, nullptr};
     // kind 1 (compressed)
@@ -272,10 +273,11 @@ template <typename R> struct Engine : EngineBase {
         const bool fast = is_pow2(c.pad_h) && is_pow2(c.pad_w) && c.pad_h >= 64 && c.pad_w >= 64 && c.pad_h <= 8192 &&
                           c.pad_w <= 8192;
         if (!fast) {
-            // any other shape up to 4096 per axis runs through Bluestein's identity on the power-of-two transforms
-            if (c.pad_h < 2 || c.pad_w < 2 || c.pad_h > 4096 || c.pad_w > 4096)
-                return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d): powers of two in [64, 8192] or any shape with "
-                            "2 <= n <= 4096 per axis", c.pad_h, c.pad_w);
+            // any other shape runs axis by axis on the workgroup transforms: a power-of-two axis up to 16384 (fp64:
+            // 8192) directly, any other length up to 8192 (fp64: 4096) through Bluestein's identity
+            if (!axis_ok(c.pad_h) || !axis_ok(c.pad_w))
+                return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d): per axis a power of two up to %d or any length "
+                            "in [2, %d] (%s)", c.pad_h, c.pad_w, max_line(), max_line() / 2, sizeof(R) == 4 ? "float32" : "float64");
             general = true;
         }
         if (c.slm_h < 1 || c.slm_w < 1 || c.slm_h > c.pad_h || c.slm_w > c.pad_w)
@@ -334,6 +336,10 @@ template <typename R> struct Engine : EngineBase {
     }
 
     // ---- general padded shapes (Bluestein) ----------------------------------------------------------
+    // the longest line one workgroup transforms: 1024 lanes x 16 elements, LDS image (17/16) * 16384 * sizeof(C)
+    static constexpr int max_line() { return sizeof(R) == 4 ? 16384 : 8192; }
+    static bool axis_plain(int N) { return is_pow2(N) && N >= 256 && N <= max_line(); }
+    static bool axis_ok(int N) { return N >= 2 && (axis_plain(N) || 2 * N - 1 <= max_line()); }
     static void host_fft(std::vector<std::complex<double>>& a) {      // in-place radix-2, forward sign
         const size_t n = a.size();
         for (size_t i = 1, j = 0; i < n; ++i) {
@@ -354,7 +360,8 @@ template <typename R> struct Engine : EngineBase {
         }
     }
     // tables of one centred transform of length N (bluestein.hpp): dir = -1 forward, +1 inverse
-    int make_blue_tables(int N, int M, int dir, C** out3) {
+    // plain: no chirp (A = pre, Cc = post / sqrt(N), Bf unused but allocated as one element)
+    int make_blue_tables(int N, int M, int dir, bool plain, C** out3) {
         using cd = std::complex<double>;
         const long long h = N / 2;
         const double sg = dir < 0 ? -1.0 : 1.0;
@@ -364,8 +371,8 @@ template <typename R> struct Engine : EngineBase {
             const double a = sign * 2.0 * M_PI * (double)r / (double)den;
             return cd(std::cos(a), std::sin(a));
         };
-        std::vector<cd> chirp(N), A(N), Cc(N), bt(M, cd(0, 0));
-        for (long long n = 0; n < N; ++n) chirp[n] = unit(n * n, 2LL * N, sg);       // W^(n^2/2), W = exp(sg 2 pi i / N)
+        std::vector<cd> chirp(N), A(N), Cc(N), bt(plain ? 1 : M, cd(0, 0));
+        for (long long n = 0; n < N; ++n) chirp[n] = plain ? cd(1, 0) : unit(n * n, 2LL * N, sg);   // W^(n^2/2), W = exp(sg 2 pi i / N)
         const double sc = 1.0 / std::sqrt((double)N);
         for (long long n = 0; n < N; ++n) {
             // forward: pre = W^(-n h), post = W^(h (k - h));  inverse (W -> conj W): pre = Wc^(n h), post = Wc^(-h (i + h))
@@ -374,10 +381,12 @@ template <typename R> struct Engine : EngineBase {
             A[n] = pre * chirp[n];
             Cc[n] = post * chirp[n] * sc;
         }
-        bt[0] = std::conj(chirp[0]);
-        for (int d = 1; d < N; ++d) bt[d] = bt[M - d] = std::conj(chirp[d]);
-        host_fft(bt);
-        for (auto& v : bt) v /= (double)M;
+        if (!plain) {
+            bt[0] = std::conj(chirp[0]);
+            for (int d = 1; d < N; ++d) bt[d] = bt[M - d] = std::conj(chirp[d]);
+            host_fft(bt);
+            for (auto& v : bt) v /= (double)M;
+        }
         auto up = [&](const std::vector<cd>& src, C** dst) -> int {
             std::vector<C> hbuf(src.size());
             for (size_t i = 0; i < src.size(); ++i) { hbuf[i].x = (R)src[i].real(); hbuf[i].y = (R)src[i].imag(); }
@@ -389,9 +398,11 @@ template <typename R> struct Engine : EngineBase {
         return up(Cc, &out3[2]);
     }
     int init_general(const hgs_config& c) {
-        auto conv_len = [](int N) { int M = 256; while (M < 2 * N - 1) M <<= 1; return M; };
+        auto conv_len = [](int N) { if (axis_plain(N)) return N; int M = 256; while (M < 2 * N - 1) M <<= 1; return M; };
         blue_M[0] = conv_len(g.Pw);
         blue_M[1] = conv_len(g.Ph);
+        blue_plain[0] = axis_plain(g.Pw);
+        blue_plain[1] = axis_plain(g.Ph);
         ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
         col_blocks = tile_blocks = row_blocks = 1;
         if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
@@ -409,8 +420,8 @@ template <typename R> struct Engine : EngineBase {
             const int N = d == 0 ? g.Pw : g.Ph;
             if (d == 1 && blue_M[1] == blue_M[0]) blue_tw[1] = blue_tw[0];
             else if (int e = make_twiddles(&blue_tw[d], blue_M[d])) return e;
-            if (int e = make_blue_tables(N, blue_M[d], -1, blue_tab[d][0])) return e;
-            if (int e = make_blue_tables(N, blue_M[d], +1, blue_tab[d][1])) return e;
+            if (int e = make_blue_tables(N, blue_M[d], -1, blue_plain[d], blue_tab[d][0])) return e;
+            if (int e = make_blue_tables(N, blue_M[d], +1, blue_plain[d], blue_tab[d][1])) return e;
         }
         if (c.n_spots > 0) {
             if (dalloc(&spot_xy, (size_t)2 * c.n_spots)) return HGS_ERR_DEVICE;
@@ -431,6 +442,7 @@ template <typename R> struct Engine : EngineBase {
         a.out_start = out_start; a.out_len = out_len; a.N = dim == 0 ? g.Pw : g.Ph;
         C** t3 = blue_tab[dim][dir < 0 ? 0 : 1];
         a.A = t3[0]; a.Bf = t3[1]; a.Cc = t3[2]; a.tw = blue_tw[dim];
+        a.plain = blue_plain[dim] ? (dir < 0 ? 1 : 2) : 0;
         LCHK(launch_bluestein<R>(blue_M[dim], dim3(lines, B), stream, a));
         return 0;
     }

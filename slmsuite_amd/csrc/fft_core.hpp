@@ -327,6 +327,7 @@ template <> struct Sched<1024> { static constexpr int S = 3; static constexpr in
 template <> struct Sched<2048> { static constexpr int S = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
 template <> struct Sched<4096> { static constexpr int S = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
 template <> struct Sched<8192> { static constexpr int S = 4; static constexpr int r[4] = {16, 16, 16, 2}; };
+template <> struct Sched<16384> { static constexpr int S = 4; static constexpr int r[4] = {16, 16, 16, 4}; };   // 1024 lanes (general path)
 
 template <int N, int STAGE> constexpr int sched_ns() {  // product of radices before STAGE
     int ns = 1;

@@ -22,6 +22,9 @@ template <> int launch_bluestein<HGS_REAL>(int M, dim3 grid, hipStream_t s, cons
         case 2048: return launch_blue_one<HGS_REAL, 2048>(grid, s, a);
         case 4096: return launch_blue_one<HGS_REAL, 4096>(grid, s, a);
         case 8192: return launch_blue_one<HGS_REAL, 8192>(grid, s, a);
+#ifdef HGS_REAL_IS_FLOAT
+        case 16384: return launch_blue_one<HGS_REAL, 16384>(grid, s, a);     // (fp64: 278 KB of LDS, not available)
+#endif
     }
     return (int)hipErrorInvalidValue;
 }

@@ -328,9 +328,11 @@ def test_batch_matches_single():
 
 def test_errors_are_loud():
     with pytest.raises(NotImplementedError):
-        Engine((5000, 100), (50, 50))             # not a power of two and beyond the Bluestein range
+        Engine((9000, 100), (50, 50))             # not a power of two and beyond the Bluestein range (8192)
     with pytest.raises(NotImplementedError):
-        Engine((16384, 16384), (50, 50))
+        Engine((32768, 256), (50, 50))            # longer than the longest line one workgroup transforms
+    with pytest.raises(NotImplementedError):
+        Engine((16384, 256), (50, 50), dtype=np.float64)    # float64: 8192
     with pytest.raises(ValueError):
         Engine((64, 64), (128, 128))
     h = Hologram(synth.random_target(1, (64, 64)), phase=synth.seed_phase(1, (64, 64)))
@@ -730,7 +732,10 @@ def test_sparse_paths_small_grids(shape, slm, n, method, feedback):
 
 # ---- padded shapes that are not powers of two (the reference only warns, _hologram.py:378-384) --------------
 GENERAL_SHAPES = [((100, 150), (48, 80), True), ((96, 120), (96, 120), False), ((101, 75), (33, 51), True),
-                  ((7, 300), (5, 121), False), ((640, 1000), (300, 500), False), ((1152, 1920), (1152, 1920), False)]
+                  ((7, 300), (5, 121), False), ((640, 1000), (300, 500), False), ((1152, 1920), (1152, 1920), False),
+                  # beyond 4096: a 16384-point line is one 1024-lane workgroup; Bluestein up to 8192 runs on it
+                  ((16384, 256), (1152, 200), False), ((300, 16384), (120, 160), True), ((6000, 320), (1152, 300), False),
+                  ((512, 8191), (200, 1920), False), ((16384, 4096), (1152, 1920), False)]
 
 
 @pytest.mark.parametrize("shape,slm,fancy", GENERAL_SHAPES)
@@ -753,6 +758,22 @@ def test_general_shape_transforms_match_numpy_fft(shape, slm, fancy):
     back = phase_rel_l2(e.get(L.PHASE)[0], phase)
     report(f"general shape {shape} {slm}", farfield=err, round_trip_phase=back)
     assert err < 3e-6 and back < 2e-5
+    e.close()
+
+
+@pytest.mark.parametrize("shape,slm", [((8192, 300), (1152, 200)), ((4000, 260), (1000, 250))])
+def test_general_shape_long_lines_float64(shape, slm):
+    """float64 reaches 8192-point lines (direct) and 4096 (Bluestein): forward and round trip at 1e-12."""
+    phase = synth.seed_phase(33, slm, dtype=np.float64)
+    ref = oracle_forward(shape, slm, phase, dtype=np.float64)
+    e = Engine(shape, slm, dtype=np.float64)
+    e.set(L.PHASE, phase)
+    e.nearfield2farfield()
+    err = rel_l2(e.get(L.FARFIELD)[0], ref.farfield)
+    e.farfield2nearfield()
+    back = phase_rel_l2(e.get(L.PHASE)[0], phase)
+    report(f"general shape fp64 {shape}", farfield=err, round_trip_phase=back)
+    assert err < 1e-12 and back < 1e-11
     e.close()
 
 
