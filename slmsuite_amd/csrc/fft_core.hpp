@@ -570,6 +570,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
     }
 
     template <int DIR, int s> __device__ __forceinline__ void butterfly_pre(Cx<R> (&v)[16], int p) {
+        if (HGS_ABL_BFLY) return;
         if (HGS_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         static_for<1, 4>([&](auto r2_) {
             constexpr int r2 = r2_;
@@ -584,6 +585,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         if (HGS_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     }
     template <int DIR, int s> __device__ __forceinline__ void butterfly_post(Cx<R> (&v)[16], int p) {
+        if (HGS_ABL_BFLY) return;
         Dft<16, DIR, R>::run_tw_post(v, this->template twv<s, 0>(p), this->template twv<s, 1>(p), this->template twv<s, 2>(p),
                                      this->template twv<s, 3>(p), this->template twv<s, 4>(p), this->template twv<s, 5>(p));
     }
@@ -593,9 +595,9 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
     template <int DIR, int NZ = 16> __device__ __forceinline__ void forward_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
         Cx<R>* rowb = lds + ROW * (p >> 4);
         HGS_T(tr_n, 10);
-        Dft<16, DIR, R>::template run_lead<NZ>(v);
+        if (!HGS_ABL_BFLY) Dft<16, DIR, R>::template run_lead<NZ>(v);
         HGS_T(tr_n, 11);
-        {   // 16 x 16 transpose inside the row of 16 lanes
+        if (!HGS_ABL_XCHG) {   // 16 x 16 transpose inside the row of 16 lanes
             Cx<R>* w = rowb + 17 * (p & 15);
             static_for<0, 16>([&](auto i_) { constexpr int i = i_; w[i] = v[i]; });
             wave_lds_order();
@@ -605,7 +607,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         HGS_T(tr_n, 12);
         butterfly_pre<DIR, 1>(v, p);
         HGS_T(tr_n, 13);
-        {   // cross-wave exchange: lane (row n0, k_a) register k_b -> lane k_a + 16 k_b register n0
+        if (!HGS_ABL_XCHG) {   // cross-wave exchange: lane (row n0, k_a) register k_b -> lane k_a + 16 k_b register n0
             Cx<R>* w = rowb + (p & 15);
             static_for<0, 16>([&](auto r_) { constexpr int r = r_; w[16 * r] = v[r]; });
             __syncthreads();
@@ -623,7 +625,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         HGS_T(tr_n, 20);
         butterfly_post<DIR, 2>(v, p);
         HGS_T(tr_n, 21);
-        {
+        if (!HGS_ABL_XCHG) {
             if constexpr (LEAD) __syncthreads();
             Cx<R>* g = lds + p;
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; g[ROW * m] = v[m]; });
@@ -634,7 +636,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         HGS_T(tr_n, 22);
         butterfly_post<DIR, 1>(v, p);
         HGS_T(tr_n, 23);
-        {
+        if (!HGS_ABL_XCHG) {
             wave_lds_order();
             Cx<R>* w = rowb + (p & 15);
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; w[17 * m] = v[m]; });
@@ -643,7 +645,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
             static_for<0, 16>([&](auto i_) { constexpr int i = i_; v[i] = r[i]; });
         }
         HGS_T(tr_n, 24);
-        Dft<16, DIR, R>::run(v);
+        if (!HGS_ABL_BFLY) Dft<16, DIR, R>::run(v);
         HGS_T(tr_n, 25);
     }
 
