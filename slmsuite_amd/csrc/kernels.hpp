@@ -57,6 +57,11 @@ struct Geo {
 // so the 16 values a lane needs are 64 contiguous bytes (4 x 16-byte loads instead of 16 scalar
 // ones, 4 KiB contiguous per wave).  Elementwise kernels are oblivious to the permutation;
 // hgs_set_array / hgs_get_array and the spot kernels apply it.
+// Tile-resident column kernel: pick the column of the pass out of the tile registers with a register-relative move
+// (the pass index is uniform: s_set_gpr_idx + v_mov, 24 instructions per pass) instead of 84 v_cndmask
+#ifndef HGS_TILE_MOVREL
+#define HGS_TILE_MOVREL 1
+#endif
 #ifndef HGS_LANE_MAJOR
 #define HGS_LANE_MAJOR 1
 #endif
@@ -1048,12 +1053,16 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m < NR) {
+#if HGS_TILE_MOVREL
+                    R xr = gtx[m < NR ? m : 0][c], xi = gty[m < NR ? m : 0][c];     // (uniform index: register-relative move)
+#else
                     R xr = gtx[m < NR ? m : 0][0], xi = gty[m < NR ? m : 0][0];
 #pragma unroll
                     for (int cc = 1; cc < 4; ++cc) {
                         xr = (c == cc) ? gtx[m < NR ? m : 0][cc] : xr;
                         xi = (c == cc) ? gty[m < NR ? m : 0][cc] : xi;
                     }
+#endif
                     v[m] = mk<R>(xr * sgs, xi * sgs);
                 } else {
                     v[m] = mk<R>(0, 0);
@@ -1165,11 +1174,16 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
                 const Cx<R> h = v[m] * (sgs * a.scale);
+#if HGS_TILE_MOVREL
+                gtx[m][c] = h.x;
+                gty[m][c] = h.y;
+#else
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     gtx[m][cc] = (c == cc) ? h.x : gtx[m][cc];
                     gty[m][cc] = (c == cc) ? h.y : gty[m][cc];
                 }
+#endif
             }
         }
         if (EXTRAS && cp.weights_only) continue;
