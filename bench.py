@@ -16,6 +16,7 @@ Workloads (``--workload``):
   cfg2       headline (above)                 cfg3      the same with --batch 8
   cfg2dense  cfg 2 geometry, dense random image target (nothing to skip)
   cfg4       CompressedSpotHologram, 1e4 spots, SLM 1152 x 1920, D = 2, WGS-Kim (cfg4d3: D = 3) -- MFMA bound
+  cfg4grid   the DFT-grid companion of cfg 4: SpotHologram with 1e4 spots at distinct pixels of an 8192^2 pad, WGS-Kim
   cfg5mraf   Hologram with MRAF (NaN noise box 3072^2, image 2048^2) on an 8192^2 pad; --dtype f32|f64,
              --method GS|WGS-Leonardo
   cfg5pad / hd / small   spot arrays on 8192^2 / 2048^2 (1080 x 1920 SLM) / 1024^2 pads
@@ -69,7 +70,21 @@ SPOT_WORKLOADS = {
 }
 IMAGE_WORKLOADS = {"cfg2dense": ((4096, 4096), (1152, 1920)), "cfg5mraf": ((8192, 8192), (1152, 1920))}
 COMPRESSED_WORKLOADS = {"cfg4": 2, "cfg4d3": 3}
-ALL_WORKLOADS = sorted(list(SPOT_WORKLOADS) + list(IMAGE_WORKLOADS) + list(COMPRESSED_WORKLOADS))
+# cfg 4's DFT-grid companion: the same number of spots at distinct pixels of an 8192^2 grid, inside the
+# centred 3360^2 box that |k| <= 0.02 rad spans there (pitch 8 um, 0.78 um), WGS-Kim
+VECTOR_WORKLOADS = {"cfg4grid": ((8192, 8192), (1152, 1920), 3360)}
+ALL_WORKLOADS = sorted(list(SPOT_WORKLOADS) + list(IMAGE_WORKLOADS) + list(COMPRESSED_WORKLOADS) + list(VECTOR_WORKLOADS))
+
+
+def grid_spots(shape, box, n):
+    """``n`` distinct pixels (x, y) inside the centred ``box`` x ``box`` window of ``shape``, from the counter PRNG."""
+    from slmsuite_amd import synth
+    lin = np.unique((synth.uniform01(4, (4 * n,), stream=7) * box * box).astype(np.int64))
+    if lin.size < n:
+        raise SystemExit(f"only {lin.size} distinct positions for {n} spots")
+    lin = np.sort(lin[np.argsort(synth.uniform01(5, (lin.size,), stream=8), kind="stable")[:n]])
+    lo_y, lo_x = (shape[0] - box) // 2, (shape[1] - box) // 2
+    return np.stack([lin % box + lo_x, lin // box + lo_y]).astype(np.float64)
 
 
 def parse():
@@ -99,7 +114,7 @@ def parse():
     if a.batch is None:
         a.batch = 8 if a.workload == "cfg3" else 1
     if a.method is None:
-        a.method = "WGS-Kim" if a.workload in COMPRESSED_WORKLOADS else "WGS-Leonardo"
+        a.method = "WGS-Kim" if (a.workload in COMPRESSED_WORKLOADS or a.workload in VECTOR_WORKLOADS) else "WGS-Leonardo"
     return a
 
 
@@ -125,6 +140,14 @@ class GridProblem:
             self.n_targets = grid[0] * grid[1]
             self.sparse_target = True
             self.desc = f"SpotHologram {grid} spots, pitch {pitch}"
+        elif w in VECTOR_WORKLOADS:
+            self.shape, self.slm, box = VECTOR_WORKLOADS[w]
+            host = SpotHologram(self.shape, grid_spots(self.shape, box, args.spots), basis="knm", slm_shape=self.slm,
+                                phase=synth.seed_phase(2, self.slm), dtype=self.np_dtype)
+            target, kw = host.target, dict(spot_index=host.spot_knm_rounded, spot_amp=host.spot_amp)
+            self.n_targets = args.spots
+            self.sparse_target = True
+            self.desc = f"SpotHologram {args.spots} spots at distinct pixels of the centred {box}^2 box"
         else:
             self.shape, self.slm = IMAGE_WORKLOADS[w]
             n = self.shape[0]
@@ -263,6 +286,14 @@ def cpu_baseline(args):
         shape, slm, grid, pitch = SPOT_WORKLOADS[w]
         o = orc.OracleSpotHologram(shape, orc.rectangular_array(shape, grid, pitch), slm_shape=slm,
                                    phase=synth.seed_phase(2, slm), dtype=dt)
+        flags = {}
+        sample = f"{iters} {args.method} loop bodies of {w} (one hologram)"
+    elif w in VECTOR_WORKLOADS:
+        iters = args.cpu_iters if args.cpu_iters is not None else 3
+        if iters <= 0:
+            return None
+        shape, slm, box = VECTOR_WORKLOADS[w]
+        o = orc.OracleSpotHologram(shape, grid_spots(shape, box, args.spots), slm_shape=slm, phase=synth.seed_phase(2, slm), dtype=dt)
         flags = {}
         sample = f"{iters} {args.method} loop bodies of {w} (one hologram)"
     elif w in IMAGE_WORKLOADS:
@@ -406,7 +437,7 @@ def main():
     # targets with empty farfield columns (spot arrays; the zero frame outside an MRAF noise box): the engine would
     # skip those columns, the byte model of the roofline counts all of them - time the dense kernels, report the
     # default separately
-    spot = args.workload in SPOT_WORKLOADS or bool(getattr(prob, "mraf", False))
+    spot = args.workload in SPOT_WORKLOADS or args.workload in VECTOR_WORKLOADS or bool(getattr(prob, "mraf", False))
 
     def barrier():
         prob.engine.sync()

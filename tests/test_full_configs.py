@@ -219,3 +219,32 @@ def test_cfg4_full_size_against_direct_summation(D, sep):
            farfield_64_spots=err_ff, constraint=err_cons, phase_1000_pixels=err_ph)
     assert err_ff < 2e-5 and err_cons < 1e-6 and err_ph < 1e-4
     h._release_engine()
+
+
+# ---- cfg 4's DFT-grid companion: 1e4 spots at distinct pixels of an 8192^2 pad, WGS-Kim ---------
+def _grid_spots(shape, box, n):
+    lin = np.unique((synth.uniform01(4, (4 * n,), stream=7) * box * box).astype(np.int64))
+    lin = np.sort(lin[np.argsort(synth.uniform01(5, (lin.size,), stream=8), kind="stable")[:n]])
+    return np.stack([lin % box + (shape[1] - box) // 2, lin // box + (shape[0] - box) // 2]).astype(np.float64)
+
+
+@pytest.mark.parametrize("path", ["default", "dense"])
+def test_cfg4_grid_companion_follows_oracle(path):
+    """
+    SpotHologram with 1e4 spots at distinct pixels of the centred 3360^2 box of an 8192^2 pad (what |k| <= 0.02 rad
+    spans there), WGS-Kim with the phase fixed from iteration 2: four loop bodies on the engine (active-column list
+    and dense kernels) and on the CPU oracle from the same seed.
+    """
+    shape, n = (8192, 8192), 10000
+    vec = _grid_spots(shape, 3360, n)
+    kw = dict(fix_phase_iteration=2)
+    h = SpotHologram(shape, vec, basis="knm", slm_shape=SLM, phase=synth.seed_phase(4, SLM), engine_options=PATHS[path])
+    o = orc.OracleSpotHologram(shape, vec, slm_shape=SLM, phase=synth.seed_phase(4, SLM))
+    h.optimize("WGS-Kim", maxiter=4, verbose=False, **kw)
+    o.optimize("WGS-Kim", maxiter=4, **kw)
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    errs = dict(spot_amp=rel_l2(h.amp_ff[ky, kx], o.amp_ff[ky, kx]), spot_weights=rel_l2(h.weights[ky, kx], o.weights[ky, kx]),
+                phase=phase_rel_l2(h.phase, o.phase))
+    report(f"cfg4 grid companion WGS-Kim 4 it [{path}]", **errs)
+    assert h.stats["flags"]["fixed_phase"] == o.stats["flags"]["fixed_phase"]
+    assert errs["spot_amp"] < 1e-5 and errs["spot_weights"] < 1e-5 and errs["phase"] < 1e-4
