@@ -14,6 +14,7 @@ the timed region, fed straight from device memory).
 
 Workloads (``--workload``):
   cfg2       headline (above)                 cfg3      the same with --batch 8
+  cfg1       Hologram 512 x 512 on a 512 x 512 SLM, GS (BASELINE configs[0], the reference's CPU-runnable case)
   cfg2dense  cfg 2 geometry, dense random image target (nothing to skip)
   cfg4       CompressedSpotHologram, 1e4 spots, SLM 1152 x 1920, D = 2, WGS-Kim (cfg4d3: D = 3) -- MFMA bound
   cfg4grid   the DFT-grid companion of cfg 4: SpotHologram with 1e4 spots at distinct pixels of an 8192^2 pad, WGS-Kim
@@ -68,7 +69,7 @@ SPOT_WORKLOADS = {
     "hd": ((2048, 2048), (1080, 1920), (16, 16), (64, 64)),        # a 1920x1080 SLM at padding_order = 1
     "cfg5pad": ((8192, 8192), (1152, 1920), (32, 32), (128, 128)),
 }
-IMAGE_WORKLOADS = {"cfg2dense": ((4096, 4096), (1152, 1920)), "cfg5mraf": ((8192, 8192), (1152, 1920))}
+IMAGE_WORKLOADS = {"cfg1": ((512, 512), (512, 512)), "cfg2dense": ((4096, 4096), (1152, 1920)), "cfg5mraf": ((8192, 8192), (1152, 1920))}
 COMPRESSED_WORKLOADS = {"cfg4": 2, "cfg4d3": 3}
 # cfg 4's DFT-grid companion: the same number of spots at distinct pixels of an 8192^2 grid, inside the
 # centred 3360^2 box that |k| <= 0.02 rad spans there (pitch 8 um, 0.78 um), WGS-Kim
@@ -114,7 +115,8 @@ def parse():
     if a.batch is None:
         a.batch = 8 if a.workload == "cfg3" else 1
     if a.method is None:
-        a.method = "WGS-Kim" if (a.workload in COMPRESSED_WORKLOADS or a.workload in VECTOR_WORKLOADS) else "WGS-Leonardo"
+        a.method = ("WGS-Kim" if (a.workload in COMPRESSED_WORKLOADS or a.workload in VECTOR_WORKLOADS) else
+                    "GS" if a.workload == "cfg1" else "WGS-Leonardo")
     return a
 
 
@@ -160,6 +162,10 @@ class GridProblem:
                 self.flags = {"mraf_factor": 0.5}
                 self.n_targets = 2048 * 2048
                 self.desc = "Hologram MRAF (mraf_factor 0.5; NaN noise box 3072^2, image 2048^2)"
+            elif w == "cfg1":
+                target = synth.random_target(1, self.shape, dtype=self.np_dtype)
+                self.n_targets = n * n
+                self.desc = "Hologram, random amplitude image (the reference's CPU-runnable case; launch / latency bound here)"
             else:
                 target = synth.random_target(11, self.shape, 0.2, 1.0, dtype=self.np_dtype)
                 self.n_targets = n * n
@@ -297,7 +303,7 @@ def cpu_baseline(args):
         flags = {}
         sample = f"{iters} {args.method} loop bodies of {w} (one hologram)"
     elif w in IMAGE_WORKLOADS:
-        iters = args.cpu_iters if args.cpu_iters is not None else (12 if w == "cfg2dense" else 3)
+        iters = args.cpu_iters if args.cpu_iters is not None else (200 if w == "cfg1" else 12 if w == "cfg2dense" else 3)
         if iters <= 0:
             return None
         shape, slm = IMAGE_WORKLOADS[w]
@@ -309,6 +315,9 @@ def cpu_baseline(args):
             a, b = (n - 2048) // 2, (n + 2048) // 2
             t[a:b, a:b] = synth.random_target(5, (b - a, b - a), 0.2, 1.0, dtype=dt)
             flags = {"mraf_factor": 0.5}
+        elif w == "cfg1":
+            t = synth.random_target(1, shape, dtype=dt)
+            flags = {}
         else:
             t = synth.random_target(11, shape, 0.2, 1.0, dtype=dt)
             flags = {}

@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/configs.jsonl
 : > $OUT
 run() { echo "== $@" >&2; timeout 900 python bench.py "$@" 2>gpurun_out/configs.err | grep '^{' >> $OUT || { echo "FAILED: $@"; tail -5 gpurun_out/configs.err; }; }
+run --workload cfg1 --steps 400 --warmup 20
 run --workload cfg3 --steps 100 --warmup 10
 run --workload cfg2dense --steps 100 --warmup 12
 run --workload cfg2dense --steps 100 --warmup 12 --method GS
