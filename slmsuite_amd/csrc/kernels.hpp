@@ -381,7 +381,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo g = a.g;
     const int tid = threadIdx.x;
-    const int f = tid / T, j = tid % T;
+    // (T a multiple of 64: the row of a lane is the same for its whole wave -- say so, or every per-row predicate and
+    //  address is treated as divergent: exec-mask branches, per-lane 64-bit addresses, unmerged loads)
+    const int f = (T % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T, j = tid % T;
     const int b = blockIdx.y;
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + f * lds_elems<N>();
 
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo g = a.g;
     const int tid = threadIdx.x;
-    const int cpar = tid / T, j = tid % T;
+    const int cpar = (T % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T, j = tid % T;   // wave-uniform (see row_kernel)
     const int b = blockIdx.y;
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo g = a.g;
     const int tid = threadIdx.x;
-    const int cpar = tid / T, j = tid % T;
+    const int cpar = (T % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T, j = tid % T;   // wave-uniform (see row_kernel)
     const int b = blockIdx.y;
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + cpar * lds_elems<N>();
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
@@ -787,12 +789,15 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
         const R* wc = a.w + cb;
         const R* tc = a.t + cb;
-        const bool ok = col_valid(q);
-        static_for<0, 16>([&](auto m_) {
-            constexpr int m = m_;
-            wr[m] = ok ? wc[lane_pos<T>(j, m)] : (R)0;
-            if (cp.do_update || STATS || cp.mraf) tr[m] = ok ? tc[lane_pos<T>(j, m)] : (R)0;
-        });
+        // one (wave-uniform where T >= 64) branch around the whole group: a select per element turns every load into
+        // its own predicated dword access instead of four 16-byte ones
+        const bool need_t = cp.do_update || STATS || cp.mraf;
+        if (col_valid(q)) {
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = wc[lane_pos<T>(j, m)]; });
+            if (need_t) static_for<0, 16>([&](auto m_) { constexpr int m = m_; tr[m] = tc[lane_pos<T>(j, m)]; });
+        } else {
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = (R)0; tr[m] = (R)0; });
+        }
     };
     auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
         int ct, c4;
