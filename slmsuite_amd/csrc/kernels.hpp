@@ -27,6 +27,9 @@
 #ifndef HGS_ROW_TW_RESIDENT
 #define HGS_ROW_TW_RESIDENT true
 #endif
+#ifndef HGS_ROW_BUF
+#define HGS_ROW_BUF 1        // row kernel: raw buffer accesses, straight-line (rows whose lane group is a whole number of waves)
+#endif
 #ifndef HGS_ROW_PHASOR
 #define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
 #endif
@@ -338,6 +341,39 @@ __device__ __forceinline__ R weight_factor(int method, R fb, R t, R p_exp, R p_f
     return fc;
 }
 
+// ---- raw buffer accesses ------------------------------------------------------------------------------
+// One resource per array (row): the lane part of an address is ONE VGPR offset for all the registers of a lane,
+// the register part an SGPR offset, and the range check of the resource does the predication -- an element
+// outside [0, bytes) reads as zero and its store is dropped -- so a row of predicated accesses is straight-line
+// code instead of one exec-mask branch per element.  gfx9 range-checks the VGPR offset + immediate only (NOT the
+// SGPR offset): whatever has to be checked goes into the VGPR offset.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0xf0000000u;   // a VGPR offset past every resource
+struct Buf {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ Buf(const void* p, unsigned bytes)
+        : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+    template <typename V> __device__ __forceinline__ V ld(unsigned voff, unsigned soff) const {
+        if constexpr (sizeof(V) == 4) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    }
+    template <typename V> __device__ __forceinline__ void st(V x, unsigned voff, unsigned soff) const {
+        if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, voff, soff, 0);
+        else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, x), r, voff, soff, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, x), r, voff, soff, 0);
+    }
+};
+// 1 / sqrt(x) from the hardware instruction (1 ulp), pre-scaled where x is too small for it (v_rsq_f32 takes
+// denormal inputs as zero): the values of rsqrtf() without its inlined control flow
+__device__ __forceinline__ float rsqrt_full(float x) {
+    const bool tiny = x < 0x1p-100f;
+    const float r = __builtin_amdgcn_rsqf(tiny ? x * 0x1p+100f : x);
+    return tiny ? r * 0x1p+50f : r;
+}
+__device__ __forceinline__ double rsqrt_full(double x) { return 1.0 / ::sqrt(x); }
+
 // =====================================================================================================
 // ROW kernels: transforms along x over the Sh SLM rows.
 //   MODE 0 : phase -> G            (_build_nearfield :1000 + row half of fft2 :1048)
@@ -462,6 +498,88 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
         const R* am = a.amp ? a.amp + srow : nullptr;
         Cx<R>* ghr = gh + (size_t)rr * 4;
 
+        // (measured: 2048^2 22.5 -> 21.5 us, 1024^2 10.8 -> 10.2 us; 4096 / 8192-wide rows lose 1 us with it -- their
+        //  one-row workgroups gain nothing from the shorter code and pay for the 8 more eager phasors -- and keep the
+        //  branching form)
+        if constexpr (HGS_ROW_BUF && T % 64 == 0 && T <= 128) {
+            // ---- straight-line form: raw buffer accesses (see Buf), no per-element branch ----
+            // resources of this row (wave-uniform); a row past Sh gets empty ones: loads give 0, stores vanish
+            constexpr unsigned CB = sizeof(Cx<R>), RB = sizeof(R);
+            const unsigned row_bytes = valid ? (unsigned)g.Sw * RB : 0u;
+            const Buf bph(ph, row_bytes);
+            const Buf bkn(kn, kn != nullptr ? row_bytes : 0u);
+            const Buf bam(am, am != nullptr ? row_bytes : 0u);
+            const Buf bgh(gh, valid ? (unsigned)((size_t)g.Sh * g.Pw * CB) : 0u);
+            const unsigned ghl = gh_lane * CB, ghs = gh_step * CB, ghr0 = (unsigned)rr * 4u * CB;
+            const unsigned c_off = (unsigned)c_lane * RB, c_step = (unsigned)T * RB;   // negative columns wrap out of range
+            if constexpr (MODE != 0) {
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const unsigned vo = ((lmask >> m) & 1u) ? ghl : BUF_OOB;
+                    v[m] = bgh.template ld<Cx<R>>(vo, ghr0 + (unsigned)m * ghs) * sgn;
+                });
+#if HGS_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                HGS_T(fft.tr_n, 2);
+                if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
+                else fft.inv(v, lds, j);
+                if constexpr (MODE == 1) {
+                    const R sc = sgs * a.scale;
+                    if (a.nf_out != nullptr) {
+                        const Buf bnf(a.nf_out + (size_t)b * g.Sh * g.Sw + srow, row_bytes * 2u);
+                        static_for<0, 16>([&](auto m_) {
+                            constexpr int m = m_;
+                            bnf.template st<Cx<R>>(v[m] * sc, (c_off + (unsigned)m * c_step) * 2u, 0u);
+                        });
+                    } else {
+                        static_for<0, 16>([&](auto m_) {
+                            constexpr int m = m_;
+                            const unsigned co = c_off + (unsigned)m * c_step;
+                            R p = M::atan2(v[m].y * sc, v[m].x * sc) - bkn.template ld<R>(co, 0u);   // (no kernel: reads 0)
+                            bph.template st<R>(p, co, 0u);
+                            if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                        });
+                    }
+                }
+            }
+            if constexpr (MODE != 1) {
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const unsigned co = c_off + (unsigned)m * c_step;
+                    R amv = bam.template ld<R>(co, 0u);                      // (no amplitude array: empty resource)
+                    if (am == nullptr) amv = (co < row_bytes) ? a.amp_scalar : (R)0;
+                    Cx<R> nf;
+                    if constexpr (MODE == 2) {
+                        // evaluated eagerly and selected (a conditional around it is a branch per element)
+                        const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
+                        const Cx<R> on = v[m] * (amv * rsqrt_full(p2));
+                        nf.x = (p2 > (R)0) ? on.x : amv * sgs;
+                        nf.y = (p2 > (R)0) ? on.y : (R)0;
+                    } else {
+                        const R p = bph.template ld<R>(co, 0u) + bkn.template ld<R>(co, 0u);
+                        R sn, cs;
+                        M::sincos(p, &sn, &cs);
+                        nf = mk<R>(amv * sgs * cs, amv * sgs * sn);
+                    }
+                    v[m] = nf;
+                    if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                });
+                HGS_T(fft.tr_n, 3);
+                fft.fwd(v, lds, j);
+                HGS_T(fft.tr_n, 4);
+                const R sc = sgn * a.scale;
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const unsigned vo = ((smask >> m) & 1u) ? ghl : BUF_OOB;
+                    bgh.template st<Cx<R>>(v[m] * sc, vo, ghr0 + (unsigned)m * ghs);
+                });
+#if HGS_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                HGS_T(fft.tr_n, 5);
+            }
+        } else {
         if constexpr (MODE != 0) {
             // ---- load H row, centred inverse transform along x ----
             static_for<0, 16>([&](auto m_) {
@@ -546,6 +664,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             HGS_T(fft.tr_n, 5);
+        }
         }
     }
 #if HGS_TRACE
