@@ -27,6 +27,9 @@
 #ifndef HGS_ROW_TW_RESIDENT
 #define HGS_ROW_TW_RESIDENT true
 #endif
+#ifndef HGS_COL_BUF
+#define HGS_COL_BUF 1        // fused column kernel: G / H columns through a buffer resource (see Buf)
+#endif
 #ifndef HGS_ROW_BUF
 #define HGS_ROW_BUF 1        // row kernel: raw buffer accesses, straight-line (rows whose lane group is a whole number of waves)
 #endif
@@ -918,9 +921,23 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = (R)0; tr[m] = (R)0; });
         }
     };
+    // rows outside the SLM (and whole columns past the end of a list) through the range check of a buffer resource
+    // where the column of a lane is wave-uniform: 16 straight-line loads / stores instead of 16 branches
+    constexpr bool GBUF = HGS_COL_BUF && T % 64 == 0;
+    constexpr unsigned CB = sizeof(Cx<R>);
+    auto g_buf = [&](int q, int ct, int c4) {
+        const Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
+        return Buf(gh, col_valid(q) ? (unsigned)(g.Sh * 4 - c4) * CB : 0u);
+    };
+    const unsigned g_voff = (unsigned)r_lane * 4u * CB, g_vstep = (unsigned)T * 4u * CB;    // negative rows wrap out of range
     auto issue_g = [&](int q, Cx<R> (&dst)[16]) {
         int ct, c4;
         col_of(q, ct, c4);
+        if constexpr (GBUF) {
+            const Buf bg = g_buf(q, ct, c4);
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; dst[m] = bg.template ld<Cx<R>>(g_voff + (unsigned)m * g_vstep, 0u); });
+            return;
+        }
         const Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
         static_for<0, 16>([&](auto m_) {
             constexpr int m = m_;
@@ -1029,12 +1046,17 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         }
         if (!cp.weights_only) {
             fft.inv_after_fwd(v, lds, j);
-            Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
-            static_for<0, 16>([&](auto m_) {
-                constexpr int m = m_;
-                const int r = r_lane + m * T;
-                if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * scs;
-            });
+            if constexpr (GBUF) {
+                const Buf bg = g_buf(q, ct, c4);
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; bg.template st<Cx<R>>(v[m] * scs, g_voff + (unsigned)m * g_vstep, 0u); });
+            } else {
+                Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const int r = r_lane + m * T;
+                    if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * scs;
+                });
+            }
         }
         if constexpr (!LEAN) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
