@@ -987,11 +987,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if (cp.do_update) {
                 const R t = tr[m];
                 if (cp.method == M_LEONARDO || cp.method == M_KIM) {
-                    if (t != (R)0) {                       // T == 0 -> factor 1 (:1841)
-                        R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
-                        if (!(fc < (R)INFINITY)) fc = 1;   // inf (:1840,:1867) and nan (:1843) -> 1
-                        wv *= fc;
-                    }
+                    // evaluated for every lane and selected (a branch per pixel splits the pass into 16 blocks):
+                    // T == 0 -> factor 1 (:1841); inf (:1840,:1867) and nan (:1843) -> 1
+                    R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
+                    fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
+                    wv *= fc;
                 } else {
                     wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, nogv);
                 }
@@ -1009,13 +1009,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if constexpr (PHASE == 2) {
                 M::sincos_phase(pfc[idx], &si, &co);
             } else {
-                if (p2 > (R)0) {                           // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
-                    const R inv = M::rsqrt(p2);
-                    co = F.x * inv;
-                    si = F.y * inv;
-                } else {
-                    co = 1;
-                    si = 0;
+                {                                          // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
+                    const R inv = rsqrt_full(p2);
+                    co = (p2 > (R)0) ? F.x * inv : (R)1;
+                    si = (p2 > (R)0) ? F.y * inv : (R)0;
                 }
                 if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
@@ -1253,11 +1250,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 if (cp.do_update) {
                     const R t = tr[m];
                     if (cp.method == M_LEONARDO || cp.method == M_KIM) {
-                        if (t != (R)0) {
-                            R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
-                            if (!(fc < (R)INFINITY)) fc = 1;
-                            wv *= fc;
-                        }
+                        R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);     // (eager + select, see col_fused_kernel)
+                        fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
+                        wv *= fc;
                     } else {
                         wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, nogv);
                     }
@@ -1277,11 +1272,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     M::sincos_phase(pf[m], &sn, &cs);
                     ph = mk<R>(cs, sn);
                 } else {
-                    if (p2 > (R)0) {
-                        const R inv = M::rsqrt(p2);
-                        ph = mk<R>(F.x * inv, F.y * inv);
-                    } else {
-                        ph = mk<R>(1, 0);
+                    {
+                        const R inv = rsqrt_full(p2);
+                        ph = mk<R>((p2 > (R)0) ? F.x * inv : (R)1, (p2 > (R)0) ? F.y * inv : (R)0);
                     }
                     if constexpr (PHASE == 1) pf[m] = M::atan2(F.y, F.x);
                 }
