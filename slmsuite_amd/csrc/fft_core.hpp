@@ -107,6 +107,42 @@ template <typename V> __device__ __forceinline__ V cmulc(V a, V b) {
     }
 }
 
+// Four values times the same factor w (DIR < 0) or conj(w) (DIR > 0), in place.  fp32: ONE asm statement with the four
+// multiplies ahead of the four dependent fused multiply-adds -- as single cmul()s the two instructions of a product
+// sit back to back in the instruction stream (the compiler cannot see into the asm to interleave them) with a hazard
+// s_nop between them, and all products of a group chain through one temporary.
+template <int DIR, typename V> __device__ __forceinline__ void cmul4(V& a0, V& a1, V& a2, V& a3, V w) {
+    if constexpr (std::is_same<V, v2f>::value) {
+        v2f t0, t1, t2, t3;
+        if constexpr (DIR < 0) {
+            asm("v_pk_mul_f32 %4, %0, %8 op_sel_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %5, %1, %8 op_sel_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %6, %2, %8 op_sel_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %7, %3, %8 op_sel_hi:[0,1]\n\t"
+                "v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+                "v_pk_fma_f32 %1, %1, %8, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+                "v_pk_fma_f32 %2, %2, %8, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+                "v_pk_fma_f32 %3, %3, %8, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(w));
+        } else {
+            asm("v_pk_mul_f32 %4, %0, %8 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %5, %1, %8 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %6, %2, %8 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %7, %3, %8 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                "v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %1, %1, %8, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %2, %2, %8, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %3, %3, %8, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(w));
+        }
+    } else {
+        a0 = DIR < 0 ? cmul(a0, w) : cmulc(a0, w);
+        a1 = DIR < 0 ? cmul(a1, w) : cmulc(a1, w);
+        a2 = DIR < 0 ? cmul(a2, w) : cmulc(a2, w);
+        a3 = DIR < 0 ? cmul(a3, w) : cmulc(a3, w);
+    }
+}
+
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
         f(std::integral_constant<int, I>{});
@@ -216,12 +252,9 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
         dft4<DIR>(v[2], v[6], v[10], v[14]);
         dft4<DIR>(v[3], v[7], v[11], v[15]);
         if constexpr (TW) {
-            static_for<0, 4>([&](auto p2_) {
-                constexpr int p2 = p2_;
-                v[1 + 4 * p2] = DIR < 0 ? cmul(v[1 + 4 * p2], bt1) : cmulc(v[1 + 4 * p2], bt1);
-                v[2 + 4 * p2] = DIR < 0 ? cmul(v[2 + 4 * p2], bt2) : cmulc(v[2 + 4 * p2], bt2);
-                v[3 + 4 * p2] = DIR < 0 ? cmul(v[3 + 4 * p2], bt3) : cmulc(v[3 + 4 * p2], bt3);
-            });
+            cmul4<DIR>(v[1], v[5], v[9], v[13], bt1);
+            cmul4<DIR>(v[2], v[6], v[10], v[14], bt2);
+            cmul4<DIR>(v[3], v[7], v[11], v[15], bt3);
         }
         // step 2: twiddle t[r1][p2] *= w16^(r1*p2)
         v[5] = rot16<1, DIR>(v[5]);   v[6] = rot16<2, DIR>(v[6]);   v[7] = rot16<3, DIR>(v[7]);
@@ -288,24 +321,18 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
         v[9] = rot16<2, DIR>(v[9]);   v[10] = rot16<4, DIR>(v[10]); v[11] = rot16<6, DIR>(v[11]);
         v[13] = rot16<3, DIR>(v[13]); v[14] = rot16<6, DIR>(v[14]); v[15] = rot16<9, DIR>(v[15]);
         // ... *= W^(p1 k)
-        static_for<0, 4>([&](auto r2_) {
-            constexpr int r2 = r2_;
-            v[4 + r2] = DIR < 0 ? cmul(v[4 + r2], bt1) : cmulc(v[4 + r2], bt1);
-            v[8 + r2] = DIR < 0 ? cmul(v[8 + r2], bt2) : cmulc(v[8 + r2], bt2);
-            v[12 + r2] = DIR < 0 ? cmul(v[12 + r2], bt3) : cmulc(v[12 + r2], bt3);
-        });
+        cmul4<DIR>(v[4], v[5], v[6], v[7], bt1);
+        cmul4<DIR>(v[8], v[9], v[10], v[11], bt2);
+        cmul4<DIR>(v[12], v[13], v[14], v[15], bt3);
         // layer 2: DFT4 over r2 for each p1 -> V[p1 + 4 p2] at v[4 p1 + p2]
         dft4<DIR>(v[0], v[1], v[2], v[3]);
         dft4<DIR>(v[4], v[5], v[6], v[7]);
         dft4<DIR>(v[8], v[9], v[10], v[11]);
         dft4<DIR>(v[12], v[13], v[14], v[15]);
         // ... *= W^(4 p2 k)
-        static_for<0, 4>([&](auto p1_) {
-            constexpr int p1 = p1_;
-            v[4 * p1 + 1] = DIR < 0 ? cmul(v[4 * p1 + 1], ot1) : cmulc(v[4 * p1 + 1], ot1);
-            v[4 * p1 + 2] = DIR < 0 ? cmul(v[4 * p1 + 2], ot2) : cmulc(v[4 * p1 + 2], ot2);
-            v[4 * p1 + 3] = DIR < 0 ? cmul(v[4 * p1 + 3], ot3) : cmulc(v[4 * p1 + 3], ot3);
-        });
+        cmul4<DIR>(v[1], v[5], v[9], v[13], ot1);
+        cmul4<DIR>(v[2], v[6], v[10], v[14], ot2);
+        cmul4<DIR>(v[3], v[7], v[11], v[15], ot3);
         // natural order
         Cx<R> t;
         t = v[1]; v[1] = v[4]; v[4] = t;
@@ -442,11 +469,7 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
             if constexpr (RAD == 16 && s > 0) {
                 static_for<1, 4>([&](auto r2_) {
                     constexpr int r2 = r2_;
-                    static_for<0, 4>([&](auto r1_) {
-                        constexpr int r = r1_ + 4 * r2;
-                        const Cx<R> w = this->template twv<s, r2 - 1>(j);
-                        u[r] = DIR < 0 ? cmul(u[r], w) : cmulc(u[r], w);
-                    });
+                    cmul4<DIR>(u[4 * r2], u[4 * r2 + 1], u[4 * r2 + 2], u[4 * r2 + 3], this->template twv<s, r2 - 1>(j));
                 });
                 if (!HGS_ABL_BFLY)
                     Dft<16, DIR, R>::template run_tw<true>(u, this->template twv<s, 3>(j), this->template twv<s, 4>(j),
@@ -574,11 +597,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         if (HGS_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         static_for<1, 4>([&](auto r2_) {
             constexpr int r2 = r2_;
-            const Cx<R> w = this->template twv<s, r2 - 1>(p);
-            static_for<0, 4>([&](auto r1_) {
-                constexpr int r = r1_ + 4 * r2;
-                v[r] = DIR < 0 ? cmul(v[r], w) : cmulc(v[r], w);
-            });
+            cmul4<DIR>(v[4 * r2], v[4 * r2 + 1], v[4 * r2 + 2], v[4 * r2 + 3], this->template twv<s, r2 - 1>(p));
         });
         Dft<16, DIR, R>::template run_tw<true>(v, this->template twv<s, 3>(p), this->template twv<s, 4>(p),
                                                this->template twv<s, 5>(p));
