@@ -68,6 +68,9 @@ struct Geo {
 #ifndef HGS_TILE_MOVREL
 #define HGS_TILE_MOVREL 1
 #endif
+#ifndef HGS_CONS_GROUP
+#define HGS_CONS_GROUP 16    // pixels of a lane whose rule evaluation the scheduler may interleave (fp32; fp64: 4)
+#endif
 #ifndef HGS_LANE_MAJOR
 #define HGS_LANE_MAJOR 1
 #endif
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                     if constexpr (PHASE == 1) { if (vcol) pfc[idx] = (R)0; }
                 }
             }
-            if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) - 1) __builtin_amdgcn_sched_barrier(0);
         });
 
         if constexpr (STATS) sacc.flush(stat_slot);
@@ -1289,7 +1292,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                         if constexpr (PHASE == 1) pf[m] = (R)0;      // atan2 of the zeroed field
                     }
                 }
-                if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) - 1) __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (STATS) sacc.flush(stat_slot);
             // updated weights of this lane (unchanged lanes -- zeros of a sparse target -- write nothing)
