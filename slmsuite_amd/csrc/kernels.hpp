@@ -636,7 +636,8 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) 
                     if constexpr (MODE == 2 && HGS_ROW_PHASOR) {
                         // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
-                        nf = (p2 > (R)0) ? v[m] * (amv * M::rsqrt(p2)) : mk<R>(amv * sgs, 0);
+                        const Cx<R> on = v[m] * (amv * rsqrt_full(p2));      // (eager + select: no inner branches)
+                        nf = mk<R>((p2 > (R)0) ? on.x : amv * sgs, (p2 > (R)0) ? on.y : (R)0);
                     } else if constexpr (MODE == 2) {
                         // the reference's own arithmetic: phase rounded to working precision, then exp(i phase)
                         const R scs = sgs * a.scale;
@@ -992,9 +993,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if (cp.method == M_LEONARDO || cp.method == M_KIM) {
                     // evaluated for every lane and selected (a branch per pixel splits the pass into 16 blocks):
                     // T == 0 -> factor 1 (:1841); inf (:1840,:1867) and nan (:1843) -> 1
-                    R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
-                    fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
-                    wv *= fc;
+                    // (fp64: the rule is some hundred instructions of double log2 / exp2 -- worth the branch)
+                    if (sizeof(R) == 4 || t != (R)0) {
+                        R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
+                        fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
+                        wv *= fc;
+                    }
                 } else {
                     wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, nogv);
                 }
@@ -1012,10 +1016,13 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if constexpr (PHASE == 2) {
                 M::sincos_phase(pfc[idx], &si, &co);
             } else {
-                {                                          // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
+                if (sizeof(R) == 4 || p2 > (R)0) {         // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
                     const R inv = rsqrt_full(p2);
                     co = (p2 > (R)0) ? F.x * inv : (R)1;
                     si = (p2 > (R)0) ? F.y * inv : (R)0;
+                } else {
+                    co = 1;
+                    si = 0;
                 }
                 if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
