@@ -797,18 +797,28 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                 Cx<R>* ffc = a.ff + cb;
                 R* afc = a.amp_ff + cb;
                 R* pfc = a.pff ? a.pff + cb : nullptr;
+                // the 16 pixels of a lane are contiguous (lane-major layout): one test, then whole-group stores (an
+                // element-wise test + scheduling barrier turned them into 32 scalar stores per lane and pass)
+                R af[16];
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    const unsigned idx = lane_pos<T>(j, m);
                     const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
-                    if (vcol) {
-                        ffc[idx] = v[m];
-                        afc[idx] = M::sqrt(p2);
-                        if (a.store_pff) pfc[idx] = M::atan2(v[m].y, v[m].x);
-                    }
+                    af[m] = M::sqrt(p2);
                     acc_f += (double)p2;
-                    __builtin_amdgcn_sched_barrier(0);
                 });
+                if (vcol) {
+                    static_for<0, 16>([&](auto m_) { constexpr int m = m_; ffc[lane_pos<T>(j, m)] = v[m]; });
+                    static_for<0, 16>([&](auto m_) { constexpr int m = m_; afc[lane_pos<T>(j, m)] = af[m]; });
+                    if (a.store_pff) {
+                        static_for<0, 4>([&](auto q_) {
+                            constexpr int q4 = q_;
+                            R pf4[4];
+                            static_for<0, 4>([&](auto i_) { constexpr int i = i_; pf4[i] = M::atan2(v[4 * q4 + i].y, v[4 * q4 + i].x); });
+                            static_for<0, 4>([&](auto i_) { constexpr int i = i_; pfc[lane_pos<T>(j, 4 * q4 + i)] = pf4[i]; });
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                    }
+                }
             }
             if constexpr (MODE & C_LOAD) {
                 const Cx<R>* ffc = a.ff + cb;
