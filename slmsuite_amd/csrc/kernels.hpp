@@ -782,12 +782,21 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
             const int kx = ct * 4 + c4;
             const size_t cb = (size_t)b * P + (size_t)kx * g.Ph;   // column base in the P arrays
             Cx<R> v[16];
+            // (rows outside the SLM through the range check of a buffer resource where the column is wave-uniform)
+            constexpr bool GBUF = HGS_COL_BUF && T % 64 == 0;
+            constexpr unsigned CB = sizeof(Cx<R>);
+            const Buf bg(gh + c4, vcol ? (unsigned)(g.Sh * 4 - c4) * CB : 0u);
+            const unsigned g_voff = (unsigned)r_lane * 4u * CB, g_vstep = (unsigned)T * 4u * CB;
             if constexpr (MODE & C_FWD) {
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    const int r = r_lane + m * T;
                     Cx<R> x = mk<R>(0, 0);
-                    if (r >= 0 && r < g.Sh && vcol) x = gh[(unsigned)r * 4u + (unsigned)c4];
+                    if constexpr (GBUF) {
+                        x = bg.template ld<Cx<R>>(g_voff + (unsigned)m * g_vstep, 0u);
+                    } else {
+                        const int r = r_lane + m * T;
+                        if (r >= 0 && r < g.Sh && vcol) x = gh[(unsigned)r * 4u + (unsigned)c4];
+                    }
                     v[m] = x * sgs;
                 });
                 fft.fwd(v, lds, j);
@@ -831,8 +840,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs
                 const R scs = sgs * a.scale;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    const int r = r_lane + m * T;
-                    if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u + (unsigned)c4] = v[m] * scs;
+                    if constexpr (GBUF) {
+                        bg.template st<Cx<R>>(v[m] * scs, g_voff + (unsigned)m * g_vstep, 0u);
+                    } else {
+                        const int r = r_lane + m * T;
+                        if (r >= 0 && r < g.Sh) gh[(unsigned)r * 4u + (unsigned)c4] = v[m] * scs;
+                    }
                 });
             }
         }
