@@ -18,6 +18,9 @@
 #include "fft_core.hpp"
 
 // minimum waves per SIMD the transform kernels are register-allocated for (tunable at build time)
+#ifndef HGS_ROW_OCC_8192
+#define HGS_ROW_OCC_8192 4
+#endif
 #ifndef HGS_ROW_OCC
 #define HGS_ROW_OCC 3
 #endif
@@ -417,7 +420,9 @@ template <typename R> struct RowArgs {
 };
 
 template <typename R, int N, int MODE>
-__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : HGS_ROW_OCC)) void row_kernel(RowArgs<R> a) {
+// (8192-wide rows: a workgroup is 8 waves, two per SIMD -- a second resident workgroup needs four waves per SIMD,
+//  i.e. at most 128 VGPRs)
+__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? HGS_ROW_OCC_8192 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
     using M = Math<R>;
     constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
