@@ -18,6 +18,9 @@
 #include "fft_core.hpp"
 
 // minimum waves per SIMD the transform kernels are register-allocated for (tunable at build time)
+#ifndef HGS_COL_OCC_8192
+#define HGS_COL_OCC_8192 4
+#endif
 #ifndef HGS_ROW_OCC_8192
 #define HGS_ROW_OCC_8192 4
 #endif
@@ -736,7 +739,7 @@ template <typename R> struct ColArgs {
 };
 
 template <typename R, int N, int MODE>
-__global__ __launch_bounds__(ColCfg<N>::WG, HGS_COL_OCC) void col_kernel(ColArgs<R> a) {
+__global__ __launch_bounds__(ColCfg<N>::WG, (N >= 8192 && sizeof(R) == 4 ? HGS_COL_OCC_8192 : HGS_COL_OCC)) void col_kernel(ColArgs<R> a) {   // (8192: see row_kernel)
     using M = Math<R>;
     constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
