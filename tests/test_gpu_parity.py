@@ -730,6 +730,38 @@ def test_sparse_paths_small_grids(shape, slm, n, method, feedback):
                                        err_msg=f"{grp}.{nme}")
 
 
+
+@pytest.mark.parametrize("shape,slm", [((2048, 2048), (1080, 1920)), ((1024, 2048), (288, 480)), ((2048, 1024), (500, 300))])
+@pytest.mark.parametrize("method,kw", [("WGS-Leonardo", {}), ("WGS-Kim", {"fix_phase_iteration": 2})])
+def test_sparse_column_path_two_and_four_lines_per_workgroup(shape, slm, method, kw):
+    """
+    1024- and 2048-point lines put four / two of them into one workgroup (row kernel: raw buffer accesses with the
+    column mask folded into the offset; column kernel: a lane group past the end of the list): 37 scattered spots,
+    active-column path vs dense kernels vs the CPU oracle over five loop bodies.
+    """
+    n = 37
+    lo = (shape[1] // 4, shape[0] // 4)
+    xy = np.vstack((lo[0] + np.floor(shape[1] // 2 * synth.uniform01(81, (n,), 0)), lo[1] + np.floor(shape[0] // 2 * synth.uniform01(81, (n,), 1))))
+    xy = np.unique(xy.astype(int), axis=1).astype(float)
+    amp = 0.5 + synth.uniform01(82, (xy.shape[1],), 0)
+    hs = []
+    for sparse in (1, 0):
+        h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(83, slm),
+                         engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+        h.optimize(method, maxiter=5, verbose=False, **kw)
+        hs.append(h)
+    o = orc.OracleSpotHologram(shape, xy, spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(83, slm))
+    o.optimize(method, maxiter=5, **kw)
+    a, b = hs
+    ky, kx = a.spot_knm_rounded[1], a.spot_knm_rounded[0]
+    errs = dict(sparse_vs_dense=rel_l2(a.amp_ff[ky, kx], b.amp_ff[ky, kx]), phase_sd=phase_rel_l2(a.phase, b.phase),
+                spot_amp=rel_l2(a.amp_ff[ky, kx], o.amp_ff[ky, kx]), weights=rel_l2(a.weights[ky, kx], o.weights[ky, kx]),
+                phase=phase_rel_l2(a.phase, o.phase))
+    report(f"sparse path {shape} {method}", **errs)
+    assert errs["sparse_vs_dense"] < 3e-6 and errs["phase_sd"] < 1e-5
+    assert errs["spot_amp"] < 1e-5 and errs["weights"] < 1e-5 and errs["phase"] < 1e-4
+    assert np.count_nonzero(a.weights) == xy.shape[1]
+
 # ---- padded shapes that are not powers of two (the reference only warns, _hologram.py:378-384) --------------
 GENERAL_SHAPES = [((100, 150), (48, 80), True), ((96, 120), (96, 120), False), ((101, 75), (33, 51), True),
                   ((7, 300), (5, 121), False), ((640, 1000), (300, 500), False), ((1152, 1920), (1152, 1920), False),
