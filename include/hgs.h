@@ -81,7 +81,15 @@ typedef struct {
     int32_t has_mraf_factor;     /* flags["mraf_factor"] is not None                     */
     int32_t zero_mode;           /* flags["zero_factor"] given and != 0 (:1514)          */
     int32_t spot_window;         /* spot_integration_width_knm (_spots.py:1284-1297)     */
+    int32_t efficiency_group;    /* statistics group whose efficiency gates WGS-Kim (0 "computational",
+                                    1 "computational_spot"): the LAST group of stats["stats"] (:1562-1567) */
+    int32_t reserved;            /* keeps the doubles 8-byte aligned; set to 0           */
     double feedback_exponent, feedback_factor, mraf_factor, zero_factor;
+    double fix_phase_efficiency; /* flags["fix_phase_efficiency"] (:1560-1569), NaN = None.  WGS-Kim only: the
+                                    phase is fixed from the iteration AFTER the first one (iter > 0) whose recorded
+                                    efficiency exceeds it.  Needs hgs_iterate_stats with that group (batch = 1);
+                                    hgs_iterate / hgs_farfield_constraint return HGS_ERR_ARG when it is set without
+                                    statistics ("Must track statistics ..."), like the reference's ValueError. */
 } hgs_step;
 
 /* array selectors for hgs_set_array / hgs_get_array */
@@ -118,6 +126,16 @@ int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes);
 int hgs_get_array_device(hgs_engine* e, int which, void* dev, size_t nbytes);
 /* Hologram.reset_weights (:603-614): weights = target with NaN -> 0; zero_weights cleared */
 int hgs_reset_weights(hgs_engine* e);
+/* Hologram.reset (:442-478) as far as the device is concerned: hgs_reset_weights, and phase_ff / farfield /
+ * amp_ff go back to "None" (a later WGS-Kim fix stores a fresh phase; reading them back fails with
+ * HGS_ERR_STATE until hgs_nearfield2farfield ran).  Phase, amplitude, target, spots and options stay. */
+int hgs_reset(hgs_engine* e);
+/* Sparse upload of a farfield-sized real array (HGS_TARGET or HGS_WEIGHTS, kind 0): the array becomes `fill`
+ * everywhere (0 or NaN -- the MRAF background of a SpotHologram with null points is not supported here, upload
+ * it densely) except values[k] at pixel (kx = xy[k], ky = xy[n + k]), k < n, later entries winning where
+ * pixels repeat (NumPy fancy assignment, _spots.py:1541).  One hologram's list broadcasts over the batch.
+ * This is what SpotHologram._set_target_spots produces: n_spots values instead of pad_h * pad_w. */
+int hgs_set_array_sparse(hgs_engine* e, int which, const int32_t* xy, const void* values, int32_t n);
 
 /* Hologram._nearfield2farfield (:1038-1056) + _midloop_cleaning (:951-953): fills farfield and
  * amp_ff; with store_phase_ff != 0 also phase_ff = atan2(farfield) (_populate_results :934-949). */

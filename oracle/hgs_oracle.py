@@ -507,27 +507,44 @@ class OracleSpotHologram(OracleHologram):
     """
 
     def __init__(self, shape, spot_vectors, spot_amp=None, slm_shape=None, phase=None,
-                 amp=None, dtype=np.float32, null_region=None, **flags):
+                 amp=None, dtype=np.float32, null_vectors=None, null_radius=None, null_region=None,
+                 null_region_radius_frac=None, **flags):
         v = np.asarray(spot_vectors, dtype=float).reshape(2, -1)
         N = v.shape[1]
         self.spot_knm = v
         self.spot_amp = np.full(N, 1.0 / np.sqrt(N)) if spot_amp is None else np.ravel(spot_amp)
         self.external_spot_amp = np.copy(self.spot_amp)
+        # null parameters, basis "knm" (:1196-1199)
+        self.null_knm = None if null_vectors is None else np.asarray(null_vectors, dtype=float).reshape(2, -1)
+        self.null_radius_knm = null_radius if self.null_knm is not None else None
         self.null_region_knm = null_region
         self.spot_integration_width_knm = spot_integration_width(v)
         if np.any(v[0] < 0) or np.any(v[1] < 0) or np.any(v[0] >= shape[1]) or np.any(v[1] >= shape[0]):
             raise ValueError("Spots outside SLM computational space bounds!")
+        if self.null_knm is not None:               # :1343-1349
+            if self.null_radius_knm is None:
+                self.null_radius_knm = smallest_distance_chebyshev(np.hstack((self.null_knm, self.spot_knm))) / 4
+            self.null_radius_knm = int(np.ceil(self.null_radius_knm))
         super().__init__((int(shape[0]), int(shape[1])), amp=amp, phase=phase,
                          slm_shape=slm_shape, dtype=dtype, **flags)
+        if null_region_radius_frac is not None:     # :1361-1373 (shape[0] points along x: only square grids agree)
+            if self.null_region_knm is None:
+                self.null_region_knm = np.zeros(self.shape, dtype=bool)
+            xg, yg = np.meshgrid(np.linspace(-1, 1, self.shape[0]), np.linspace(-1, 1, self.shape[1]))
+            self.null_region_knm[np.square(xg) + np.square(yg) > null_region_radius_frac ** 2] = True
         self.set_target_spots(reset_weights=True)
 
     def set_target_spots(self, reset_weights=False):
         self.spot_knm_rounded = np.rint(self.spot_knm).astype(int)
-        if self.null_region_knm is None:
+        if self.null_knm is None:                   # :1514-1515 (a null region alone changes nothing)
             self.target.fill(0)
-        else:   # MRAF background: NaN = free, null_region = forced zero  (:1516-1524)
+        else:   # MRAF background: NaN = free; null region and disks around null points AND spots = 0 (:1516-1538)
             self.target.fill(np.nan)
-            self.target[self.null_region_knm] = 0
+            if self.null_region_knm is not None:
+                self.target[self.null_region_knm] = 0
+            w = int(2 * self.null_radius_knm + 1)
+            for x, y in np.hstack((self.null_knm, self.spot_knm)).T:
+                imprint_zero_disk(self.target, np.rint(x), np.rint(y), w)
         self.target[self.spot_knm_rounded[1], self.spot_knm_rounded[0]] = self.spot_amp
         self.target /= l2norm(self.target)
         if reset_weights:
@@ -564,6 +581,26 @@ class OracleSpotHologram(OracleHologram):
                 stats["computational_spot"] = calculate_stats(
                     np.sqrt(fb), self.spot_amp, total=np.sum(pwr))
         return stats
+
+
+def imprint_zero_disk(matrix, x, y, w):
+    """
+    toolbox.imprint(matrix, (x, w, y, w), 0, centered=True, circular=True) -> window_slice
+    (toolbox/__init__.py:499-528): the bounding box is clipped to [0, n - 1] FIRST, the disk is centred on the
+    clipped box's corner + (w - 1) // 2, and the clipped upper bound is exclusive.
+    """
+    xi = int(x - (w - 2) / 2)
+    xf = xi + int(w)
+    yi = int(y - (w - 2) / 2)
+    yf = yi + int(w)
+    xi, xf = np.clip([xi, xf], 0, matrix.shape[1] - 1)
+    yi, yf = np.clip([yi, yf], 0, matrix.shape[0] - 1)
+    xg, yg = np.meshgrid(np.arange(xi, xf), np.arange(yi, yf))
+    xc = xi + int((w - 1) / 2)
+    yc = yi + int((w - 1) / 2)
+    rr = (w ** 2) * np.square(xg.astype(float) - xc) + (w ** 2) * np.square(yg.astype(float) - yc)
+    mask = rr <= (w ** 2) * (w ** 2) / 4.0
+    matrix[yg[mask], xg[mask]] = 0
 
 
 def smallest_distance_chebyshev(vectors):

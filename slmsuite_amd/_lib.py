@@ -30,9 +30,9 @@ class hgs_config(C.Structure):
 class hgs_step(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("method", "feedback", "iter", "fixed_phase", "fix_phase_iteration", "false_run",
-                 "mraf_enabled", "has_mraf_factor", "zero_mode", "spot_window")] + \
+                 "mraf_enabled", "has_mraf_factor", "zero_mode", "spot_window", "efficiency_group", "reserved")] + \
                [(n, C.c_double) for n in
-                ("feedback_exponent", "feedback_factor", "mraf_factor", "zero_factor")]
+                ("feedback_exponent", "feedback_factor", "mraf_factor", "zero_factor", "fix_phase_efficiency")]
 
 
 _lib = None
@@ -62,6 +62,8 @@ def load():
         "hgs_get_array": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
         "hgs_get_array_device": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
         "hgs_reset_weights": (C.c_int, [eng]),
+        "hgs_reset": (C.c_int, [eng]),
+        "hgs_set_array_sparse": (C.c_int, [eng, C.c_int, P(C.c_int32), C.c_void_p, C.c_int32]),
         "hgs_nearfield2farfield": (C.c_int, [eng, C.c_int]),
         "hgs_farfield_constraint": (C.c_int, [eng, P(hgs_step)]),
         "hgs_farfield2nearfield": (C.c_int, [eng]),
@@ -87,7 +89,7 @@ def load():
 
 
 EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device",
-           "hgs_reset_weights", "hgs_nearfield2farfield", "hgs_farfield_constraint",
+           "hgs_reset_weights", "hgs_reset", "hgs_set_array_sparse", "hgs_nearfield2farfield", "hgs_farfield_constraint",
            "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_multiplane_farfield2nearfield", "hgs_set_option", "hgs_sync", "hgs_profile_enable",
            "hgs_profile_read", "hgs_iterate_timed", "hgs_last_error", "hgs_version")
 

@@ -162,10 +162,12 @@ def optimize_batch_distributed(shape, slm_shape, target, phases, method="WGS-Leo
                 hb.close()
     else:
         if compute is None:
-            if device is None:
-                device = 0
+            if device is None:      # this rank's GPU, as on the RCCL branch (a gloo job may still own one GPU per rank)
+                device = torch.cuda.current_device() if torch.cuda.is_available() else 0
             compute = lambda *a, **k: optimize_batch(*a, device=device, **k)   # noqa: E731
-        local = np.asarray(compute(shape, slm_shape, target, phases[lo:hi], method, maxiter, dtype=dtype, **kw),
+        tg = np.asarray(target)
+        local_target = tg[lo:hi] if tg.ndim == 3 else target      # per-hologram targets shard with the phases
+        local = np.asarray(compute(shape, slm_shape, local_target, phases[lo:hi], method, maxiter, dtype=dtype, **kw),
                            dtype=dtype) if hi > lo else np.zeros((0,) + tuple(slm_shape), dtype=dtype)
         buf = np.zeros((per,) + tuple(slm_shape), dtype=dtype)
         buf[: hi - lo] = local

@@ -88,6 +88,8 @@ struct EngineBase {
     virtual int set_array(int which, const void* host, size_t nbytes) = 0;
     virtual int get_array(int which, void* dst, size_t nbytes, bool dst_device) = 0;
     virtual int reset_weights() = 0;
+    virtual int reset_state() = 0;
+    virtual int set_array_sparse(int which, const int32_t* xy, const void* values, int n) = 0;
     virtual int n2f(int store_pff) = 0;
     virtual int constraint(hgs_step* st) = 0;
     virtual int f2n() = 0;
@@ -403,6 +405,15 @@ template <typename R> struct Engine : EngineBase {
         blue_M[1] = conv_len(g.Ph);
         blue_plain[0] = axis_plain(g.Pw);
         blue_plain[1] = axis_plain(g.Ph);
+        {   // one workgroup holds a whole line in LDS ((17/16) M complex numbers): fail here, with a message, rather
+            // than at the first transform with a raw HIP error
+            int lds_max = 0;
+            HIPCHK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c.device));
+            const size_t need = (size_t)(std::max(blue_M[0], blue_M[1]) / 16 * 17) * sizeof(C);
+            if (need > (size_t)lds_max)
+                return fail(HGS_ERR_UNSUPPORTED, "padded shape (%d, %d) needs %zu bytes of LDS per workgroup, the device offers %d",
+                            c.pad_h, c.pad_w, need, lds_max);
+        }
         ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
         col_blocks = tile_blocks = row_blocks = 1;
         if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
@@ -999,6 +1010,62 @@ template <typename R> struct Engine : EngineBase {
         HIPCHK(hipGetLastError());
         return fill_wscale_one();
     }
+    // Hologram.reset (:442-478): weights from the target, phase_ff / farfield / amp_ff back to "None"
+    int reset_state() override {
+        have_pff = false;
+        farfield_valid = false;
+        return reset_weights();
+    }
+    // n values at listed pixels, `0` everywhere else (SpotHologram targets: n_spots numbers instead of P)
+    int set_array_sparse(int which, const int32_t* xy, const void* values, int n) override {
+        if (cfg.kind != 0) return fail(HGS_ERR_UNSUPPORTED, "sparse uploads are for the padded-grid holograms");
+        if (which != HGS_TARGET && which != HGS_WEIGHTS) return fail(HGS_ERR_ARG, "sparse upload: HGS_TARGET or HGS_WEIGHTS only");
+        if (n < 0 || (n > 0 && (!xy || !values))) return fail(HGS_ERR_ARG, "sparse upload: null list");
+        // duplicates: the last entry wins (NumPy fancy assignment); resolved here so that the scatter is order-free
+        std::vector<uint32_t> pos;
+        std::vector<R> val;
+        pos.reserve(n); val.reserve(n);
+        {
+            std::vector<std::pair<uint32_t, int>> key(n);
+            for (int k = 0; k < n; ++k) {
+                const int x = xy[k], y = xy[n + k];
+                if (x < 0 || x >= g.Pw || y < 0 || y >= g.Ph) return fail(HGS_ERR_ARG, "sparse upload: pixel %d outside the grid", k);
+                const int yd = col_pos(y, g.lane_T);
+                key[k] = {(uint32_t)((size_t)x * g.Ph + yd), k};
+            }
+            std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
+            for (int k = 0; k < n; ++k)
+                if (k + 1 == n || key[k + 1].first != key[k].first) {
+                    pos.push_back(key[k].first);
+                    val.push_back(static_cast<const R*>(values)[key[k].second]);
+                }
+        }
+        R* dst = which == HGS_TARGET ? t : w;
+        HIPCHK(hipMemsetAsync(dst, 0, (size_t)B * P * sizeof(R), stream));
+        const int m = (int)pos.size();
+        if (m > 0) {
+            uint32_t* dpos = nullptr;
+            R* dval = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&dpos), (size_t)m * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&dval), (size_t)m * sizeof(R)));
+            hipError_t e1 = hipMemcpyAsync(dpos, pos.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+            hipError_t e2 = hipMemcpyAsync(dval, val.data(), (size_t)m * sizeof(R), hipMemcpyHostToDevice, stream);
+            if (e1 == hipSuccess && e2 == hipSuccess) {
+                hipLaunchKernelGGL(scatter_values<R>, dim3((m + 255) / 256, B), dim3(256), 0, stream, dst, (const uint32_t*)dpos,
+                                   (const R*)dval, m, P);
+                e1 = hipGetLastError();
+            }
+            hipStreamSynchronize(stream);
+            hipFree(dpos);
+            hipFree(dval);
+            if (e1 != hipSuccess || e2 != hipSuccess) return fail(HGS_ERR_DEVICE, "sparse upload failed");
+        } else {
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        sparse_dirty = true;
+        if (which == HGS_TARGET) { has_target = true; return 0; }
+        return fill_wscale_one();
+    }
 
     // ---- operator launches ----
     RowArgs<R> row_args(bool finalize) {
@@ -1199,6 +1266,34 @@ template <typename R> struct Engine : EngineBase {
         return p;
     }
 
+    // WGS-Kim fixed by efficiency (_hologram.py:1560-1569).  In the reference the flag is raised inside the
+    // routines of the iteration whose recorded efficiency exceeds the threshold; that iteration still takes its
+    // phase from the current farfield and stores it (was_not_fixed, :1582), so raising the flag right AFTER the
+    // iteration is the same thing -- and the statistics the fused pass accumulates are available by then.
+    static bool eff_gate_set(const hgs_step* st) {
+        return st->method == HGS_WGS_KIM && st->fix_phase_efficiency == st->fix_phase_efficiency;
+    }
+    // the efficiency recorded for the iteration that just ran (st->iter not yet advanced); eff_host: value already on
+    // the host (general path) or null to read slot `dev` on the device
+    int eff_gate_after(hgs_step* st, const double* eff_host, const double* dev) {
+        if (!eff_gate_set(st) || st->fixed_phase || st->iter <= 0) return 0;
+        double eff = 0;
+        if (eff_host) eff = *eff_host;
+        else {
+            HIPCHK(hipMemcpyAsync(&eff, dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        if (eff > st->fix_phase_efficiency) st->fixed_phase = 1;
+        return 0;
+    }
+    int eff_gate_check(const hgs_step* st, int groups) {
+        if (!eff_gate_set(st)) return 0;
+        if (st->efficiency_group < 0 || st->efficiency_group > 1 || !(groups & (1 << st->efficiency_group)))
+            return fail(HGS_ERR_ARG, "Must track statistics to fix phase based on efficiency!");
+        if (B != 1) return fail(HGS_ERR_UNSUPPORTED, "fix_phase_efficiency needs one flag per hologram: batch must be 1");
+        return 0;
+    }
+
     CParams<R> cparams(const hgs_step* st, const Plan& p) {
         CParams<R> c{};
         c.method = st->method; c.do_update = p.do_update; c.use_fixed = p.use_fixed; c.store_phase = p.store_phase;
@@ -1295,6 +1390,8 @@ template <typename R> struct Engine : EngineBase {
     int constraint(hgs_step* st) override {
         RoctxRange range(opt_roctx, "hgs_farfield_constraint");
         if (int e = check_step(st)) return e;
+        if (eff_gate_set(st) && st->iter > 0)     // the stepwise caller evaluates the gate itself (it holds the statistics)
+            return fail(HGS_ERR_ARG, "Must track statistics to fix phase based on efficiency!");
         Plan p = plan_iteration(st, nullptr);
         return constraint_planned(st, p);
     }
@@ -1384,6 +1481,7 @@ template <typename R> struct Engine : EngineBase {
             if (r) return r;
             if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
+            if (stat_ctx) { if (int e = eff_gate_after(st, nullptr, stat_ctx->dev_out + ((size_t)i * 2 + st->efficiency_group) * B * 4)) return e; }
             st->iter++;
             Plan pn{0, 0, 0};
             int store_next = 1;
@@ -1402,6 +1500,9 @@ template <typename R> struct Engine : EngineBase {
         if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
         if (n == 0) return 0;
         if (int e = check_step(st)) return e;
+        // the reference raises as soon as an iteration with iter > 0 consults statistics that were never tracked
+        if (!stat_ctx && eff_gate_set(st) && (st->iter > 0 || n > 1))
+            return fail(HGS_ERR_ARG, "Must track statistics to fix phase based on efficiency!");
         const bool fused = fused_ok(st) && !opt_stepwise;
         if (!fused && spot_sparse_ok(st)) return iterate_spot_sparse(st, n, hist);
         if (!fused) {
@@ -1530,6 +1631,7 @@ template <typename R> struct Engine : EngineBase {
             if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
             if (p.do_update) w_pending = true;
+            if (stat_ctx) { if (int e = eff_gate_after(st, nullptr, stat_ctx->dev_out + ((size_t)i * 2 + st->efficiency_group) * B * 4)) return e; }
             st->iter++;
             Plan pn{0, 0, 0};
             if (i + 1 < n) pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
@@ -1576,6 +1678,7 @@ template <typename R> struct Engine : EngineBase {
         if (n == 0) return 0;
         if (cfg.kind != 0) return fail(HGS_ERR_UNSUPPORTED, "hgs_iterate_stats is for the padded-grid holograms");
         if (int e = check_step(st)) return e;
+        if (int e = eff_gate_check(st, groups)) return e;
         std::vector<int32_t> ixy;
         if (groups & 2) {
             if (cfg.n_spots <= 0 || !xy || !has_spots) return fail(HGS_ERR_STATE, "spot statistics need spots");
@@ -1600,6 +1703,7 @@ template <typename R> struct Engine : EngineBase {
                 Plan p = plan_iteration(st, hist ? hist + i : nullptr);
                 if (int e = constraint_planned(st, p)) return e;
                 if (int e = f2n()) return e;
+                if (int e = eff_gate_after(st, out + ((size_t)i * 2 + st->efficiency_group) * B * 4, nullptr)) return e;
                 st->iter++;
             }
             return 0;
@@ -1793,6 +1897,19 @@ template <typename R> struct Engine : EngineBase {
     }
 };
 
+// makes `dev` current for the calling thread, restores the previous device when it goes out of scope
+struct DeviceGuard {
+    int prev = -1, dev;
+    bool ok = true;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace hgs
 
 // =================================================================================================
@@ -1811,7 +1928,10 @@ int hgs_create(const hgs_config* cfg, hgs_engine** out) {
     if (cfg->real_bytes == 4) impl = new hgs::Engine<float>();
     else if (cfg->real_bytes == 8) impl = new hgs::Engine<double>();
     else return hgs::fail(HGS_ERR_ARG, "real_bytes must be 4 or 8 (got %d)", cfg->real_bytes);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     int e = impl->init(*cfg);
+    if (prev >= 0 && prev != cfg->device) (void)hipSetDevice(prev);
     if (e) {
         delete impl;
         return e;
@@ -1829,15 +1949,22 @@ int hgs_destroy(hgs_engine* e) {
 
 // every entry point validates the handle and makes the engine's device current for the calling thread
 // (lazy allocations, event creation and launches all follow the current device)
+// and puts the caller's device back on return: a torch process whose current device differs from the engine's
+// keeps allocating and launching where it was
 #define ENG(e)                                                                         \
     if (!(e) || !(e)->impl) return hgs::fail(HGS_ERR_ARG, "null engine handle");       \
-    if (hipSetDevice((e)->impl->device) != hipSuccess)                                  \
-        return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", (e)->impl->device);
+    hgs::DeviceGuard guard_((e)->impl->device);                                         \
+    if (!guard_.ok) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", (e)->impl->device);
 
 int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes) { ENG(e) return e->impl->set_array(which, host, nbytes); }
 int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes) { ENG(e) return e->impl->get_array(which, host, nbytes, false); }
 int hgs_get_array_device(hgs_engine* e, int which, void* dev, size_t nbytes) { ENG(e) return e->impl->get_array(which, dev, nbytes, true); }
 int hgs_reset_weights(hgs_engine* e) { ENG(e) return e->impl->reset_weights(); }
+int hgs_reset(hgs_engine* e) { ENG(e) return e->impl->reset_state(); }
+int hgs_set_array_sparse(hgs_engine* e, int which, const int32_t* xy, const void* values, int32_t n) {
+    ENG(e)
+    return e->impl->set_array_sparse(which, xy, values, n);
+}
 int hgs_nearfield2farfield(hgs_engine* e, int store_phase_ff) { ENG(e) return e->impl->n2f(store_phase_ff); }
 int hgs_farfield_constraint(hgs_engine* e, hgs_step* step) {
     ENG(e)
@@ -1856,7 +1983,8 @@ int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double*
             info[k].device != info[0].device)
             return hgs::fail(HGS_ERR_ARG, "multiplane: child %d differs in SLM shape, batch, precision or device", k);
     }
-    if (hipSetDevice(info[0].device) != hipSuccess) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", info[0].device);
+    hgs::DeviceGuard guard_(info[0].device);
+    if (!guard_.ok) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", info[0].device);
     for (int k = 0; k < n; ++k) {
         if (int r = children[k]->impl->f2n_complex()) return r;
         if (int r = children[k]->impl->mp_info(&info[k])) return r;     // the nearfield buffer exists now

@@ -1688,6 +1688,12 @@ template <typename R> __global__ void scale_weights_kernel(R* w, const R* wscale
 }
 
 // Hologram.reset_weights (_hologram.py:603-614): weights = target, NaN -> 0; zero_weights cleared
+// hgs_set_array_sparse: dst[b][pos[k]] = val[k] (positions already in the engine layout, unique)
+template <typename R> __global__ void scatter_values(R* dst, const uint32_t* pos, const R* val, int n, size_t P) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[(size_t)blockIdx.y * P + pos[k]] = val[k];
+}
+
 template <typename R> __global__ void reset_weights_kernel(R* w, const R* t, Cx<R>* zw, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const R v = t[i];

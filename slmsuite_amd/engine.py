@@ -75,8 +75,21 @@ class Engine:
     def get_into_device(self, which, dev_ptr, nbytes):
         L.check(self.lib.hgs_get_array_device(self._h, which, C.c_void_p(dev_ptr), nbytes))
 
+    def set_sparse(self, which, xy, values):
+        """hgs_set_array_sparse: ``values[k]`` at pixel (kx = xy[0, k], ky = xy[1, k]), zero elsewhere."""
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=self.dtype)
+        if xy.ndim != 2 or xy.shape[0] != 2 or xy.shape[1] != v.size:
+            raise ValueError("sparse upload needs xy of shape (2, n) and n values")
+        L.check(self.lib.hgs_set_array_sparse(self._h, which, xy.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              v.ctypes.data_as(C.c_void_p), int(v.size)))
+
     def reset_weights(self):
         L.check(self.lib.hgs_reset_weights(self._h))
+
+    def reset(self):
+        """hgs_reset: weights from the target, phase_ff / farfield / amp_ff forgotten (Hologram.reset)."""
+        L.check(self.lib.hgs_reset(self._h))
 
     # -- operators ---------------------------------------------------------------------------
     def nearfield2farfield(self, store_phase_ff=False):
@@ -162,8 +175,12 @@ class Engine:
         return self.lib.hgs_version().decode()
 
 
-def make_step(flags, iteration, false_run=0, mraf_enabled=False, spot_window=3):
-    """POD image of Hologram.flags for one engine call (see hgs_step in include/hgs.h)."""
+def make_step(flags, iteration, false_run=0, mraf_enabled=False, spot_window=3, efficiency_group=None):
+    """
+    POD image of Hologram.flags for one engine call (see hgs_step in include/hgs.h).  ``efficiency_group``
+    (index into Engine.STAT_GROUPS) hands flags["fix_phase_efficiency"] to the engine for a device-resident loop
+    with statistics; None leaves that gate with the caller (the stepwise path evaluates it on the host).
+    """
     method = flags["method"]
     if method not in ALGORITHM_INDEX:
         raise ValueError(f"Unsupported optimization method '{method}'")
@@ -189,4 +206,10 @@ def make_step(flags, iteration, false_run=0, mraf_enabled=False, spot_window=3):
     st.feedback_factor = float(flags.get("feedback_factor", 1.0) or 0.0)
     st.mraf_factor = float(mf) if mf is not None else float("nan")
     st.zero_factor = float(zf if zf is not None else 0.0)
+    st.fix_phase_efficiency = float("nan")
+    st.efficiency_group = 0
+    st.reserved = 0
+    if efficiency_group is not None and flags.get("fix_phase_efficiency", None) is not None and "Kim" in method:
+        st.fix_phase_efficiency = float(flags["fix_phase_efficiency"])
+        st.efficiency_group = int(efficiency_group)
     return st

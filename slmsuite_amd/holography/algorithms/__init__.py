@@ -130,6 +130,7 @@ class Hologram:
         self._stale = set()    # names whose device copy is newer than the host copy
         self._upload = set()   # names whose host copy must reach the device before the next op
         self._n_spots_engine = 0
+        self._weights_reset = False   # weights == target with NaN -> 0 (reset_weights): host copy built on access
         # engine policy applied whenever this hologram creates an engine: {L.OPT_*: value} (hgs_set_option)
         self.engine_options = dict(kwargs.pop("engine_options", {}) or {})
 
@@ -160,13 +161,25 @@ class Hologram:
             arr = self._engine.get(_DEVICE_ARRAYS[name])[0]
             self._host[name] = arr
             self._stale.discard(name)
+        elif name == "weights":
+            self._materialise_weights()
         return self._host.get(name)
 
     def _set_dev(self, name, value):
         self._host[name] = value
         self._stale.discard(name)
+        if name == "weights":
+            self._weights_reset = False
         if value is not None and name in ("phase", "weights", "phase_ff"):
             self._upload.add(name)
+
+    def _materialise_weights(self):
+        """Host copy of freshly reset weights (target with NaN -> 0, :608-614), built only when somebody looks:
+        the device derives its own from the target it already holds (hgs_reset_weights)."""
+        if self.__dict__.get("_weights_reset") and self._host.get("weights") is None and self.target is not None:
+            w = np.array(self.target, copy=True)
+            np.nan_to_num(w, copy=False, nan=0)
+            self._host["weights"] = w
 
     phase = property(lambda s: s._get_dev("phase"), lambda s, v: s._set_dev("phase", v))
     weights = property(lambda s: s._get_dev("weights"), lambda s, v: s._set_dev("weights", v))
@@ -199,8 +212,13 @@ class Hologram:
                 e.set(L.AMP, self.amp)
             if self.propagation_kernel is not None:
                 e.set(L.PROP_KERNEL, self.propagation_kernel)
-            e.set(L.TARGET, self.target)
-            self._upload |= {"phase", "weights"}
+            self._upload_target(e)
+            self._upload.add("phase")
+            if self._weights_reset and self._host.get("weights") is None:
+                e.reset_weights()                     # built on the device from the target just uploaded
+                self._upload.discard("weights")
+            else:
+                self._upload.add("weights")
             if self._host.get("phase_ff") is not None:
                 self._upload.add("phase_ff")
             self._engine_setup(e)
@@ -212,6 +230,10 @@ class Hologram:
 
     def _engine_setup(self, e):
         pass
+
+    def _upload_target(self, e):
+        """The target's way to the device; SpotHologram sends its spot list instead of the raster."""
+        e.set(L.TARGET, self.target)
 
     # ---- reset helpers (_hologram.py:442-614) -----------------------------------------------------------
     def reset(self, reset_phase=True, reset_flags=False):
@@ -228,17 +250,19 @@ class Hologram:
         self._stale -= {"amp_ff", "phase_ff", "farfield"}
         self._upload.discard("phase_ff")
         if self._engine is not None:
-            # phase_ff "None" on the device side: a fresh engine is the simplest faithful reset.  What only
-            # the device holds and must survive (the current phase when reset_phase is False) comes home first.
-            self._release_engine()
+            # the engine survives: weights from its target, phase_ff / farfield / amp_ff back to "None" (hgs_reset);
+            # a phase only the device holds (reset_phase False after an optimize()) simply stays there
+            self._engine.reset()
 
     def _release_engine(self):
-        """Download every device-fresh array that outlives the engine, then destroy it."""
+        """Download every device-fresh array (the engine may not be able to serve all of them), then destroy it."""
         if self._engine is None:
             return
-        for name in ("phase", "weights"):
-            if name in self._stale:
+        for name in list(self._stale):
+            try:
                 self._get_dev(name)
+            except L.HgsError:                  # e.g. a farfield the loop has consumed since: nothing to keep
+                self._host[name] = None
         self._stale.clear()
         self._engine.close()
         self._engine = None
@@ -292,12 +316,12 @@ class Hologram:
         self.phase = ph
 
     def reset_weights(self):
-        w = np.array(self.target, copy=True)
-        np.nan_to_num(w, copy=False, nan=0)
-        self.weights = w
+        self._host["weights"] = None          # = target with NaN -> 0; see _materialise_weights
+        self._stale.discard("weights")
+        self._upload.discard("weights")
+        self._weights_reset = True
         if self._engine is not None:
             self._engine.reset_weights()
-            self._upload.discard("weights")
 
     # ---- padding rule (_hologram.py:616-725) -----------------------------------------------------------
     @staticmethod
@@ -340,6 +364,9 @@ class Hologram:
 
     # ---- target / accessors (_hologram.py:741-931) ---------------------------------------------------------
     def _set_target(self, new_target, reset_weights=False):
+        if not reset_weights:
+            self._materialise_weights()        # weights derived from the OLD target must not follow the new one
+            self._weights_reset = False
         if new_target is None or (hasattr(new_target, "__len__") and len(new_target) == 0):
             self.target = np.zeros(self.shape, dtype=self.dtype)
         else:
@@ -349,7 +376,7 @@ class Hologram:
                 warnings.simplefilter("ignore")
                 self.target *= 1 / _norm(self.target)
         if self._engine is not None:
-            self._engine.set(L.TARGET, self.target)
+            self._upload_target(self._engine)
         if reset_weights:
             self.reset_weights()
 
@@ -563,9 +590,10 @@ class Hologram:
     def _spot_window(self):
         return 3
 
-    def _make_step(self, skip_last=False):
+    def _make_step(self, skip_last=False, efficiency_group=None):
         return make_step(self.flags, self.iter, false_run=self._false_run(skip_last),
-                         mraf_enabled=self._mraf_enabled(), spot_window=self._spot_window())
+                         mraf_enabled=self._mraf_enabled(), spot_window=self._spot_window(),
+                         efficiency_group=efficiency_group)
 
     def _mark_device_fresh(self, names):
         for n in names:
@@ -576,16 +604,34 @@ class Hologram:
         """(groups, width, spot_xy) for Engine.iterate_stats: the groups _update_stats computes on the device."""
         return [g for g in ("computational",) if g in self.flags["stat_groups"]], 1, None
 
-    def _device_loop_ok(self, callback):
+    def _efficiency_group(self):
         """
-        True when the whole loop can run inside one engine call: no callback, no raw farfield
-        capture, no efficiency-gated Kim fixing (that decision needs this iteration's statistics on
-        the host before the constraint, :1560-1569).  Requested statistics are computed on the device
-        in the same pass (hgs_iterate_stats).
+        WGS-Kim fixed by efficiency (:1560-1569) decides on ``stats[groups[-1]]["efficiency"][iter]``, the group
+        that entered ``stats["stats"]`` last.  Returns None when that gate is off, the group's index in
+        Engine.STAT_GROUPS when the engine can decide inside hgs_iterate_stats (exactly one requested group, computed
+        on the device, and it is -- or will become -- the last key), and -1 when the host has to (no statistics:
+        the reference's ValueError; several groups: their order is the iteration order of a Python set).
         """
         fl = self.flags
-        return not (callback is not None or fl.get("raw_stats", False)
-                    or ("Kim" in fl["method"] and fl.get("fix_phase_efficiency", None) is not None))
+        if not ("Kim" in fl["method"] and fl.get("fix_phase_efficiency", None) is not None):
+            return None
+        requested = list(fl["stat_groups"])
+        groups = self._device_stat_groups()[0] if len(requested) > 0 else []
+        if len(requested) != 1 or len(groups) != 1:
+            return -1
+        keys = list(self.stats["stats"].keys())
+        if groups[0] in keys and keys[-1] != groups[0]:
+            return -1
+        return Engine.STAT_GROUPS.index(groups[0])
+
+    def _device_loop_ok(self, callback):
+        """
+        True when the whole loop can run inside one engine call: no callback, no raw farfield capture, and an
+        efficiency-gated Kim fixing only where the engine can take the decision (see _efficiency_group).  Requested
+        statistics are computed on the device in the same pass (hgs_iterate_stats).
+        """
+        fl = self.flags
+        return not (callback is not None or fl.get("raw_stats", False) or self._efficiency_group() == -1)
 
     def optimize_gs(self, iterations, callback):
         e = self._get_engine()
@@ -597,9 +643,10 @@ class Hologram:
             done = 0
             chunk = n_total if bar is None else max(1, n_total // 20)
             groups, width, xy = self._device_stat_groups() if len(self.flags["stat_groups"]) > 0 else ([], 1, None)
+            eg = self._efficiency_group()
             while done < n_total:
                 n = min(chunk, n_total - done)
-                st = self._make_step()
+                st = self._make_step(efficiency_group=eg)
                 if groups:
                     hist, per_iter = e.iterate_stats(st, n, groups, width, xy)
                 else:
@@ -886,15 +933,26 @@ class SpotHologram(FeedbackHologram):
                 toolbox.imprint_disk_zero(target, np.rint(all_spots[0, ii]), np.rint(all_spots[1, ii]), w)
         target[self.spot_knm_rounded[1, :], self.spot_knm_rounded[0, :]] = self.spot_amp
         target /= _norm(target)
+        if not reset_weights:
+            self._materialise_weights()
+            self._weights_reset = False
         self.target = target
         if self._engine is not None:
-            self._engine.set(L.TARGET, self.target)
+            self._upload_target(self._engine)
             self._engine_setup(self._engine)
         if reset_weights:
             self.reset_weights()
 
     def set_target(self, reset_weights=False, plot=False):
         self._set_target_spots(reset_weights=reset_weights)
+
+    def _upload_target(self, e):
+        """One value per spot instead of the padded raster (hgs_set_array_sparse) -- unless null points give the
+        target a NaN background."""
+        if self.null_knm is not None:
+            return super()._upload_target(e)
+        ky, kx = self.spot_knm_rounded[1], self.spot_knm_rounded[0]
+        e.set_sparse(L.TARGET, self.spot_knm_rounded, self.target[ky, kx])
 
     def _engine_setup(self, e):
         e.set(L.SPOT_INDEX, self.spot_knm_rounded)
@@ -1050,6 +1108,9 @@ class CompressedSpotHologram(FeedbackHologram):
             self.spot_amp = np.array(new_target, dtype=self.dtype)
         np.abs(target, out=target)
         target *= 1 / _norm(target)
+        if not reset_weights:
+            self._materialise_weights()
+            self._weights_reset = False
         self.target = target
         if self._engine is not None:
             self._engine.set(L.TARGET, self.target)
@@ -1097,6 +1158,7 @@ class CompressedSpotHologram(FeedbackHologram):
             e.set(L.YGRID, self._yg)
             e.set(L.TARGET, self.target)
             self._spot_zernike_cached = None
+            self._materialise_weights()
             self._upload |= {"phase", "weights"}
             if self._host.get("phase_ff") is not None:
                 self._upload.add("phase_ff")
@@ -1108,7 +1170,7 @@ class CompressedSpotHologram(FeedbackHologram):
             self._upload.discard(name)
         return e
 
-    def _make_step(self, skip_last=False):
+    def _make_step(self, skip_last=False, efficiency_group=None):
         fl = dict(self.flags)
         if fl.get("feedback") in ("computational", "computational_spot"):
             fl["feedback"] = "computational"          # the N-vector rule on amp_ff

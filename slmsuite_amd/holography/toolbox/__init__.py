@@ -162,17 +162,27 @@ def take_indices(vectors, size):
 
 def imprint_disk_zero(matrix, cx, cy, w):
     """
-    toolbox.imprint(matrix, (cx, w, cy, w), 0, centered=True, circular=True): set the pixels of a
-    centred w-wide disk to zero (clipped to the array).  Used by SpotHologram for null points
-    (_spots.py:1531-1538).
+    Zero a w-wide disk around (cx, cy), as SpotHologram does for null points and spots
+    (_spots.py:1531-1538 through toolbox.imprint(..., centered=True, circular=True)).
+
+    Follows the reference at the array edge too (window_slice, toolbox/__init__.py:499-528): the w x w
+    bounding box is clamped into [0, n - 1] per axis before the disk is laid out, its upper bound stays
+    exclusive, and the disk is centred (w - 1) // 2 pixels from the CLAMPED lower corner -- so a disk that
+    crosses the low edge moves inwards and one that crosses the high edge loses the last row / column.
     """
-    h_, w_ = matrix.shape
-    r = w / 2.0
-    x0, y0 = int(cx - w // 2), int(cy - w // 2)
-    for yy in range(max(0, y0), min(h_, y0 + w)):
-        for xx in range(max(0, x0), min(w_, x0 + w)):
-            if (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r:
-                matrix[yy, xx] = 0
+    n_y, n_x = matrix.shape
+    half = (w - 1) // 2
+    lo_x = min(max(int(cx - (w - 2) / 2), 0), n_x - 1)
+    lo_y = min(max(int(cy - (w - 2) / 2), 0), n_y - 1)
+    hi_x = min(max(int(cx - (w - 2) / 2) + int(w), 0), n_x - 1)
+    hi_y = min(max(int(cy - (w - 2) / 2) + int(w), 0), n_y - 1)
+    if hi_x <= lo_x or hi_y <= lo_y:
+        return matrix
+    dx = np.arange(lo_x, hi_x, dtype=float) - (lo_x + half)
+    dy = np.arange(lo_y, hi_y, dtype=float) - (lo_y + half)
+    inside = np.add.outer(dy * dy, dx * dx) <= (w * w) / 4.0
+    block = matrix[lo_y:hi_y, lo_x:hi_x]
+    block[inside] = 0
     return matrix
 
 

@@ -34,6 +34,22 @@ def spot_external_amp(meta, spot_amp):
     return spot_amp * (1 + 0.2 * (synth.uniform01(meta["seed"], (len(spot_amp),), 5) - 0.5))
 
 
+def spot_null_region(shape):
+    """The blanket null region of the spotnull_* fixtures (tools/make_golden.py spot_null_region)."""
+    m = np.zeros(shape, dtype=bool)
+    m[:24, :] = m[-24:, :] = m[:, :24] = m[:, -24:] = True
+    m[150:170, 40:90] = True
+    return m
+
+
+def spot_null_ctor(meta, gold):
+    """Constructor keywords (null_vectors, null_radius, null_region, null_region_radius_frac) of a spotnull fixture."""
+    kw = dict(null_vectors=np.array(gold["null_vectors"], dtype=float))
+    for k, v in meta["ctor"].items():
+        kw[k] = spot_null_region(tuple(meta["shape"])) if v == "spot_null_region" else v
+    return kw
+
+
 # ---- MultiplaneHologram fixtures (tools/make_golden.py gen_multiplane_cases) -----------------------------
 MULTIPLANE_SLM = (48, 80)
 MULTIPLANE_WEIGHTS = (1.0, 2.0, 0.5)

@@ -1,0 +1,252 @@
+"""
+GPU parity tests added in round 3 (``-m gpu``), all through the C ABI:
+
+  * WGS-Kim fixed by efficiency (``fix_phase_efficiency``, _hologram.py:1560-1569) -- device-resident loop
+    (hgs_iterate_stats takes the decision) and the stepwise path (host decision) against reference fixtures;
+  * SpotHologram with null points / a null region (_spots.py:1300-1373, 1514-1538): spot feedback through the MRAF
+    branch, engine default / dense kernels / stepwise operators;
+  * the sparse target upload (hgs_set_array_sparse) and the engine-preserving reset (hgs_reset) that make a cold
+    ``SpotHologram.optimize()`` cheap.
+
+Tolerances are relative L2 norms (phase: distance of unit phasors), fp32.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, rel_l2, phase_rel_l2, report
+from golden_cases import hologram_inputs, spot_null_ctor
+from slmsuite_amd import _lib as L
+from slmsuite_amd import synth
+from slmsuite_amd.engine import Engine
+from slmsuite_amd.holography.algorithms import Hologram, SpotHologram
+from test_gpu_parity import forced_hologram, step_pairs
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"device": dict(cb=False, opts={}), "device-dense": dict(cb=False, opts={L.OPT_SPARSE_COLUMNS: 0}),
+         "stepwise": dict(cb=True, opts={})}
+
+
+# ---- WGS-Kim fixed by efficiency -------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["device", "stepwise"])
+def test_kim_efficiency_gate_single_steps(mode):
+    """Every recorded body of the dense 64^2 run, teacher-forced: before the threshold, the body that crosses it
+    (the flag must come out raised, the phase still taken from the current farfield) and the fixed bodies after."""
+    meta, gold = load_golden("kimeff_hologram")
+    pairs = step_pairs(gold)
+    assert 4 in pairs and 5 in pairs, pairs
+    cb = (lambda hh: False) if mode == "stepwise" else None
+    for k in pairs:
+        h = forced_hologram(meta, gold, k)
+        h.optimize(meta["method"], maxiter=1, verbose=False, stat_groups=meta["stat_groups"], callback=cb, **meta["kwargs"])
+        ep = phase_rel_l2(h.phase, gold[f"phase_{k + 1}"])
+        ew = rel_l2(h.weights, gold[f"weights_{k + 1}"])
+        report(f"kimeff step {mode} k={k}", phase=ep, weights=ew)
+        assert ep < 5e-6 and ew < 3e-6, (mode, k, ep, ew)
+        assert bool(h.flags["fixed_phase"]) == bool(gold[f"fixed_{k + 1}"]), (mode, k)
+        np.testing.assert_allclose(h.stats["stats"]["computational"]["efficiency"][k],
+                                   gold["stats_computational_efficiency"][k], rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["device", "stepwise"])
+def test_kim_efficiency_gate_trajectory_hologram(mode):
+    """From the seed: the flag history the reference walked (the efficiency crosses 0.95 in iteration 4, margins of
+    1 % and 2.4 % on either side) and the statistics.  Dense pixel-wise WGS is chaotic, so the end state is loose."""
+    meta, gold = load_golden("kimeff_hologram")
+    h = Hologram(**hologram_inputs(meta))
+    cb = (lambda hh: False) if mode == "stepwise" else None
+    h.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, stat_groups=meta["stat_groups"], callback=cb,
+               **meta["kwargs"])
+    assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
+    assert bool(h.flags["fixed_phase"])
+    eff = np.array(h.stats["stats"]["computational"]["efficiency"])
+    report(f"kimeff trajectory hologram {mode}", eff=float(np.max(np.abs(eff - gold["stats_computational_efficiency"]))),
+           phase=phase_rel_l2(h.phase, gold["final_phase"]))
+    np.testing.assert_allclose(eff[:6], gold["stats_computational_efficiency"][:6], rtol=2e-3)
+    np.testing.assert_allclose(eff, gold["stats_computational_efficiency"], rtol=5e-2)
+
+
+def _kimeff_spot(meta, opts):
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    return SpotHologram.make_rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]), basis="knm",
+                                               slm_shape=slm, phase=synth.seed_phase(meta["seed"], slm),
+                                               engine_options=opts)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_kim_efficiency_gate_trajectory_spot(mode):
+    """SpotHologram, spot feedback, the spot group's efficiency decides (crosses 0.575 in iteration 4): history,
+    every recorded state and the end state, through the active-column path, the dense kernels and the stepwise
+    operators."""
+    meta, gold = load_golden("kimeff_spot")
+    h = _kimeff_spot(meta, MODES[mode]["opts"])
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    snaps = {}
+
+    def cb(hh):
+        if f"phase_{hh.iter}" in gold:
+            snaps[hh.iter] = (hh.phase.copy(), hh.weights[ky, kx].copy(), hh.amp_ff[ky, kx].copy())
+        return False
+
+    h.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, feedback=meta["feedback"],
+               stat_groups=meta["stat_groups"], callback=cb if MODES[mode]["cb"] else None, **meta["kwargs"])
+    assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
+    for k, (ph, w, a) in snaps.items():
+        assert phase_rel_l2(ph, gold[f"phase_{k}"]) < 2e-5, (mode, k)
+        assert rel_l2(w, gold[f"weights_{k}_spots"]) < 1e-5, (mode, k)
+        assert rel_l2(a, gold[f"ampff_{k}_spots"]) < 1e-5, (mode, k)
+    ep, ea = phase_rel_l2(h.phase, gold["final_phase"]), rel_l2(h.amp_ff[ky, kx], gold["final_ampff_spots"])
+    ew = rel_l2(h.weights[ky, kx], gold["final_weights_spots"])
+    report(f"kimeff trajectory spot {mode}", phase=ep, spot_amp=ea, weights=ew)
+    assert ep < 2e-5 and ea < 1e-5 and ew < 1e-5
+    for n in ("efficiency", "uniformity", "pkpk_err", "std_err"):
+        np.testing.assert_allclose(h.stats["stats"]["computational_spot"][n], gold[f"stats_computational_spot_{n}"],
+                                   rtol=2e-3, atol=2e-6)
+
+
+def test_kim_efficiency_gate_needs_statistics():
+    """Without statistics the reference raises ValueError in the first iteration with iter > 0 (:1564-1565)."""
+    meta, _ = load_golden("kimeff_hologram")
+    h = Hologram(**hologram_inputs(meta))
+    with pytest.raises(ValueError, match="Must track statistics"):
+        h.optimize("WGS-Kim", maxiter=3, verbose=False, fix_phase_efficiency=0.5)
+    # straight at the C ABI: hgs_iterate with the gate set
+    h = Hologram(**hologram_inputs(meta))
+    h._update_flags("WGS-Kim", False, None, [], fix_phase_efficiency=0.5)
+    st = h._make_step(efficiency_group=0)
+    assert st.fix_phase_efficiency == 0.5
+    with pytest.raises(ValueError, match="Must track statistics"):
+        h._get_engine().iterate(st, 3)
+    # ... and a batch of two cannot share one flag
+    e = Engine((64, 64), (64, 64), batch=2)
+    e.set(L.TARGET, h.target)
+    e.set(L.PHASE, h.phase)
+    e.reset_weights()
+    with pytest.raises(NotImplementedError):
+        e.iterate_stats(st, 3, ["computational"])
+    e.close()
+
+
+# ---- SpotHologram with null points / null region -------------------------------------------------------------
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("name", golden_names("spotnull_"))
+def test_spot_hologram_null_targets_match_reference(name, mode):
+    """NaN background + zero disks + spot (or pixel) feedback: recorded states of 6 bodies, statistics, end state."""
+    meta, gold = load_golden(name)
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    h = SpotHologram.make_rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]), basis="knm",
+                                            slm_shape=slm, phase=synth.seed_phase(meta["seed"], slm),
+                                            engine_options=MODES[mode]["opts"], **spot_null_ctor(meta, gold))
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    snaps = {}
+
+    def cb(hh):
+        if f"phase_{hh.iter}" in gold:
+            snaps[hh.iter] = (hh.phase.copy(), hh.weights[ky, kx].copy(), hh.amp_ff[ky, kx].copy())
+        return False
+
+    h.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, feedback=meta["feedback"],
+               stat_groups=meta["stat_groups"], callback=cb if MODES[mode]["cb"] else None, **meta["kwargs"])
+    worst = dict(phase=0.0, weights=0.0, amp=0.0)
+    for k, (ph, w, a) in snaps.items():
+        worst["phase"] = max(worst["phase"], phase_rel_l2(ph, gold[f"phase_{k}"]))
+        worst["weights"] = max(worst["weights"], rel_l2(w, gold[f"weights_{k}_spots"]))
+        worst["amp"] = max(worst["amp"], rel_l2(a, gold[f"ampff_{k}_spots"]))
+    ep, ea = phase_rel_l2(h.phase, gold["final_phase"]), rel_l2(h.amp_ff[ky, kx], gold["final_ampff_spots"])
+    ew = rel_l2(h.weights[ky, kx], gold["final_weights_spots"])
+    es = rel_l2(h.amp_ff[::4, ::4], gold["final_ampff_sub"])
+    report(f"spotnull {name} {mode}", phase=ep, spot_amp=ea, weights=ew, field=es, snap_phase=worst["phase"],
+           snap_weights=worst["weights"], snap_amp=worst["amp"])
+    assert worst["phase"] < 2e-5 and worst["weights"] < 1e-5 and worst["amp"] < 1e-5, worst
+    assert ep < 2e-5 and ea < 1e-5 and ew < 1e-5 and es < 5e-5, (ep, ea, ew, es)
+    assert abs(float(np.sum(h.weights.astype(float))) - float(gold["final_weights_sum"])) < 1e-3
+    assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
+    for grp in meta["stat_groups"]:
+        for n in ("efficiency", "uniformity", "pkpk_err", "std_err"):
+            np.testing.assert_allclose(h.stats["stats"][grp][n], gold[f"stats_{grp}_{n}"], rtol=2e-3, atol=2e-6)
+
+
+# ---- sparse target upload / engine-preserving reset -----------------------------------------------------------
+@pytest.mark.parametrize("shape,slm", [((512, 512), (144, 240)), ((4096, 4096), (1152, 1920)), ((100, 150), (48, 80))])
+def test_sparse_target_upload_is_the_dense_upload(shape, slm):
+    """hgs_set_array_sparse(HGS_TARGET) + hgs_reset_weights leave exactly the arrays the dense uploads leave --
+    fused layout (lane-major columns) and the general-shape layout; repeated pixels: the last value wins."""
+    rng = np.random.default_rng(5)
+    n = 40
+    xy = np.vstack((rng.integers(0, shape[1], n), rng.integers(0, shape[0], n))).astype(np.int32)
+    xy[:, -1] = xy[:, 3]                                   # a repeated pixel
+    vals = rng.uniform(0.1, 1.0, n).astype(np.float32)
+    dense = np.zeros(shape, np.float32)
+    dense[xy[1], xy[0]] = vals
+    e = Engine(shape, slm, n_spots=n)
+    e.set_sparse(L.TARGET, xy, vals)
+    np.testing.assert_array_equal(e.get(L.TARGET)[0], dense)
+    e.reset_weights()
+    np.testing.assert_array_equal(e.get(L.WEIGHTS)[0], dense)
+    e.set_sparse(L.WEIGHTS, xy[:, :5], vals[:5])
+    d2 = np.zeros(shape, np.float32)
+    d2[xy[1, :5], xy[0, :5]] = vals[:5]
+    np.testing.assert_array_equal(e.get(L.WEIGHTS)[0], d2)
+    with pytest.raises(ValueError):
+        e.set_sparse(L.TARGET, np.array([[shape[1]], [0]]), np.array([1.0]))
+    with pytest.raises(ValueError):
+        e.set_sparse(L.PHASE_FF, xy, vals)
+    e.close()
+
+
+def test_spot_hologram_cold_optimize_uses_sparse_upload_and_matches_dense_upload():
+    """A SpotHologram whose target went up as a spot list ends where one with a dense upload ends (bit for bit)."""
+    shape, slm = (1024, 1024), (288, 480)
+    mk = lambda: SpotHologram.make_rectangular_array(shape, (10, 10), (40, 40), basis="knm", slm_shape=slm,   # noqa: E731
+                                                     phase=synth.seed_phase(21, slm))
+    a, b = mk(), mk()
+    b._upload_target = lambda e: e.set(L.TARGET, b.target)         # the dense route
+    b.weights = b.weights.copy()                                   # ... and explicit weights instead of the device reset
+    for h in (a, b):
+        h.optimize("WGS-Kim", maxiter=14, verbose=False, fix_phase_iteration=5)
+    np.testing.assert_array_equal(a.phase, b.phase)
+    np.testing.assert_array_equal(a.weights, b.weights)
+    np.testing.assert_array_equal(a.amp_ff, b.amp_ff)
+
+
+def test_reset_keeps_the_engine_and_forgets_the_device_state():
+    """Hologram.reset() (:442-478): same engine handle afterwards, phase_ff / amp_ff gone, weights = target, the phase
+    kept on the device when reset_phase is False -- and the next run equals that of a fresh hologram."""
+    shape, slm = (512, 512), (144, 240)
+    p0 = synth.seed_phase(31, slm)
+    h = SpotHologram.make_rectangular_array(shape, (6, 6), (48, 48), basis="knm", slm_shape=slm, phase=p0.copy())
+    h.optimize("WGS-Kim", maxiter=8, verbose=False, fix_phase_iteration=3)
+    assert h.flags["fixed_phase"]
+    eng = h._engine
+    ph8 = h.phase.copy()
+    h.reset(reset_phase=False, reset_flags=True)
+    assert h._engine is eng and h.iter == 0 and h.amp_ff is None and h.phase_ff is None
+    np.testing.assert_array_equal(h.phase, ph8)
+    np.testing.assert_array_equal(h.weights, np.nan_to_num(h.target, nan=0))
+    with pytest.raises(L.HgsError):
+        eng.get(L.PHASE_FF)
+    h.optimize("WGS-Kim", maxiter=6, verbose=False, fix_phase_iteration=3)
+    f = SpotHologram.make_rectangular_array(shape, (6, 6), (48, 48), basis="knm", slm_shape=slm, phase=ph8.copy())
+    f.optimize("WGS-Kim", maxiter=6, verbose=False, fix_phase_iteration=3)
+    np.testing.assert_array_equal(h.phase, f.phase)
+    np.testing.assert_array_equal(h.weights, f.weights)
+    assert h.stats["flags"]["fixed_phase"] == f.stats["flags"]["fixed_phase"]
+    # reset with a new phase
+    h.reset_phase(p0)
+    h.reset(reset_phase=False)
+    assert h._engine is eng
+    h.optimize("WGS-Leonardo", maxiter=3, verbose=False)
+    g = SpotHologram.make_rectangular_array(shape, (6, 6), (48, 48), basis="knm", slm_shape=slm, phase=p0.copy())
+    g.optimize("WGS-Leonardo", maxiter=3, verbose=False)
+    np.testing.assert_array_equal(h.phase, g.phase)
+
+
+def test_engine_calls_leave_the_callers_device_alone():
+    """The C ABI makes the engine's device current per call and puts the caller's back (one GPU here: just no change)."""
+    import torch
+    before = torch.cuda.current_device()
+    e = Engine((256, 256), (64, 64))
+    e.set(L.PHASE, synth.seed_phase(1, (64, 64)))
+    e.nearfield2farfield()
+    assert torch.cuda.current_device() == before
+    e.close()

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, golden_names, load_golden
-from golden_cases import hologram_inputs
+from golden_cases import hologram_inputs, spot_null_ctor
 from slmsuite_amd import _lib as L
 from slmsuite_amd import synth
 from slmsuite_amd.engine import make_step
@@ -112,6 +112,29 @@ def test_spot_hologram_host_state_matches_reference():
         SpotHologram((64, 64), [[70], [10]], basis="knm", slm_shape=(64, 64))
 
 
+@pytest.mark.parametrize("name", golden_names("spotnull_"))
+def test_spot_hologram_null_target_matches_reference(name):
+    """null_vectors / null_radius / null_region / null_region_radius_frac (_spots.py:1300-1373, 1514-1538): the target
+    raster the reference built -- NaN background, zero region, zero disks (edge rule included), spots -- bit for bit."""
+    meta, gold = load_golden(name)
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    h = SpotHologram.make_rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]),
+                                            basis="knm", slm_shape=slm, phase=synth.seed_phase(meta["seed"], slm),
+                                            **spot_null_ctor(meta, gold))
+    assert h.null_radius_knm == int(gold["null_radius_knm"])
+    np.testing.assert_array_equal(np.isnan(h.target), np.isnan(gold["target"]))
+    np.testing.assert_array_equal(np.nan_to_num(h.target, nan=-1), np.nan_to_num(gold["target"], nan=-1))
+    assert h._mraf_enabled()
+    np.testing.assert_array_equal(h.weights, np.nan_to_num(gold["target"], nan=0))
+
+
+def test_spot_hologram_null_region_alone_is_ignored():
+    """Without null points the reference never consults the null region (_spots.py:1514-1515): plain zero background."""
+    region = np.ones((64, 64), dtype=bool)
+    h = SpotHologram((64, 64), [[20, 40], [30, 30]], basis="knm", slm_shape=(64, 64), null_region=region)
+    assert not np.isnan(h.target).any() and np.count_nonzero(h.target) == 2
+
+
 def test_flag_parsing_and_errors():
     h = Hologram(synth.random_target(1, (64, 64)), phase=synth.seed_phase(1, (64, 64)), my_flag=3)
     with pytest.raises(ValueError):
@@ -194,11 +217,12 @@ def test_quadratic_initial_phase_matches_reference():
 
 
 class _StubEngine:
-    """Stands in for the HIP engine in host-logic tests: holds arrays, counts closes."""
+    """Stands in for the HIP engine in host-logic tests: holds arrays, counts resets and closes."""
 
     def __init__(self, arrays):
         self.arrays = dict(arrays)
         self.closed = False
+        self.resets = 0
 
     def get(self, which):
         return [self.arrays[which].copy()]
@@ -209,6 +233,9 @@ class _StubEngine:
     def reset_weights(self):
         pass
 
+    def reset(self):
+        self.resets += 1
+
     def close(self):
         self.closed = True
 
@@ -216,20 +243,54 @@ class _StubEngine:
 def test_reset_keeps_the_optimised_phase():
     """
     Hologram.reset(reset_phase=False) keeps the CURRENT phase (_hologram.py:442-478).  After optimize() the
-    current phase lives on the device only; it must come home before the engine is destroyed.
+    current phase lives on the device only; the engine survives the reset (hgs_reset) and keeps serving it.
+    A released engine (MultiplaneHologram takes its children's) brings every device-fresh array home first.
     """
     h = Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
-    stub = _StubEngine({L.PHASE: np.full((64, 64), 7.0, np.float32), L.WEIGHTS: h.weights.copy()})
+    stub = _StubEngine({L.PHASE: np.full((64, 64), 7.0, np.float32), L.WEIGHTS: h.weights.copy(),
+                        L.AMP_FF: np.full((64, 64), 3.0, np.float32)})
     h._engine = stub
     h._mark_device_fresh(["phase", "weights"])          # what optimize_gs leaves behind
     h.reset(reset_phase=False)
-    assert stub.closed and h._engine is None
-    assert np.all(h.phase == 7.0)
+    assert h._engine is stub and stub.resets == 1 and not stub.closed
+    assert np.all(h.phase == 7.0) and h.amp_ff is None and h.phase_ff is None and h.iter == 0
+    np.testing.assert_array_equal(h.weights, np.nan_to_num(h.target, nan=0))
     # reset_phase=True replaces it
-    h._engine = stub2 = _StubEngine({L.PHASE: np.full((64, 64), 9.0, np.float32), L.WEIGHTS: h.weights.copy()})
+    stub.arrays[L.PHASE][:] = 9.0
     h._mark_device_fresh(["phase"])
     h.reset(reset_phase=True)
-    assert stub2.closed and not np.any(h.phase == 9.0)
+    assert h._engine is stub and not np.any(h.phase == 9.0) and "phase" in h._upload
+    # releasing the engine: phase, weights AND amp_ff come home; what the engine cannot serve becomes None
+    h._mark_device_fresh(["phase", "amp_ff", "phase_ff"])
+    stub.arrays[L.PHASE][:] = 5.0
+
+    def get(which, _get=stub.get):
+        if which == L.PHASE_FF:
+            raise L.HgsError("phase_ff has not been computed")
+        return _get(which)
+
+    stub.get = get
+    h._release_engine()
+    assert stub.closed and h._engine is None
+    assert np.all(h.phase == 5.0) and np.all(h.amp_ff == 3.0) and h.phase_ff is None
+
+
+def test_reset_weights_are_lazy_but_follow_the_reference():
+    """reset_weights (:603-614): weights = target with NaN -> 0.  The host copy is only built when read; a later
+    set_target(reset_weights=False) must not change what the weights were."""
+    t = synth.random_target(2, (32, 32))
+    t[3, 4] = np.nan
+    h = Hologram(t.copy(), phase=np.zeros((32, 32), np.float32))
+    assert h._host["weights"] is None and h._weights_reset
+    w0 = h.weights
+    np.testing.assert_array_equal(w0, np.nan_to_num(h.target, nan=0))
+    h.reset_weights()
+    h.set_target(synth.random_target(3, (32, 32)), reset_weights=False)
+    np.testing.assert_array_equal(h.weights, w0)                     # still those of the OLD target
+    h.set_target(synth.random_target(4, (32, 32)), reset_weights=True)
+    np.testing.assert_array_equal(h.weights, h.target)
+    h.set_weights(w0)
+    assert not h._weights_reset and "weights" in h._upload
 
 
 def test_batch_targets_are_normalised_like_set_target():
@@ -284,8 +345,12 @@ def test_asan_build_of_the_shim_is_clean():
     import subprocess
     import sys
     asan_lib = os.path.join(ROOT, "slmsuite_amd", "libhgs_asan.so")
-    if not os.path.exists(asan_lib):
-        pytest.skip("libhgs_asan.so not built")
+    if not os.path.exists(os.path.join(ROOT, "slmsuite_amd", "libhgs.so")):
+        pytest.skip("libhgs.so not built")
+    # made on demand (a file target: nothing happens when it is up to date; one -O1 compile of engine.hip otherwise)
+    mk = subprocess.run(["make", "-C", os.path.join(ROOT, "slmsuite_amd", "csrc"), "asan"], capture_output=True, text=True)
+    if mk.returncode != 0 or not os.path.exists(asan_lib):
+        pytest.skip("ASan build of the shim failed: " + mk.stderr[-300:])
     rt = subprocess.run(["hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
     if not os.path.isabs(rt) or not os.path.exists(rt):
         pytest.skip("ASan runtime not found")

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden, rel_l2, phase_rel_l2
-from golden_cases import hologram_inputs, spot_external_amp
+from golden_cases import hologram_inputs, spot_external_amp, spot_null_ctor
 from oracle import hgs_oracle as orc
 
 
@@ -98,6 +98,68 @@ def test_oracle_matches_reference_spot(name):
         for n in ("efficiency", "uniformity", "pkpk_err", "std_err"):
             np.testing.assert_allclose(h.stats["stats"][grp][n], gold[f"stats_{grp}_{n}"],
                                        rtol=2e-3, atol=1e-6)
+
+
+def check_spot_traj(meta, gold, h, snaps, tol):
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    for k, v in gold.items():
+        if k.startswith("phase_") and k.split("_")[1].isdigit():
+            assert phase_rel_l2(snaps[int(k.split("_")[1])]["phase"], v) < tol, k
+        if k.startswith("weights_") and k.endswith("_spots"):
+            assert rel_l2(snaps[int(k.split("_")[1])]["weights"][ky, kx], v) < tol, k
+        if k.startswith("ampff_") and k.endswith("_spots"):
+            assert rel_l2(snaps[int(k.split("_")[1])]["amp_ff"][ky, kx], v) < tol, k
+        if k.startswith("fixed_") and k.split("_")[1].isdigit():
+            assert snaps[int(k.split("_")[1])]["fixed"] == bool(v), k
+    assert phase_rel_l2(h.phase, gold["final_phase"]) < tol
+    assert rel_l2(h.amp_ff[::4, ::4], gold["final_ampff_sub"]) < tol
+    assert rel_l2(h.weights[ky, kx], gold["final_weights_spots"]) < tol
+    assert abs(float(np.sum(h.weights.astype(float))) - float(gold["final_weights_sum"])) < 1e-3
+    assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
+    for grp in meta["stat_groups"]:
+        for n in ("efficiency", "uniformity", "pkpk_err", "std_err"):
+            np.testing.assert_allclose(h.stats["stats"][grp][n], gold[f"stats_{grp}_{n}"], rtol=2e-3, atol=1e-6)
+
+
+def test_oracle_kim_fixed_by_efficiency_hologram():
+    """fix_phase_efficiency (_hologram.py:1560-1569), dense Hologram: the history, every recorded state and the
+    statistics that drive the decision."""
+    meta, gold = load_golden("kimeff_hologram")
+    h = orc.OracleHologram(**hologram_inputs(meta))
+    snaps = run_with_snapshots(h, meta["method"], meta["maxiter"], stat_groups=meta["stat_groups"], **meta["kwargs"])
+    assert [bool(x) for x in gold["fixed_history"]] == [False] * 5 + [True] * 4
+    check_traj(meta, gold, h, snaps, 2e-5)
+
+
+def test_oracle_kim_fixed_by_efficiency_spot():
+    """Same gate on a SpotHologram deciding on the spot group's efficiency (crosses 0.575 at iteration 4)."""
+    from slmsuite_amd import synth
+    meta, gold = load_golden("kimeff_spot")
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    vec = orc.rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]))
+    h = orc.OracleSpotHologram(shape, vec, slm_shape=slm, phase=synth.seed_phase(meta["seed"], slm))
+    snaps = run_with_snapshots(h, meta["method"], meta["maxiter"], feedback=meta["feedback"],
+                               stat_groups=meta["stat_groups"], **meta["kwargs"])
+    assert [bool(x) for x in gold["fixed_history"]] == [False] * 5 + [True] * 4
+    check_spot_traj(meta, gold, h, snaps, 2e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("spotnull_"))
+def test_oracle_matches_reference_spot_null(name):
+    """SpotHologram(null_vectors, null_radius, null_region, null_region_radius_frac): target raster (NaN background,
+    zero disks incl. the edge-clipping rule) bit-identical, then spot feedback through the MRAF branch."""
+    from slmsuite_amd import synth
+    meta, gold = load_golden(name)
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    vec = orc.rectangular_array(shape, tuple(meta["array_shape"]), tuple(meta["array_pitch"]))
+    h = orc.OracleSpotHologram(shape, vec, slm_shape=slm, phase=synth.seed_phase(meta["seed"], slm),
+                               **spot_null_ctor(meta, gold))
+    assert h.null_radius_knm == int(gold["null_radius_knm"])
+    np.testing.assert_array_equal(np.isnan(h.target), np.isnan(gold["target"]))
+    np.testing.assert_array_equal(np.nan_to_num(h.target, nan=-1), np.nan_to_num(gold["target"], nan=-1))
+    snaps = run_with_snapshots(h, meta["method"], meta["maxiter"], feedback=meta["feedback"],
+                               stat_groups=meta["stat_groups"], **meta["kwargs"])
+    check_spot_traj(meta, gold, h, snaps, 2e-5)
 
 
 def test_helpers_match_reference():

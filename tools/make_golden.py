@@ -232,6 +232,105 @@ def gen_spot_cases(alg):
             save(f"spot_{method.replace('-', '')}_{fb}", meta, rec)
 
 
+def _spot_record_slim(h, rec):
+    """Spot fixtures keep P-sized per-iteration arrays only at the spots (+ a strided amp_ff sample of the end state)."""
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    rec["spot_knm"] = np.array(h.spot_knm)
+    rec["spot_knm_rounded"] = np.array(h.spot_knm_rounded)
+    rec["spot_amp"] = np.array(h.spot_amp)
+    rec["final_ampff_sub"] = rec["final_ampff"][::4, ::4].copy()
+    rec["final_ampff_spots"] = rec["final_ampff"][ky, kx]
+    rec["final_weights_spots"] = rec["final_weights"][ky, kx]
+    rec["final_weights_sum"] = np.array(float(np.sum(rec["final_weights"].astype(float))))
+    del rec["final_ampff"], rec["final_weights"]
+    for k in list(rec.keys()):
+        if k.startswith("phaseff_"):
+            del rec[k]
+        elif k.startswith(("weights_", "ampff_")):
+            rec[k + "_spots"] = rec[k][ky, kx]
+            del rec[k]
+    return rec
+
+
+def gen_kimeff_cases(alg):
+    """
+    WGS-Kim fixed by efficiency (_hologram.py:1560-1569): the phase is frozen at the first iteration whose recorded
+    efficiency -- of the LAST statistics group -- exceeds fix_phase_efficiency.  Two cases: a dense 64^2 Hologram with
+    the iteration rule out of reach (fix_phase_iteration = 100, threshold crossed at iteration 4), and the 256^2
+    SpotHologram with the spot group (threshold 0.575 between its iterations 3 and 4; the pixel group never exceeds
+    0.13) and the iteration rule left at its default.  Only ONE group is requested: with two, "last" is the iteration
+    order of a Python set of strings (_stats.py:162-171), which changes with PYTHONHASHSEED from process to process.
+    """
+    seed = 150
+    shape = slm = (64, 64)
+    h = alg.Hologram(synth.random_target(seed, shape), phase=synth.seed_phase(seed, slm), slm_shape=slm)
+    kw = dict(fix_phase_efficiency=0.95, fix_phase_iteration=100)
+    rec = record_run(h, "WGS-Kim", 9, save_iters=(0, 1, 2, 3, 4, 5, 6, 8), stat_groups=["computational"], **kw)
+    meta = dict(kind="kimeff_hologram", method="WGS-Kim", seed=seed, shape=shape, slm_shape=slm, dtype="float32",
+                maxiter=9, kwargs=kw, stat_groups=["computational"])
+    save("kimeff_hologram", meta, rec)
+
+    seed = 401
+    shape, slm = (256, 256), (72, 120)
+    h = alg.SpotHologram.make_rectangular_array(shape, array_shape=(8, 8), array_pitch=(16, 16), basis="knm",
+                                                slm_shape=slm, phase=synth.seed_phase(seed, slm))
+    kw = dict(fix_phase_efficiency=0.575)
+    sg = ["computational_spot"]
+    rec = record_run(h, "WGS-Kim", 9, save_iters=(0, 1, 2, 3, 4, 5, 6, 8), feedback="computational_spot",
+                     stat_groups=sg, **kw)
+    rec = _spot_record_slim(h, rec)
+    meta = dict(kind="kimeff_spot", method="WGS-Kim", feedback="computational_spot", seed=seed, shape=shape,
+                slm_shape=slm, dtype="float32", maxiter=9, kwargs=kw, array_shape=(8, 8), array_pitch=(16, 16),
+                width=int(h.spot_integration_width_knm), stat_groups=sg)
+    save("kimeff_spot", meta, rec)
+
+
+SPOT_NULL_VECTORS = ((40.0, 100.4, 200.0, 128.0), (60.0, 180.6, 90.0, 128.0))
+# two more null points whose disks cross the array edge: window_slice clips the bounding box first and centres the
+# disk on the CLIPPED box (toolbox/__init__.py:503-528), so these pin that behaviour
+SPOT_NULL_VECTORS_EDGE = ((40.0, 100.4, 200.0, 128.0, 1.0, 254.0), (60.0, 180.6, 90.0, 128.0, 128.0, 254.0))
+
+
+def spot_null_region(shape):
+    """The blanket null region of the spot_null fixtures: a 24-pixel frame plus one off-centre block."""
+    m = np.zeros(shape, dtype=bool)
+    m[:24, :] = m[-24:, :] = m[:, :24] = m[:, -24:] = True
+    m[150:170, 40:90] = True
+    return m
+
+
+def gen_spot_null_cases(alg):
+    """
+    SpotHologram with null points / a null region (_spots.py:1300-1373, 1514-1538): the background of the target is
+    NaN (amplitude freedom), the null region and a disk around every null point AND every spot are zero.  Spot
+    feedback then meets the MRAF branch of the farfield routines.  Variants: an explicit null_radius with a region;
+    the automatic radius (smallest distance / 4) with null_region_radius_frac and a noise attenuation.
+    """
+    shape, slm = (256, 256), (72, 120)
+    seed = 410
+    for tag, ctor, fb, method, kw in (
+        ("radius", dict(null_radius=3, null_region=spot_null_region(shape)), "computational_spot", "WGS-Leonardo", {}),
+        ("auto", dict(null_region_radius_frac=0.8), "computational", "WGS-Leonardo", {"mraf_factor": 0.5}),
+        ("kim", dict(null_radius=2.5), "computational_spot", "WGS-Kim", {"fix_phase_iteration": 3}),
+    ):
+        nulls = np.array(SPOT_NULL_VECTORS_EDGE if tag == "kim" else SPOT_NULL_VECTORS)
+        h = alg.SpotHologram.make_rectangular_array(
+            shape, array_shape=(6, 6), array_pitch=(20, 20), basis="knm", slm_shape=slm,
+            phase=synth.seed_phase(seed, slm), null_vectors=nulls, **ctor)
+        sg = ["computational", "computational_spot"]
+        target0 = np.array(h.target)
+        rec = record_run(h, method, 6, save_iters=(0, 1, 2, 3, 4, 5), feedback=fb, stat_groups=sg, **kw)
+        rec = _spot_record_slim(h, rec)
+        rec["target"] = target0
+        rec["null_radius_knm"] = np.array(h.null_radius_knm)
+        rec["null_vectors"] = nulls
+        meta = dict(kind="spot_null", variant=tag, method=method, feedback=fb, seed=seed, shape=shape, slm_shape=slm,
+                    dtype="float32", maxiter=6, kwargs=kw, array_shape=(6, 6), array_pitch=(20, 20),
+                    width=int(h.spot_integration_width_knm), stat_groups=sg,
+                    ctor={k: (v if not isinstance(v, np.ndarray) else "spot_null_region") for k, v in ctor.items()})
+        save(f"spotnull_{tag}", meta, rec)
+
+
 def gen_multiplane_cases(alg):
     """MultiplaneHologram (_multiplane.py): three children of different pad shapes on one 48x80 SLM."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -544,6 +643,8 @@ def main():
         "multiplane": lambda: gen_multiplane_cases(alg),
         "fourier": lambda: gen_fourier_cases(alg),
         "misc": lambda: gen_misc_cases(alg),
+        "kimeff": lambda: gen_kimeff_cases(alg),
+        "spotnull": lambda: gen_spot_null_cases(alg),
     }
     if args.cfg2:
         steps["cfg2"] = lambda: gen_cfg2(alg)
