@@ -42,6 +42,28 @@ class HgsError(RuntimeError):
     pass
 
 
+def _torch_runtime_first():
+    """
+    PyTorch-ROCm wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so) next to the system one
+    libhgs.so links (libamdhip64.so.7).  Both can live in one process -- the batch driver hands torch tensors to
+    hgs_get_array_device -- but only when torch's copy has opened the GPU FIRST: after the system runtime did,
+    ``torch.cuda`` reports "No HIP GPUs are available" (measured on the MI355X box, round 3).  So when torch is
+    installed its runtime is brought up before libhgs.so is loaded (HGS_SKIP_TORCH_INIT=1 skips this).
+    """
+    if os.environ.get("HGS_SKIP_TORCH_INIT") == "1":
+        return
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is None:
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:       # torch present but unusable: the engine does not need it
+        pass
+
+
 def load():
     """Load libhgs.so once and declare prototypes.  Raises if it has not been built."""
     global _lib
@@ -52,6 +74,7 @@ def load():
             f"{LIB_PATH} not found: build the HIP engine first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C slmsuite_amd/csrc). "
             "slmsuite_amd has no CPU fallback.")
+    _torch_runtime_first()
     lib = C.CDLL(LIB_PATH)
     P = C.POINTER
     eng = C.c_void_p

@@ -303,8 +303,10 @@ template <typename R> struct Engine : EngineBase {
         cap = cap / B > 0 ? cap / B : 1;
         int per = (row_units + cap - 1) / cap;
         row_blocks = (row_units + per - 1) / per;
-        row_xcd = (fpw == 1 && row_blocks >= 32 && env_int("HGS_ROW_XCD", 1)) ? 1 : 0;
-        if (row_xcd) row_blocks = (row_blocks + 31) / 32 * 32;
+        // XCD-aware row mapping (row_kernel): the 4 / fpw workgroups of a 128-byte line group on one XCD together
+        const int grp = fpw <= 4 ? 4 / fpw : 1;
+        row_xcd = (grp > 1 && row_blocks >= 8 * grp && env_int("HGS_ROW_XCD", 1)) ? 1 : 0;
+        if (row_xcd) row_blocks = (row_blocks + 8 * grp - 1) / (8 * grp) * (8 * grp);
         const int tiles = g.Pw / 4;
         cap = env_int("HGS_COL_BLOCKS", n_cu * 3);
         cap = cap / B > 0 ? cap / B : 1;
@@ -1074,6 +1076,7 @@ template <typename R> struct Engine : EngineBase {
         a.amp_scalar = (R)amp_scalar; a.gh = gh; a.tw = tw_row; a.scale = (R)(1.0 / std::sqrt((double)g.Pw));
         a.wpartial = finalize ? wpartial : nullptr; a.n_wpartial = wpartial_n; a.wscale = wscale;
         a.xcd_map = row_xcd;
+        a.n_row_blocks = row_blocks;
         return a;
     }
     // load / store: 0 = every column, 1 = active columns, 2 = active columns dilated by the spot windows

@@ -216,6 +216,23 @@ __device__ __forceinline__ void dft4_lead(V& v0, V& v1, V& v2, V& v3) {
     }
 }
 
+// 4-point DFT of which only the first K outputs are wanted (the others are left undefined): K = 4 is dft4
+template <int DIR, int K, typename V>
+__device__ __forceinline__ void dft4_trail(V& v0, V& v1, V& v2, V& v3) {
+    static_assert(K >= 0 && K <= 4, "dft4_trail");
+    if constexpr (K == 4) {
+        dft4<DIR>(v0, v1, v2, v3);
+    } else if constexpr (K >= 1) {
+        const V a0 = v0 + v2, a2 = v1 + v3;
+        if constexpr (K >= 2) {
+            const V a1 = v0 - v2, d = v1 - v3;
+            v1 = cadd_rot4<DIR>(a1, d);
+        }
+        v0 = a0 + a2;
+        if constexpr (K == 3) v2 = a0 - a2;
+    }
+}
+
 // R-point DFT, v[r] natural order in, V[p] natural order out (in place).
 template <int RADIX, int DIR, typename R> struct Dft;
 
@@ -244,7 +261,9 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
     // TW: the stage twiddle W^(r k) = W^(r1 k) * W^(4 r2 k) is split (fewer twiddle registers):
     // the caller pre-multiplies v[r1+4r2] by W^(4 r2 k); the common factor W^(r1 k) = bt[r1-1]
     // of each inner 4-point transform is applied here to its outputs.
-    template <bool TW>
+    // NOUT: only the outputs V[0 .. NOUT-1] are wanted (the rows / columns outside the SLM are dropped after an
+    // inverse transform): the last radix-4 layer shrinks to them (NOUT = 6: 18 packed operations instead of 32).
+    template <bool TW, int NOUT = 16>
     static __device__ __forceinline__ void run_tw(Cx<R> (&v)[16], Cx<R> bt1, Cx<R> bt2, Cx<R> bt3) {
         // step 1: DFT4 over r2 for each r1 -> t[r1][p2] stored at v[r1 + 4*p2]
         dft4<DIR>(v[0], v[4], v[8], v[12]);
@@ -261,10 +280,12 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
         v[9] = rot16<2, DIR>(v[9]);   v[10] = rot16<4, DIR>(v[10]); v[11] = rot16<6, DIR>(v[11]);
         v[13] = rot16<3, DIR>(v[13]); v[14] = rot16<6, DIR>(v[14]); v[15] = rot16<9, DIR>(v[15]);
         // step 3: DFT4 over r1 for each p2 -> V[4*p1 + p2]; inputs at v[r1 + 4*p2]
-        dft4<DIR>(v[0], v[1], v[2], v[3]);      // p2 = 0 -> V[0], V[4], V[8], V[12]
-        dft4<DIR>(v[4], v[5], v[6], v[7]);      // p2 = 1 -> V[1], V[5], V[9], V[13]
-        dft4<DIR>(v[8], v[9], v[10], v[11]);    // p2 = 2
-        dft4<DIR>(v[12], v[13], v[14], v[15]);  // p2 = 3
+        // (of output group p2 the first ceil((NOUT - p2) / 4) are wanted)
+        constexpr auto want = [](int p2) { const int k = (NOUT - p2 + 3) / 4; return k < 0 ? 0 : (k > 4 ? 4 : k); };
+        dft4_trail<DIR, want(0)>(v[0], v[1], v[2], v[3]);      // p2 = 0 -> V[0], V[4], V[8], V[12]
+        dft4_trail<DIR, want(1)>(v[4], v[5], v[6], v[7]);      // p2 = 1 -> V[1], V[5], V[9], V[13]
+        dft4_trail<DIR, want(2)>(v[8], v[9], v[10], v[11]);    // p2 = 2
+        dft4_trail<DIR, want(3)>(v[12], v[13], v[14], v[15]);  // p2 = 3
         // now v[p1 + 4*p2] holds V[4*p1 + p2]: transpose the 4x4 index to natural order
         Cx<R> t;
         t = v[1]; v[1] = v[4]; v[4] = t;
@@ -277,6 +298,11 @@ template <int DIR, typename R> struct Dft<16, DIR, R> {
     static __device__ __forceinline__ void run(Cx<R> (&v)[16]) {
         const Cx<R> z = mk<R>(0, 0);
         run_tw<false>(v, z, z, z);
+    }
+    // only the outputs V[0 .. NOUT-1] are wanted
+    template <int NOUT> static __device__ __forceinline__ void run_trail(Cx<R> (&v)[16]) {
+        const Cx<R> z = mk<R>(0, 0);
+        run_tw<false, NOUT>(v, z, z, z);
     }
     // The same transform when only the first NZ inputs are non-zero (zero-padded fields: the rows outside the SLM):
     // the first radix-4 layer shrinks to the non-zero inputs (NZ = 6: 8 packed operations instead of 32).
@@ -452,7 +478,7 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
     // the barrier of the exchange on image B, which every lane reaches after finishing its reads of
     // A).  `par` is the running exchange parity of this workgroup; LDS need is 2 * lds_elems<N>().
     int par = 0;
-    template <int DIR, int s, bool DB = false> __device__ __forceinline__ void stage(Cx<R> (&v)[16], Cx<R>* lds0, int j) {
+    template <int DIR, int s, bool DB = false, int NOUT = 16> __device__ __forceinline__ void stage(Cx<R> (&v)[16], Cx<R>* lds0, int j) {
         Cx<R>* lds = lds0;
         if constexpr (DB && s != Sched<N>::S - 1) {
             lds = lds0 + (par ? lds_elems<N>() : 0);
@@ -471,9 +497,11 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
                     constexpr int r2 = r2_;
                     cmul4<DIR>(u[4 * r2], u[4 * r2 + 1], u[4 * r2 + 2], u[4 * r2 + 3], this->template twv<s, r2 - 1>(j));
                 });
+                // (the last stage leaves output p of the butterfly in register p: a caller that keeps only the first
+                //  NOUT registers prunes the butterfly's last layer)
                 if (!HGS_ABL_BFLY)
-                    Dft<16, DIR, R>::template run_tw<true>(u, this->template twv<s, 3>(j), this->template twv<s, 4>(j),
-                                                           this->template twv<s, 5>(j));
+                    Dft<16, DIR, R>::template run_tw<true, (s == Sched<N>::S - 1 ? NOUT : 16)>(
+                        u, this->template twv<s, 3>(j), this->template twv<s, 4>(j), this->template twv<s, 5>(j));
             } else {
                 if constexpr (s > 0) {
                     static_for<1, RAD>([&](auto r_) {
@@ -519,10 +547,10 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
         }
     }
 
-    template <int DIR, bool DB = false> __device__ __forceinline__ void run(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+    template <int DIR, bool DB = false, int NOUT = 16> __device__ __forceinline__ void run(Cx<R> (&v)[16], Cx<R>* lds, int j) {
         static_for<0, Sched<N>::S>([&](auto s_) {
             constexpr int s = s_;
-            this->template stage<DIR, s, DB>(v, lds, j);
+            this->template stage<DIR, s, DB, NOUT>(v, lds, j);
         });
     }
     // uniform entry points (see WgFftL for why the inverse comes in two flavours)
@@ -531,6 +559,10 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
     template <int NZ> __device__ __forceinline__ void fwd_lead(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<-1>(v, lds, j); }
     __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<+1>(v, lds, j); }
     __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { run<+1>(v, lds, j); }
+    // only registers 0 .. NOUT-1 of the result are kept (pruned where the last stage is a radix-16 one)
+    template <int NOUT> __device__ __forceinline__ void inv_after_fwd_trail(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+        run<+1, false, (Sched<N>::r[Sched<N>::S - 1] == 16 ? NOUT : 16)>(v, lds, j);
+    }
 };
 
 // ---- the 4096-point transform with a row-local first exchange ----------------------------------------
@@ -639,7 +671,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
         HGS_T(tr_n, 15);
     }
     // the mirror: frequency layout in, space layout out
-    template <int DIR, bool LEAD> __device__ __forceinline__ void mirror_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
+    template <int DIR, bool LEAD, int NOUT = 16> __device__ __forceinline__ void mirror_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
         Cx<R>* rowb = lds + ROW * (p >> 4);
         HGS_T(tr_n, 20);
         butterfly_post<DIR, 2>(v, p);
@@ -664,7 +696,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
             static_for<0, 16>([&](auto i_) { constexpr int i = i_; v[i] = r[i]; });
         }
         HGS_T(tr_n, 24);
-        if (!HGS_ABL_BFLY) Dft<16, DIR, R>::run(v);
+        if (!HGS_ABL_BFLY) Dft<16, DIR, R>::template run_trail<NOUT>(v);
         HGS_T(tr_n, 25);
     }
 
@@ -680,6 +712,10 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
     __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, true>(v, lds, p); }
     // the previous LDS user of every wave was this workgroup's forward transform (or nothing)
     __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, false>(v, lds, p); }
+    // only registers 0 .. NOUT-1 of the result are kept
+    template <int NOUT> __device__ __forceinline__ void inv_after_fwd_trail(Cx<R> (&v)[16], Cx<R>* lds, int p) {
+        mirror_flow<+1, false, NOUT>(v, lds, p);
+    }
 };
 
 // Which workgroup transform a kernel uses for length N, and where lane j's elements sit on the space side

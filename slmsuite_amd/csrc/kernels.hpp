@@ -415,6 +415,7 @@ template <typename R> struct RowArgs {
     int n_wpartial;
     R* wscale;
     int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
+    int n_row_blocks;    // workgroups that own rows (the grid may hold one more, row-less, for the weight norm)
     // sparse targets: which columns the column kernel of this iteration wrote / the next one will read
     const unsigned short* load_mask;    // [b][Pw/16]: bit m of entry j = column j + m*Pw/16 is to be read ...
     const unsigned short* store_mask;   // ... / written; nullptr = every column
@@ -494,14 +495,20 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
     // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed-only
     // assumption): give the four rows that share each 128-byte GH line to four blocks of the same
     // XCD that start together, so the partial-line accesses meet in that XCD's L2.
+    // A workgroup pass covers FPW rows, so a line group of four rows is G = 4 / FPW workgroups (one-row workgroups: 4,
+    // two-row ones: 2; with four or more rows per workgroup the group never leaves it).  The row-owning blocks come
+    // in multiples of 8 G (host), and the stride between passes is that count -- a multiple of four rows -- so every
+    // pass keeps the groups aligned, also in a batch (grid.y) and with the extra row-less block of the weight norm.
     int first = blockIdx.x * FPW;
     if (a.xcd_map) {
+        constexpr int G = FPW <= 4 ? 4 / FPW : 1;
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        first = 4 * ((idx >> 2) * 8 + xcd) + (idx & 3);
+        first = (G * ((idx / G) * 8 + xcd) + (idx % G)) * FPW;
     }
+    const int row_stride = (a.n_row_blocks > 0 ? a.n_row_blocks : (int)gridDim.x) * FPW;
     HGS_T(fft.tr_n, 1);
 #pragma unroll 1
-    for (int rbase = first; rbase < g.Sh; rbase += gridDim.x * FPW) {
+    for (int rbase = first; rbase < g.Sh; rbase += row_stride) {
         const int r = rbase + f;
         const bool valid = r < g.Sh;
         const int rr = valid ? r : 0;
@@ -1350,7 +1357,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
             HGS_T(fft.tr_n, 5);
             if (EXTRAS && cp.weights_only) continue;
-            fft.inv_after_fwd(v, lds, j);
+            fft.template inv_after_fwd_trail<NR>(v, lds, j);      // slots NR.. (rows outside the SLM) are not stored
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
                 const Cx<R> h = v[m] * (sgs * a.scale);

@@ -17,6 +17,10 @@ perfect implementation of that operator would score against the reference: the f
 are not bit-identical to NumPy's kernels.  Runs on the CPU only (build container), ~2-3 min per run.
 
     python tools/conditioning_cfg2.py [--seeds 2 10 11 12] [--iters 50] [--procs 4] [--out profiles/r02/conditioning_cfg2.json]
+    python tools/conditioning_cfg2.py --seeds 2 10 11 12 13 14 15 16 --variants all64 --curve \
+        --out tests/golden/cfg2_ideal_fp32.json     # the yardstick of tests/test_full_configs.py (16 runs, ~15 min)
+
+--curve also records the distance after 5, 10, 20, 30 and 40 bodies (the iterations cfg2_seeds.npz holds).
 """
 import argparse
 import json
@@ -30,10 +34,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = ("plain", "fft64", "atan64", "exp64", "all64")
+CURVE_ITERS = (5, 10, 20, 30, 40)
 
 
 def run(job):
-    seed, variant, iters, small = job
+    seed, variant, iters, small, curve = job
     from oracle import hgs_oracle as orc
     from slmsuite_amd import synth
 
@@ -89,9 +94,17 @@ def run(job):
     else:
         shape, slm, grid, pitch = (4096, 4096), (1152, 1920), (32, 32), (64, 64)
     h = V(shape, orc.rectangular_array(shape, grid, pitch), slm_shape=slm, phase=synth.seed_phase(seed, slm))
-    h.optimize("WGS-Leonardo", maxiter=iters)
     ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
-    return seed, variant, h.amp_ff[ky, kx].astype(np.float64)
+    snaps = {}
+
+    def cb(hh):         # after the forward transform of body k: amp_ff = |FFT(phase_k)|, as cfg2_seeds.npz records it
+        if curve and hh.iter in CURVE_ITERS:
+            snaps[hh.iter] = hh.amp_ff[ky, kx].astype(np.float64)
+        return False
+
+    h.optimize("WGS-Leonardo", maxiter=iters, callback=cb)
+    snaps[iters] = h.amp_ff[ky, kx].astype(np.float64)
+    return seed, variant, snaps
 
 
 def main():
@@ -101,23 +114,31 @@ def main():
     ap.add_argument("--procs", type=int, default=4)
     ap.add_argument("--small", action="store_true", help="512^2 pad (quick look)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variants", nargs="+", default=[v for v in VARIANTS if v != "plain"])
+    ap.add_argument("--curve", action="store_true", help="also after 5, 10, 20, 30, 40 bodies")
     a = ap.parse_args()
-    jobs = [(s, v, a.iters, a.small) for s in a.seeds for v in VARIANTS]
+    variants = ["plain"] + [v for v in a.variants if v != "plain"]
+    jobs = [(s, v, a.iters, a.small, a.curve) for s in a.seeds for v in variants]
     with mp.get_context("spawn").Pool(a.procs) as pool:
         res = pool.map(run, jobs)
     amps = {(s, v): x for s, v, x in res}
-    table = {}
+    dist = lambda x, base: float(np.linalg.norm(x - base) / np.linalg.norm(base))   # noqa: E731
+    table, curves = {}, {}
     for s in a.seeds:
         base = amps[(s, "plain")]
-        table[s] = {v: float(np.linalg.norm(amps[(s, v)] - base) / np.linalg.norm(base)) for v in VARIANTS if v != "plain"}
+        table[s] = {v: dist(amps[(s, v)][a.iters], base[a.iters]) for v in variants if v != "plain"}
+        if a.curve:
+            curves[s] = {v: {str(k): dist(amps[(s, v)][k], base[k]) for k in sorted(base)} for v in variants if v != "plain"}
     out = {"what": "rel. L2 distance of the spot amplitudes from the unmodified oracle (= the reference) after "
                    f"{a.iters} WGS-Leonardo bodies, cfg 2 geometry{' (512^2 stand-in)' if a.small else ''}",
            "variants": {"fft64": "FFT/IFFT in complex128, rounded to complex64", "atan64": "arctan2 in float64, rounded",
                         "exp64": "exp(i phase) in complex128, rounded", "all64": "all three"},
            "numpy": np.__version__, "per_seed": table}
+    if a.curve:
+        out["per_seed_curve"] = curves
     print(json.dumps(out, indent=1))
     if a.out:
-        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(out, open(a.out, "w"), indent=1)
 
 

@@ -1,27 +1,128 @@
-"""Wall time of optimize() as a user sees it (cfg 2, engine default path): construction, first call (engine creation +
-uploads), repeated calls, a call with statistics, and what a call is made of."""
+"""
+Wall time of optimize() as a user sees it (cfg 2 geometry, engine default path AND dense kernels): construction, the
+cold first call (engine creation + uploads + 50 bodies + the trailing transform), warm calls, the resident rate
+(hgs_iterate_timed), reset() + re-optimise, and the wavefront-calibration re-optimisation pattern
+(cameraslms.py:1840-1930: a CompressedSpotHologram re-optimised with "GS" x 3 while spot_zernike changes).
+
+    python tools/e2e_timing.py [out.json]
+
+One JSON object; `*_ms` are host wall-clock milliseconds, `*_its` iterations per second.
+"""
+import json
 import sys
 import time
 
+import numpy as np
+
 sys.path.insert(0, ".")
-from slmsuite_amd import synth
-from slmsuite_amd.holography.algorithms import SpotHologram
+from slmsuite_amd import _lib as L  # noqa: E402
+from slmsuite_amd import synth  # noqa: E402
+from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM  # noqa: E402
+from slmsuite_amd.holography.algorithms import CompressedSpotHologram, SpotHologram  # noqa: E402
 
 SH, SLM = (4096, 4096), (1152, 1920)
-t0 = time.perf_counter()
-h = SpotHologram.make_rectangular_array(SH, (32, 32), (64, 64), basis="knm", slm_shape=SLM, phase=synth.seed_phase(2, SLM))
-t1 = time.perf_counter()
-print(f"construct {1e3 * (t1 - t0):.1f} ms")
-for i in range(5):
+K = 50
+
+
+def ms(t0):
+    return 1e3 * (time.perf_counter() - t0)
+
+
+def run(dense):
+    opts = {L.OPT_SPARSE_COLUMNS: 0} if dense else {}
+    out = {}
+    p0 = synth.seed_phase(2, SLM)
     t = time.perf_counter()
-    h.optimize("WGS-Leonardo", maxiter=50, verbose=False)
-    ta = time.perf_counter()
-    p = h.phase
-    tb = time.perf_counter()
-    print(f"optimize(50) call {i}: {1e3 * (ta - t):.2f} ms, reading .phase {1e3 * (tb - ta):.2f} ms")
-t = time.perf_counter()
-h.optimize("WGS-Leonardo", maxiter=50, verbose=False, stat_groups=["computational_spot"])
-print(f"optimize(50, stat_groups=[computational_spot]): {1e3 * (time.perf_counter() - t):.2f} ms")
-t = time.perf_counter()
-w = h.weights
-print(f"reading .weights (67 MB): {1e3 * (time.perf_counter() - t):.2f} ms")
+    h = SpotHologram.make_rectangular_array(SH, (32, 32), (64, 64), basis="knm", slm_shape=SLM, phase=p0, engine_options=opts)
+    out["construct_ms"] = ms(t)
+    t = time.perf_counter()
+    h.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+    h._engine.sync()
+    out["cold_optimize50_ms"] = ms(t)
+    t = time.perf_counter()
+    _ = h.phase
+    out["read_phase_ms"] = ms(t)
+    warm = []
+    for _i in range(5):
+        t = time.perf_counter()
+        h.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+        h._engine.sync()
+        warm.append(ms(t))
+    out["warm_optimize50_ms"] = float(np.median(warm))
+    # resident rate: the loop alone, HIP events on the engine stream
+    st = h._make_step()
+    e = h._get_engine()
+    e.iterate_timed(st, 20)
+    res = [e.iterate_timed(st, K) for _i in range(10)]
+    out["resident_50_ms"] = float(np.median(res))
+    out["resident_its"] = K / (1e-3 * out["resident_50_ms"])
+    out["cold_its"] = K / (1e-3 * out["cold_optimize50_ms"])
+    out["warm_its"] = K / (1e-3 * out["warm_optimize50_ms"])
+    out["cold_over_resident"] = out["cold_optimize50_ms"] / out["resident_50_ms"]
+    # reset() keeps the engine: weights from the target on the device, nothing re-uploaded but a new phase
+    t = time.perf_counter()
+    h.reset(reset_phase=False)
+    out["reset_keep_phase_ms"] = ms(t)
+    t = time.perf_counter()
+    h.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+    h._engine.sync()
+    out["optimize50_after_reset_ms"] = ms(t)
+    t = time.perf_counter()
+    h.reset_phase(p0)
+    h.reset(reset_phase=False)
+    h.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+    h._engine.sync()
+    out["reset_new_phase_optimize50_ms"] = ms(t)
+    t = time.perf_counter()
+    h.optimize("WGS-Leonardo", maxiter=K, verbose=False, stat_groups=["computational_spot"])
+    out["optimize50_spot_stats_ms"] = ms(t)
+    t = time.perf_counter()
+    _ = h.weights
+    out["read_weights_ms"] = ms(t)
+    # a second hologram of the same geometry in the same process (allocator warm)
+    t = time.perf_counter()
+    h2 = SpotHologram.make_rectangular_array(SH, (32, 32), (64, 64), basis="knm", slm_shape=SLM, phase=synth.seed_phase(3, SLM),
+                                             engine_options=opts)
+    h2.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+    h2._engine.sync()
+    out["second_hologram_construct_plus_optimize50_ms"] = ms(t)
+    return out
+
+
+def wavefront_pattern():
+    """wavefront_calibrate_zernike's loop body: GS x 3 per measurement while the coefficients of the spots change."""
+    slm_shape = (1152, 1920)
+    fs = SimpleFourierSLM(SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78))
+    basis = np.array([2, 1, 4, 3, 5, 7, 8, 6, 9, 12])
+    N = 16
+    z = np.zeros((len(basis), N))
+    z[:2] = 600 * (synth.uniform01(41, (2, N), 0) - 0.5)
+    z[2:] = 1.0 * (synth.uniform01(42, (len(basis) - 2, N), 0) - 0.5)
+    t = time.perf_counter()
+    h = CompressedSpotHologram(z.copy(), basis=basis, cameraslm=fs)
+    h.reset_phase(synth.seed_phase(40, slm_shape))
+    out = {"construct_ms": ms(t)}
+    t = time.perf_counter()
+    h.optimize("GS", maxiter=3, verbose=False)
+    h._engine.sync()
+    out["first_gs3_ms"] = ms(t)
+    rounds = []
+    for rnd in range(12):
+        z[2 + rnd % 8, :] += 0.05
+        h.spot_zernike = z.copy()
+        t = time.perf_counter()
+        h.optimize("GS", maxiter=3, verbose=False)
+        _ = h.get_phase()
+        rounds.append(ms(t))
+    out["reoptimise_gs3_plus_get_phase_ms"] = float(np.median(rounds))
+    out["n_spots"], out["n_terms"], out["slm_shape"] = N, len(basis), list(slm_shape)
+    return out
+
+
+if __name__ == "__main__":
+    res = {"workload": "cfg2: SpotHologram 32x32 on 4096^2, S = 1152x1920, WGS-Leonardo x 50",
+           "engine_default": run(False), "dense_kernels": run(True), "wavefront_calibration_pattern": wavefront_pattern()}
+    txt = json.dumps(res, indent=1)
+    print(txt)
+    if len(sys.argv) > 1:
+        open(sys.argv[1], "w").write(txt + "\n")

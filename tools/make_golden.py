@@ -8,7 +8,7 @@ fixtures do).  Nothing from the reference is copied: fixtures hold inputs and ou
 
     python tools/make_golden.py            # small fixtures (seconds)
     python tools/make_golden.py --cfg2     # additionally the 4096^2 config-2 summaries: cfg2 (~3 min), cfg2kim
-                                           # (~2 min), cfg2seeds (16 runs, ~12 min on 4 cores); --only NAME picks one
+                                           # (~2 min), cfg2seeds (16 runs, ~12 min on 4 cores), cfg2steps (~3 min, 27 MB); --only NAME picks one
 """
 import argparse
 import json
@@ -493,6 +493,44 @@ def gen_cfg2kim(alg):
                                  sub_ampff=16, sub_phase=6), out)
 
 
+CFG2_STEP_ITERS = (10, 30, 49)
+
+
+def gen_cfg2_steps(alg):
+    """
+    Teacher-forcing material for the headline run at FULL size (cfg 2, seed 2, WGS-Leonardo x 50): the complete state
+    before bodies 10, 30 and 49 -- the phase (8.8 MB each; the weights are zero off the 1,024 spots, so the spot values
+    are the whole array; WGS-Leonardo keeps no phase_ff) -- and what ONE reference body makes of it: the spot
+    amplitudes of the forward transform, the updated weights at the spots, the next phase (every third pixel per axis).
+    A single body is determined by its input to a few 1e-7, unlike the 50-body trajectory -> cfg2_steps.npz.
+    """
+    shape, slm = (4096, 4096), (1152, 1920)
+    h = alg.SpotHologram.make_rectangular_array(shape, array_shape=(32, 32), array_pitch=(64, 64), basis="knm",
+                                                slm_shape=slm, phase=synth.seed_phase(2, slm).copy())
+    ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+    out = {}
+
+    def snap(hh):       # fires after the forward transform of body k: phase_k, weights_k, amp_ff = |FFT(phase_k)|
+        k = hh.iter
+        if k in CFG2_STEP_ITERS:
+            out[f"phase_{k}"] = np.array(hh.phase, copy=True)
+            out[f"weights_{k}_spots"] = np.array(hh.weights[ky, kx])
+            out[f"ampff_{k}_spots"] = np.array(hh.amp_ff[ky, kx])
+            out[f"ampff_{k}_sub"] = np.array(hh.amp_ff[::16, ::16])
+            assert np.count_nonzero(hh.weights) == 1024
+        if k - 1 in CFG2_STEP_ITERS:
+            out[f"next_phase_{k - 1}_sub"] = np.array(hh.phase[::3, ::3])
+            out[f"next_weights_{k - 1}_spots"] = np.array(hh.weights[ky, kx])
+        return False
+
+    h.optimize("WGS-Leonardo", maxiter=50, verbose=False, stat_groups=[], callback=snap)
+    out["next_phase_49_sub"] = np.array(h.phase[::3, ::3])          # body 49 is the last: its output is the end state
+    out["next_weights_49_spots"] = np.array(h.weights[ky, kx])
+    out["spot_knm_rounded"] = np.array(h.spot_knm_rounded)
+    save("cfg2_steps", dict(kind="cfg2_steps", seed=2, shape=shape, slm_shape=slm, maxiter=50, method="WGS-Leonardo",
+                            iters=list(CFG2_STEP_ITERS), sub_phase=3, sub_ampff=16), out)
+
+
 CFG2_SEEDS = (2, 10, 11, 12, 13, 14, 15, 16)
 CFG2_CURVE_ITERS = (5, 10, 20, 30, 40)
 
@@ -650,6 +688,7 @@ def main():
         steps["cfg2"] = lambda: gen_cfg2(alg)
         steps["cfg2kim"] = lambda: gen_cfg2kim(alg)
         steps["cfg2seeds"] = lambda: gen_cfg2_seeds(alg)
+        steps["cfg2steps"] = lambda: gen_cfg2_steps(alg)
     for name, fn in steps.items():
         if args.only and name != args.only:
             continue
