@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -293,13 +294,25 @@ template <typename R> struct Engine : EngineBase {
         g.lane_T = general ? 0 : g.Ph / 16;
         S = (size_t)g.Sh * g.Sw;
         P = (size_t)g.Ph * g.Pw;
+        // HGS_TRACE_INIT=1: where hgs_create spends its time (developer aid, stderr)
+        const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
+        auto t_prev = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!trace_init) return;
+            const auto t_now = std::chrono::steady_clock::now();
+            fprintf(stderr, "hgs_create: %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t_now - t_prev).count());
+            t_prev = t_now;
+        };
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        lap("stream");
         if (general) return init_general(c);
 
         // grid sizes: enough workgroups to fill the chip a few times over, balanced over the work
         const int fpw = row_fpw(g.Pw);
         const int row_units = (g.Sh + fpw - 1) / fpw;
-        int cap = env_int("HGS_ROW_BLOCKS", n_cu * 8);
+        // one-row workgroups balance best (the hardware dispatcher hands a free slot the next row); a batch keeps them up
+        // to 64 workgroups per CU (cfg 3, 8 x 1152 rows: 187.6 -> 171.4 us per row launch against 256 per hologram)
+        int cap = env_int("HGS_ROW_BLOCKS", n_cu * 64);
         cap = cap / B > 0 ? cap / B : 1;
         int per = (row_units + cap - 1) / cap;
         row_blocks = (row_units + per - 1) / per;
@@ -316,26 +329,33 @@ template <typename R> struct Engine : EngineBase {
         ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
 
         if (dalloc(&phase, B * S)) return HGS_ERR_DEVICE;
+        lap("phase");
         if (dalloc(&gh, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE;
+        lap("gh");
         if (dalloc(&w, B * P)) return HGS_ERR_DEVICE;
         if (dalloc(&t, B * P)) return HGS_ERR_DEVICE;
+        lap("weights + target");
         if (dalloc(&wpartial, (size_t)B * std::max(std::max(col_blocks, tile_blocks), n_cu * 3))) return HGS_ERR_DEVICE;
         if (dalloc(&fpartial, (size_t)B * std::max(col_blocks, n_cu * 3))) return HGS_ERR_DEVICE;
         if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
         if (dalloc(&sums, (size_t)4 * B)) return HGS_ERR_DEVICE;
         if (dalloc(&wscale, (size_t)B)) return HGS_ERR_DEVICE;
         if (int e = fill_wscale_one()) return e;
+        lap("partials");
         if (int e = make_twiddles(&tw_row, g.Pw)) return e;
         if (int e = make_twiddles(&tw_col, g.Ph)) return e;
+        lap("twiddles");
         if (c.n_spots > 0) {
             if (dalloc(&spot_xy, (size_t)2 * c.n_spots)) return HGS_ERR_DEVICE;
             if (dalloc(&spot_amp, (size_t)c.n_spots)) return HGS_ERR_DEVICE;
             if (dalloc(&ext_amp, (size_t)c.n_spots)) return HGS_ERR_DEVICE;
             if (dalloc(&spot_fb, (size_t)B * c.n_spots)) return HGS_ERR_DEVICE;
         }
+        lap("spots");
         amp_scalar = 1.0 / std::sqrt((double)S);  // Hologram.__init__ :401-402
         amp_norm2 = 1.0;
         HIPCHK(hipStreamSynchronize(stream));
+        lap("sync");
         return 0;
     }
 

@@ -398,7 +398,8 @@ template <int N, int STAGE> constexpr int tw_offset() {  // first twiddle regist
 template <int N> constexpr int tw_count() { return tw_offset<N, Sched<N>::S>(); }
 
 __device__ __forceinline__ int lds_pad(int q) { return q + (q >> 4); }
-template <int N> constexpr int lds_elems() { return N + N / 16; }
+// (8192: two interleaved 4096-point images of 16 x 272 elements, 16 elements apart from that -- WgFftL8k)
+template <int N> constexpr int lds_elems() { return N == 8192 ? 2 * (16 * 272 + 16) : N + N / 16; }
 
 // ---- the workgroup FFT -----------------------------------------------------------------------------
 // Usage: WgFft<R,N> f; f.init(table, j);  ... f.template run<DIR>(v, lds, j);
@@ -436,6 +437,11 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
             } else {
                 constexpr int B = E / RAD;
                 constexpr int b = IDX / (RAD - 1), r = IDX % (RAD - 1) + 1;
+                if constexpr (RAD == 2 && NS * 2 == N && B == 8) {
+                    // closing radix-2 stage: W_N^(j + b T) = W_N^j * W_16^b -- one table entry and a constant rotation
+                    // instead of eight entries in flight
+                    return rot16<b, -1>(table_[j]);
+                }
                 return table_[(r * ((j + b * T) % NS) * STEP) & (N - 1)];
             }
         }
@@ -588,7 +594,8 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename R, bool RESIDENT = true> struct WgFftL {
+// TS: the twiddle table holds W_(4096 TS)^i (the 8192-point transform runs two of these on the W_8192 table)
+template <typename R, bool RESIDENT = true, int TS = 1> struct WgFftL {
     static constexpr int N = 4096, T = 256, E = 16, ROW = 272;
     static constexpr int NTW = RESIDENT ? 12 : 1;
     Cx<R> tw[NTW];
@@ -604,7 +611,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
             return tw[(s - 1) * 6 + IDX];
         } else {
             constexpr int q = (IDX < 3 ? 4 : 1) * (IDX % 3 + 1);
-            return s == 1 ? table_[(q * (p & 15) * 16) & (N - 1)] : table_[(q * p) & (N - 1)];
+            return s == 1 ? table_[TS * ((q * (p & 15) * 16) & (N - 1))] : table_[TS * ((q * p) & (N - 1))];
         }
     }
     __device__ __forceinline__ void init(const Cx<R>* __restrict__ table, int p) {
@@ -618,8 +625,8 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
             static_for<0, 6>([&](auto i_) {
                 constexpr int i = i_;
                 constexpr int q = (i < 3 ? 4 : 1) * (i % 3 + 1);
-                tw[i] = table[(q * (p & 15) * 16) & (N - 1)];
-                tw[6 + i] = table[(q * p) & (N - 1)];
+                tw[i] = table[TS * ((q * (p & 15) * 16) & (N - 1))];
+                tw[6 + i] = table[TS * ((q * p) & (N - 1))];
             });
         }
     }
@@ -718,6 +725,104 @@ template <typename R, bool RESIDENT = true> struct WgFftL {
     }
 };
 
+// ---- the 8192-point transform: a radix-2 step in registers + two interleaved WgFftL ----------------------
+// 512 lanes x 16 registers.  Lane j = 2 p + h runs, as lane p, the 4096-point transform number h of the split
+//     y0[n] = x[n] + x[n + 4096],   y1[n] = (x[n] - x[n + 4096]) W_8192^n,   X[2 k + h] = FFT_4096(y_h)[k]
+// on its own LDS image (lds + h IMG): lane j register m holds X[j + 512 m] on the frequency side -- the standard
+// layout -- and x[space_lane(j) + 512 r], space_lane(j) = WgFftL::space_lane(j >> 1) + 256 (j & 1), on the space
+// side, so the pairs (r, r + 8) of the radix-2 step sit in one lane.  After that step ONE wave-local exchange (X1,
+// between the lanes 2p and 2p + 1, no barrier) hands lane (p, h) the sixteen values y_h[. + 256 n2] WgFftL wants:
+// every lane writes its eight sums (block 0) and eight differences (block 1) and reads block h of itself and of its
+// neighbour.  X1 lives in the wave's own row regions of the two images (wave W: regions 2W, 2W + 1; block c in image
+// c, element c + 64 i + (j & 63)); with the images 16 elements (32 banks) apart every access of X1 and of the two
+// interleaved WgFftL flows is conflict-free, and a fused forward -> inverse pass needs 3 barriers (the general
+// four-stage code: 12, and 24 % of its LDS cycles were bank conflicts).  The inverse is the mirror.
+// tools/fft_local8k_model.py is the index model.  Zero / unwanted slots: NZ leading non-zero registers (NZ <= 8: the
+// partner x[n + 4096] is zero, the radix-2 step is a copy and a twiddle) become 2 NZ leading slots of the 4096-point
+// transforms; likewise NOUT on the way back.
+template <typename R, bool RESIDENT = true> struct WgFftL8k {
+    static constexpr int N = 8192, T = 512, IMG = 16 * 272 + 16, X1 = IMG + 1;
+    using Core = WgFftL<R, RESIDENT, 2>;
+    Core core;
+    Cx<R> w2;            // W_8192^(space_lane(j))
+    int tr_n = 0;
+
+    static __host__ __device__ __forceinline__ int space_lane(int j) { return Core::space_lane(j >> 1) + 256 * (j & 1); }
+    __device__ __forceinline__ void init(const Cx<R>* __restrict__ table, int j) {
+        core.init(table, j >> 1);
+        w2 = table[space_lane(j)];
+    }
+    // element offsets of X1 for lane j: its own slots (one per register and block) / block h of the pair (p, 0), (p, 1)
+    static __device__ __forceinline__ int x1_own(int j) { return 544 * (j >> 6) + (j & 63); }
+    static __device__ __forceinline__ int x1_pair(int j) { return (j & 1) * X1 + 544 * (j >> 6) + (j & 62); }
+
+    template <int NZ> __device__ __forceinline__ void forward(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+        static_assert(NZ >= 2 && NZ <= 16, "WgFftL8k: leading non-zero registers");
+        constexpr bool HALF = NZ <= 8;                 // registers 8.. are zero: sums = v[i], differences = v[i] * twiddle
+        constexpr int NI = HALF ? NZ : 8;              // pairs that carry data
+        if (!HGS_ABL_BFLY) {
+            static_for<0, NI>([&](auto i_) {
+                constexpr int i = i_;
+                if constexpr (HALF) {
+                    v[i + 8] = cmul(rot16<i, -1>(v[i]), w2);
+                } else {
+                    const Cx<R> d = v[i] - v[i + 8];
+                    v[i] = v[i] + v[i + 8];
+                    v[i + 8] = cmul(rot16<i, -1>(d), w2);
+                }
+            });
+        }
+        Cx<R> u[16];
+        if (!HGS_ABL_XCHG) {
+            Cx<R>* w = lds + x1_own(j);
+            static_for<0, NI>([&](auto i_) { constexpr int i = i_; w[64 * i] = v[i]; w[X1 + 64 * i] = v[i + 8]; });
+            wave_lds_order();
+            const Cx<R>* r = lds + x1_pair(j);
+            static_for<0, 16>([&](auto n_) {
+                constexpr int n2 = n_;
+                if constexpr ((n2 >> 1) < NI) u[n2] = r[64 * (n2 >> 1) + (n2 & 1)]; else u[n2] = mk<R>(0, 0);
+            });
+            wave_lds_order();                          // the core's first (wave-local) exchange reuses these regions
+        } else {
+            static_for<0, 16>([&](auto n_) { constexpr int n2 = n_; u[n2] = v[n2]; });
+        }
+        core.template forward_flow<-1, (2 * NI < 16 ? (2 * NI < 4 ? 4 : 2 * NI) : 16)>(u, lds + (j & 1) * IMG, j >> 1);
+        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = u[m]; });
+    }
+    template <bool LEAD, int NOUT> __device__ __forceinline__ void mirror(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+        static_assert(NOUT >= 2 && NOUT <= 16, "WgFftL8k: leading wanted registers");
+        constexpr bool HALF = NOUT <= 8;               // registers 8.. of the result are not wanted
+        constexpr int NI = HALF ? NOUT : 8;
+        core.template mirror_flow<+1, LEAD, (2 * NI < 16 ? 2 * NI : 16)>(v, lds + (j & 1) * IMG, j >> 1);
+        Cx<R> y0[8], y1[8];
+        if (!HGS_ABL_XCHG) {
+            wave_lds_order();                          // the core's last exchange read these regions
+            Cx<R>* w = lds + x1_pair(j);
+            static_for<0, 2 * NI>([&](auto n_) { constexpr int n2 = n_; w[64 * (n2 >> 1) + (n2 & 1)] = v[n2]; });
+            wave_lds_order();
+            const Cx<R>* r = lds + x1_own(j);
+            static_for<0, NI>([&](auto i_) { constexpr int i = i_; y0[i] = r[64 * i]; y1[i] = r[X1 + 64 * i]; });
+        } else {
+            static_for<0, NI>([&](auto i_) { constexpr int i = i_; y0[i] = v[i]; y1[i] = v[i + 8]; });
+        }
+        if (!HGS_ABL_BFLY) {
+            static_for<0, NI>([&](auto i_) {
+                constexpr int i = i_;
+                const Cx<R> t = cmulc(rot16<i, +1>(y1[i]), w2);
+                v[i] = y0[i] + t;
+                if constexpr (!HALF) v[i + 8] = y0[i] - t;
+            });
+        }
+    }
+    __device__ __forceinline__ void fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { forward<16>(v, lds, j); }
+    template <int NZ> __device__ __forceinline__ void fwd_lead(Cx<R> (&v)[16], Cx<R>* lds, int j) { forward<NZ>(v, lds, j); }
+    __device__ __forceinline__ void inv(Cx<R> (&v)[16], Cx<R>* lds, int j) { mirror<true, 16>(v, lds, j); }
+    __device__ __forceinline__ void inv_after_fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { mirror<false, 16>(v, lds, j); }
+    template <int NOUT> __device__ __forceinline__ void inv_after_fwd_trail(Cx<R> (&v)[16], Cx<R>* lds, int j) {
+        mirror<false, NOUT>(v, lds, j);
+    }
+};
+
 // Which workgroup transform a kernel uses for length N, and where lane j's elements sit on the space side
 // (frequency side: always j + m * N/16).
 #ifndef HGS_LOCAL_FFT
@@ -734,6 +839,16 @@ template <typename R, bool RESIDENT> struct FftSel<R, 4096, RESIDENT> {
     static constexpr bool local = true;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL<R, RESIDENT>::space_lane(j); }
 };
+#ifndef HGS_LOCAL_FFT8K
+#define HGS_LOCAL_FFT8K 1
+#endif
+#if HGS_LOCAL_FFT8K
+template <typename R, bool RESIDENT> struct FftSel<R, 8192, RESIDENT> {
+    using type = WgFftL8k<R, RESIDENT>;
+    static constexpr bool local = true;
+    static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL8k<R, RESIDENT>::space_lane(j); }
+};
+#endif
 #endif
 
 }  // namespace hgs

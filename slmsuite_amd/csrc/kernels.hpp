@@ -506,6 +506,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
         first = (G * ((idx / G) * 8 + xcd) + (idx % G)) * FPW;
     }
     const int row_stride = (a.n_row_blocks > 0 ? a.n_row_blocks : (int)gridDim.x) * FPW;
+    if (a.n_row_blocks > 0 && (int)blockIdx.x >= a.n_row_blocks) first = g.Sh;     // the weight-norm block owns no row
     HGS_T(fft.tr_n, 1);
 #pragma unroll 1
     for (int rbase = first; rbase < g.Sh; rbase += row_stride) {
@@ -746,7 +747,8 @@ template <typename R> struct ColArgs {
 };
 
 template <typename R, int N, int MODE>
-__global__ __launch_bounds__(ColCfg<N>::WG, (N >= 8192 && sizeof(R) == 4 ? HGS_COL_OCC_8192 : HGS_COL_OCC)) void col_kernel(ColArgs<R> a) {   // (8192: see row_kernel)
+// (fp64: two waves per SIMD -- at three, every instantiation spilled 17 .. 74 VGPRs)
+__global__ __launch_bounds__(ColCfg<N>::WG, (sizeof(R) == 8 ? 2 : N >= 8192 ? HGS_COL_OCC_8192 : HGS_COL_OCC)) void col_kernel(ColArgs<R> a) {   // (8192: see row_kernel)
     using M = Math<R>;
     constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1000,28 +1002,42 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
         const bool vcol = col_valid(q);
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
+        // fp64: this column's weights / targets land under its forward transform (8192: after it -- the 64 registers
+        // would not fit next to the transform's own)
+        if constexpr (LEAN && N < 8192) issue_wt(q);
         fft.fwd(v, lds, j);
-        if constexpr (LEAN) issue_wt(q);      // fp64: loaded at the point of use (register budget)
+        // fp64: the 16 transformed values of a lane (64 VGPRs) wait in the idle LDS image while the constraint runs --
+        // lane-private slots [m * T + j], conflict-free, no barrier -- so that the rule (inlined double log2 / exp2,
+        // atan2, sincos) does not sit on top of them: with v, weights and targets all in registers every fp64
+        // instantiation spilled 137 .. 483 VGPRs to scratch
+        Cx<R>* park = lds + j;
+        if constexpr (LEAN) {
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; park[m * T] = v[m]; });
+            if constexpr (N >= 8192) issue_wt(q);
+        }
 
         // ---- constraint + weight update on F = sc * v ----
         R* wc = a.w + cb;
         R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
         bool w_changed = false;
-        static_for<0, 16>([&](auto m_) {
+        auto cons = [&](auto m_) {
             constexpr int m = m_;
             const unsigned idx = lane_pos<T>(j, m);
+            Cx<R> vm;
+            if constexpr (LEAN) vm = park[m * T]; else vm = v[m];
+            [&]() {
             // wave-uniform skip of pixels with zero weight and zero target (see col_tile_kernel)
             if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
                 __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS || cp.mraf) && tr[m] != (R)0)) == 0) {
-                v[m] = mk<R>(0, 0);
+                vm = mk<R>(0, 0);
                 if (cp.nog_pass && vcol) acc_w += (R)1;      // T == 0 -> fc = 1 (:1841)
                 return;
             }
-            const Cx<R> F = v[m] * sc;
+            const Cx<R> F = vm * sc;
             const R p2 = F.x * F.x + F.y * F.y;
             if (cp.nog_pass) {                              // Nogrette: sum of fc = feedback / target over all pixels
                 if (vcol) acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
-                v[m] = mk<R>(0, 0);
+                vm = mk<R>(0, 0);
                 return;
             }
             const R wraw = wr[m];
@@ -1064,23 +1080,39 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 }
                 if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
-            v[m] = mk<R>(wv * co * sgn, wv * si * sgn);
+            vm = mk<R>(wv * co * sgn, wv * si * sgn);
             if (cp.mraf) {                                  // mixed-region amplitude freedom (:1606-1653)
                 const R t = tr[m];
                 if (is_nan(t)) {
                     const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
-                    v[m] = F * mf;
+                    vm = F * mf;
                 } else if (t == (R)0) {
-                    v[m] = mk<R>(0, 0);
+                    vm = mk<R>(0, 0);
                     if constexpr (PHASE == 1) { if (vcol) pfc[idx] = (R)0; }
                 }
             }
-            if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) - 1) __builtin_amdgcn_sched_barrier(0);
-        });
-
-        if constexpr (STATS) sacc.flush(stat_slot);
-        if (cp.do_update && w_changed && vcol) {
-            static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
+            }();
+            if constexpr (LEAN) park[m * T] = vm; else v[m] = vm;
+            // (fp64: one pixel at a time -- four interleaved double atan2 / sincos / log2 chains cost 100+ registers)
+            if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 1) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 1) - 1) __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (!LEAN) {
+            static_for<0, 16>(cons);
+            if constexpr (STATS) sacc.flush(stat_slot);
+            if (cp.do_update && w_changed && vcol) {
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
+            }
+        } else {
+            // fp64: updated weights leave four pixels (32 bytes) at a time, so that they do not all stay live
+            static_for<0, 4>([&](auto g_) {
+                constexpr int g0 = 4 * decltype(g_)::value;
+                w_changed = false;
+                static_for<0, 4>([&](auto i_) { cons(std::integral_constant<int, g0 + decltype(i_)::value>{}); });
+                if (cp.do_update && w_changed && vcol) {
+                    static_for<0, 4>([&](auto i_) { constexpr int m = g0 + i_; wc[lane_pos<T>(j, m)] = wr[m]; });
+                }
+            });
+            if constexpr (STATS) sacc.flush(stat_slot);
         }
         // ---- prefetch the next column while this one is transformed back ----
         if (q + 1 < ncols) {
@@ -1088,6 +1120,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 issue_wt(q + 1);
                 issue_g(q + 1, gn);
             }
+        }
+        if constexpr (LEAN) {
+            // back from the parking slots; whatever comes next -- the inverse, or (forward-only passes) the next
+            // column's forward transform -- scatters into other lanes' slots
+            if (!cp.weights_only) static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T]; });
+            __syncthreads();
         }
         if (!cp.weights_only) {
             fft.inv_after_fwd(v, lds, j);

@@ -131,6 +131,7 @@ class Hologram:
         self._upload = set()   # names whose host copy must reach the device before the next op
         self._n_spots_engine = 0
         self._weights_reset = False   # weights == target with NaN -> 0 (reset_weights): host copy built on access
+        self._populate_pending = False   # the trailing transform of optimize() (_populate_results) not yet run
         # engine policy applied whenever this hologram creates an engine: {L.OPT_*: value} (hgs_set_option)
         self.engine_options = dict(kwargs.pop("engine_options", {}) or {})
 
@@ -157,6 +158,8 @@ class Hologram:
 
     # ---- device-backed attributes -----------------------------------------------------------------
     def _get_dev(self, name):
+        if name in ("farfield", "amp_ff", "phase_ff"):
+            self._flush_populate()
         if name in self._stale and self._engine is not None:
             arr = self._engine.get(_DEVICE_ARRAYS[name])[0]
             self._host[name] = arr
@@ -166,6 +169,8 @@ class Hologram:
         return self._host.get(name)
 
     def _set_dev(self, name, value):
+        if name == "phase":
+            self._flush_populate()            # the results of the last optimize() describe the phase it ended on
         self._host[name] = value
         self._stale.discard(name)
         if name == "weights":
@@ -249,6 +254,7 @@ class Hologram:
         self._host["farfield"] = np.zeros(self.shape, dtype=self.dtype_complex)
         self._stale -= {"amp_ff", "phase_ff", "farfield"}
         self._upload.discard("phase_ff")
+        self._populate_pending = False
         if self._engine is not None:
             # the engine survives: weights from its target, phase_ff / farfield / amp_ff back to "None" (hgs_reset);
             # a phase only the device holds (reset_phase False after an optimize()) simply stays there
@@ -258,6 +264,7 @@ class Hologram:
         """Download every device-fresh array (the engine may not be able to serve all of them), then destroy it."""
         if self._engine is None:
             return
+        self._flush_populate()
         for name in list(self._stale):
             try:
                 self._get_dev(name)
@@ -407,6 +414,7 @@ class Hologram:
         repeated calls cost two kernels plus the read-back.  The affine step is the reference's own
         host call (``scipy.ndimage.affine_transform``, order 3, constant 0) on the downloaded field.
         """
+        self._flush_populate()
         if shape is None:
             shape = self.shape
         if len(shape) == 1:
@@ -634,6 +642,15 @@ class Hologram:
         return not (callback is not None or fl.get("raw_stats", False) or self._efficiency_group() == -1)
 
     def optimize_gs(self, iterations, callback):
+        if self._populate_pending:
+            # Nobody looked at the results of the previous call.  Its trailing transform matters to this loop only
+            # through phase_ff, which a fixed phase (WGS-Kim after fixing, "GS" after such a run: quirk A4) reads;
+            # a callback may look at any of it.  Otherwise this call's own trailing transform replaces all of it.
+            if callback is not None or self.flags.get("fixed_phase", False):
+                self._flush_populate()
+            else:
+                self._populate_pending = False
+                self._stale -= {"farfield", "amp_ff", "phase_ff"}
         e = self._get_engine()
         self._pre_loop_checks()
         n_total = len(iterations)
@@ -676,7 +693,15 @@ class Hologram:
                 e.farfield2nearfield()
                 self._mark_device_fresh(["phase"])
                 self.iter += 1
-        self._populate_results()
+        # _populate_results (:934-949) runs when somebody asks for farfield / amp_ff / phase_ff, when the phase is
+        # replaced, or ahead of the next call that depends on it -- not before optimize() returns
+        self._populate_pending = True
+
+    def _flush_populate(self):
+        if self.__dict__.get("_populate_pending"):
+            self._populate_pending = False
+            if self._engine is not None:
+                self._populate_results()
 
     def _constraint_step(self, e):
         """_gs_farfield_routines (:1550-1661) of the general path, after _update_stats of this iteration."""
@@ -961,6 +986,13 @@ class SpotHologram(FeedbackHologram):
 
     def _spot_window(self):
         return self.spot_integration_width_knm
+
+    def _mraf_enabled(self):
+        """NaN in the target (_mraf_helper_routines :1498) without a 67 MB reduction: the raster is zeros, the spot
+        amplitudes and -- only with null points -- a NaN background."""
+        if self.null_knm is not None or not hasattr(self, "spot_knm_rounded"):
+            return super()._mraf_enabled()
+        return bool(np.isnan(np.sum(self.target[self.spot_knm_rounded[1], self.spot_knm_rounded[0]])))
 
     def _pre_loop_checks(self):
         if self.flags.get("feedback") == "experimental":

@@ -47,12 +47,16 @@ def test_cfg2_leonardo_every_column_path_matches_reference(path):
                 amp_sub=rel_l2(amp_ff[::16, ::16], gold["ampff_sub"]),
                 phase_sub=phase_rel_l2(h.phase[::6, ::6], gold["phase_sub"]))
     report(f"cfg2 WGS-Leonardo 50 it vs reference [{path} column path]", **errs)
-    # 50 free-phase bodies: the reference itself moves by 4.3e-6 here when its seed phase changes by one fp32 ulp
-    # (cfg2_seeds.npz; other seeds: up to 4e-4), and an implementation injects that much rounding in EVERY body
-    # (test_cfg2_error_growth_over_seeds holds the whole curve); the plain north-star 1e-5 is asserted at <= 10
-    # bodies there and on the phase-fixing variant below.
-    floor = rel_l2(load_golden("cfg2_seeds")[1]["spot_ampff_perturbed"][0], gold["spot_ampff"])
-    assert errs["spot_amp"] < max(1e-5, 6 * floor)
+    # 50 free-phase bodies amplify rounding: an IDEAL fp32 implementation (float64 arithmetic rounded to float32,
+    # tests/golden/cfg2_ideal_fp32.json) ends 1.28e-5 from the reference on this seed.  The bound is tied to that
+    # yardstick, not to the engine (test_cfg2_error_growth_over_seeds holds the whole curve over eight seeds; the plain
+    # north-star 1e-5 is asserted at <= 10 bodies there, on the phase-fixing variant below, and -- at 2e-6 -- on the
+    # teacher-forced single bodies of this very run).
+    import json
+    import os
+    from conftest import GOLDEN
+    yard = json.load(open(os.path.join(GOLDEN, "cfg2_ideal_fp32.json")))["per_seed_curve"]["2"]["all64"]["50"]
+    assert errs["spot_amp"] < max(1e-5, 3 * yard)          # 1.28e-5 for the ideal fp32 implementation; engine 1.6e-5
     assert errs["spot_weights"] < 3e-4 and errs["amp_sub"] < 3e-4 and errs["phase_sub"] < 6e-4
 
 
@@ -116,21 +120,30 @@ def test_cfg2_kim_every_column_path_matches_reference(path):
 
 def test_cfg2_error_growth_over_seeds():
     """
-    Eight seed phases (tests/golden/cfg2_seeds.npz, recorded from the reference): the spot amplitudes after 5, 10,
-    20, 30, 40 and 50 WGS-Leonardo bodies, from each seed AND from the same seed perturbed by about one fp32 ulp.
-    Free-phase WGS amplifies rounding differences exponentially (the reference's own two runs drift apart at the
-    same rate), so the engine is held to the north-star 1e-5 while the trajectory is still determined by the
-    input (<= 10 bodies, every seed), and afterwards to a small multiple of the distance the reference itself
-    moves under the one-ulp change -- the floor for any fp32 implementation not bit-identical to NumPy
-    (profiles/r02/conditioning_cfg2.json: even exact arithmetic rounded to fp32 lands there).
+    Eight seed phases: the spot amplitudes after 5, 10, 20, 30, 40 and 50 WGS-Leonardo bodies against the reference's
+    (tests/golden/cfg2_seeds.npz).  Free-phase WGS amplifies rounding differences exponentially, so beyond ~10 bodies
+    no fp32 implementation that is not bit-identical to NumPy lands within a flat 1e-5.  The yardstick is NOT the
+    engine's own behaviour: tests/golden/cfg2_ideal_fp32.json (tools/conditioning_cfg2.py --variants all64 --curve,
+    CPU only) holds, per seed and iteration, how far an IDEAL fp32 implementation -- the reference's op sequence with
+    every FFT / arctan2 / exp evaluated in float64 and rounded once to float32 -- ends up from the reference.  Asserted:
+      * 5 and 10 bodies, every seed: the north-star 1e-5;
+      * every recorded iteration: error <= max(1e-5, 3 x the ideal implementation's distance) -- measured 0.2 .. 2.3 x;
+        a 2x loss of accuracy in the engine's arithmetic breaks this on the well-conditioned seeds (10, 13, 14, 16),
+        and the teacher-forced single bodies (test_cfg2_single_bodies_at_full_size_match_reference) catch it outright.
+    The distance the reference itself moves when its seed changes by one fp32 ulp (also in cfg2_seeds.npz) is reported.
     """
+    import json
+    import os
+    from conftest import GOLDEN
     meta, gold = load_golden("cfg2_seeds")
+    ideal = json.load(open(os.path.join(GOLDEN, "cfg2_ideal_fp32.json")))["per_seed_curve"]
     its = list(meta["curve_iters"]) + [meta["maxiter"]]
     worst_ratio = {"default": 0.0, "dense": 0.0}
     for i, seed in enumerate(meta["seeds"]):
         ref = np.concatenate((gold["curve_ampff"][i], gold["spot_ampff"][i][None]))
         refp = np.concatenate((gold["curve_ampff_perturbed"][i], gold["spot_ampff_perturbed"][i][None]))
-        floor = np.array([rel_l2(refp[k], ref[k]) for k in range(len(its))])
+        drift = np.array([rel_l2(refp[k], ref[k]) for k in range(len(its))])
+        yard = np.array([ideal[str(seed)]["all64"][str(k)] for k in its])
         for path in ("default", "dense"):
             h = cfg2_hologram(seed, path)
             ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
@@ -142,13 +155,12 @@ def test_cfg2_error_growth_over_seeds():
             h._release_engine()
             err = np.array(err)
             report(f"cfg2 seed {seed} [{path}] engine error at bodies {its}", **{f"it{k}": e for k, e in zip(its, err)})
-            report(f"cfg2 seed {seed} reference 1-ulp drift at bodies {its}", **{f"it{k}": e for k, e in zip(its, floor)})
+            report(f"cfg2 seed {seed} ideal fp32 implementation at bodies {its}", **{f"it{k}": e for k, e in zip(its, yard)})
+            report(f"cfg2 seed {seed} reference 1-ulp drift at bodies {its}", **{f"it{k}": e for k, e in zip(its, drift)})
             assert np.all(err[:2] < 1e-5), (seed, path, err)                 # 5 and 10 bodies: north-star tolerance
-            ratio = err / np.maximum(floor, 1e-7)
-            worst_ratio[path] = max(worst_ratio[path], float(ratio[2:].max()))
-            # later: within a small multiple of the reference's own sensitivity (or the plain 1e-5 where that is smaller)
-            assert np.all(err < np.maximum(1e-5, 6 * floor)), (seed, path, err, floor)
-    report("cfg2 seed sweep: worst engine error / reference 1-ulp drift (bodies >= 20)", **worst_ratio)
+            worst_ratio[path] = max(worst_ratio[path], float((err / yard).max()))
+            assert np.all(err < np.maximum(1e-5, 3 * yard)), (seed, path, err, yard)
+    report("cfg2 seed sweep: worst engine error / ideal-fp32 distance", **worst_ratio)
 
 
 # ---- cfg 3: eight holograms per engine at 4096^2 ------------------------------------------------------------
@@ -298,14 +310,14 @@ def test_cfg5_precision_sweep_per_step():
     BASELINE config 5 is a *sweep*: at 8192^2 (MRAF, mraf_factor 0.5), from the engine's own fp32 state before body k,
     ONE body computed by the oracle in float64 (the truth), the oracle in float32, the engine in float32 and in float64.
     Asserted per step:
-      * engine fp64 vs oracle fp64: 1e-11 (GS) / 1e-9 (WGS: the weight rule's pow) on phase and weights;
-      * engine fp32 vs oracle fp32: 5e-6 on the phase for GS (SURVEY 7-5: <= 2e-6 per transform pair + atan2);
-      * for BOTH methods the engine's fp32 rounding error against the truth is no worse than twice the reference
-        arithmetic's own fp32 error on the same step, plus the north-star 1e-5: pixel-wise WGS on a dense MRAF image
-        divides by speckle amplitudes, so its per-step error is large for ANY fp32 implementation (NumPy's: 1.5e-5 on
-        the phase, 2.2e-5 on the weights at k = 1) -- what is held fixed is the ratio.  (Measured: phase 1.0-1.6 x
-        NumPy's error; weights up to 4 x at k = 2, 1.1e-5 against 2.6e-6: the rule's power runs on the hardware
-        log2 / exp2, 1 ulp each but applied to log2 of ratios of up to 2^10, where powf is correctly rounded.)
+      * engine fp64 vs oracle fp64: 1e-11 (GS) / 1e-9 (WGS: the weight rule's pow), relative L2, phase and weights;
+      * engine fp32 vs oracle fp32, GS: 5e-6 on the phase (SURVEY 7-5: <= 2e-6 per transform pair + atan2);
+      * both methods: the engine's fp32 rounding error against the truth is no worse than twice the reference
+        arithmetic's own on the same step -- compared on the MEDIAN and the 99th PERCENTILE of the per-pixel error, not
+        on the L2 norm: pixel-wise WGS on a dense MRAF image divides by speckle amplitudes, a handful of pixels near a
+        zero of the field carry most of any L2 difference (NumPy's own fp32 L2 error is 0.9 .. 2.5e-5 per step here) and
+        which pixels they are changes with every rounding, so L2 ratios of two fp32 implementations scatter by 4x either
+        way from state to state.  (Measured: median and p99 within 1.0 .. 1.3 x NumPy's.)
     tools/cfg5_sweep.py runs k = 1..20 plus the free-running divergence curves; profiles/r03/cfg5_sweep.json keeps them.
     """
     import os
@@ -317,11 +329,13 @@ def test_cfg5_precision_sweep_per_step():
     for method, entry in res["methods"].items():
         for row in entry["teacher_forced"]:
             k = row["k"]
-            report(f"cfg5 sweep {method} k={k}", **{f"{t}_{q}": row[t][q] for t in row if t != "k" for q in ("phase", "weights")})
+            report(f"cfg5 sweep {method} k={k}", **{f"{t}_{q}_{st}": row[t][q][st] for t in row if t != "k"
+                                                    for q in ("phase", "weights") for st in ("l2", "median", "p99")})
             e64, e32 = row["engine64_vs_oracle64"], row["engine32_vs_oracle32"]
             tol64 = 1e-11 if method == "GS" else 1e-9
-            assert e64["phase"] < tol64 and e64["weights"] < tol64, (method, k, e64)
+            assert e64["phase"]["l2"] < tol64 and e64["weights"]["l2"] < tol64, (method, k, e64)
             if method == "GS":
-                assert e32["phase"] < 5e-6 and e32["weights"] < 1e-6, (method, k, e32)
+                assert e32["phase"]["l2"] < 5e-6 and e32["weights"]["l2"] < 1e-6, (method, k, e32)
             for q in ("phase", "weights"):
-                assert row["engine32_vs_truth"][q] <= 2 * row["oracle32_vs_truth"][q] + 1e-5, (method, k, q, row)
+                for st in ("median", "p99"):
+                    assert row["engine32_vs_truth"][q][st] <= 2 * row["oracle32_vs_truth"][q][st] + 1e-7, (method, k, q, st, row)

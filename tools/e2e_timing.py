@@ -89,6 +89,45 @@ def run(dense):
     return out
 
 
+def breakdown():
+    """Where a cold optimize(50) goes (engine default path): every Engine call of the class, synchronised and timed."""
+    from slmsuite_amd.engine import Engine
+    acc = {}
+
+    def wrap(name):
+        orig = getattr(Engine, name)
+
+        def f(self, *a, **k):
+            t = time.perf_counter()
+            r = orig(self, *a, **k)
+            if name != "__init__" and getattr(self, "_h", None) is not None and self._h.value:
+                self.sync()
+            acc[name] = acc.get(name, 0.0) + ms(t)
+            return r
+        setattr(Engine, name, f)
+        return orig
+
+    names = ["__init__", "set", "set_sparse", "reset_weights", "reset", "iterate", "nearfield2farfield", "get", "set_option"]
+    saved = {n: wrap(n) for n in names}
+    try:
+        t = time.perf_counter()
+        h = SpotHologram.make_rectangular_array(SH, (32, 32), (64, 64), basis="knm", slm_shape=SLM, phase=synth.seed_phase(5, SLM))
+        construct = ms(t)
+        t = time.perf_counter()
+        h.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+        total = ms(t)
+        t = time.perf_counter()
+        _ = h.phase
+        rd = ms(t)
+    finally:
+        for n, o in saved.items():
+            setattr(Engine, n, o)
+    out = {"construct_ms": construct, "optimize50_total_ms": total, "read_phase_ms": rd}
+    out.update({f"engine.{k}_ms": v for k, v in acc.items()})
+    out["host_side_ms"] = total - sum(v for k, v in acc.items() if k != "get")
+    return out
+
+
 def wavefront_pattern():
     """wavefront_calibrate_zernike's loop body: GS x 3 per measurement while the coefficients of the spots change."""
     slm_shape = (1152, 1920)
@@ -121,7 +160,8 @@ def wavefront_pattern():
 
 if __name__ == "__main__":
     res = {"workload": "cfg2: SpotHologram 32x32 on 4096^2, S = 1152x1920, WGS-Leonardo x 50",
-           "engine_default": run(False), "dense_kernels": run(True), "wavefront_calibration_pattern": wavefront_pattern()}
+           "engine_default": run(False), "dense_kernels": run(True), "cold_call_breakdown": breakdown(),
+           "wavefront_calibration_pattern": wavefront_pattern()}
     txt = json.dumps(res, indent=1)
     print(txt)
     if len(sys.argv) > 1:
