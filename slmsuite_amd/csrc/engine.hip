@@ -163,6 +163,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_separable = 1;                 // HGS_OPT_SEPARABLE
     int opt_sep_min = 32;                  // smallest spot count the matrix-core form is used for
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
+    int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
     int* stats_dxy = nullptr;         // hgs_stats group 1: floor(spot_knm)
@@ -219,6 +220,7 @@ template <typename R> struct Engine : EngineBase {
 
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
+        if (tw_col == tw_row) tw_col = nullptr;
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
         for (void* p : ptrs)
@@ -296,6 +298,7 @@ template <typename R> struct Engine : EngineBase {
         P = (size_t)g.Ph * g.Pw;
         // HGS_TRACE_INIT=1: where hgs_create spends its time (developer aid, stderr)
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
+        opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!trace_init) return;
@@ -343,7 +346,8 @@ template <typename R> struct Engine : EngineBase {
         if (int e = fill_wscale_one()) return e;
         lap("partials");
         if (int e = make_twiddles(&tw_row, g.Pw)) return e;
-        if (int e = make_twiddles(&tw_col, g.Ph)) return e;
+        if (g.Ph == g.Pw) tw_col = tw_row;                    // square pads: one table
+        else if (int e = make_twiddles(&tw_col, g.Ph)) return e;
         lap("twiddles");
         if (c.n_spots > 0) {
             if (dalloc(&spot_xy, (size_t)2 * c.n_spots)) return HGS_ERR_DEVICE;
@@ -762,6 +766,12 @@ template <typename R> struct Engine : EngineBase {
         farfield_valid = false;
         return r;
     }
+
+    // (the tile-resident kernel is fp32 only; this branch is never taken for double)
+    static int tile_rule(int N, int phase, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+        return launch_tile_rule(N, phase, rule, grid, s, a, m0);
+    }
+    static int tile_rule(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
 
     int fill_wscale_one() {
         hipLaunchKernelGGL(set_scalar<R>, dim3((B + 63) / 64), dim3(64), 0, stream, wscale, B, (R)1);
@@ -1628,7 +1638,12 @@ template <typename R> struct Engine : EngineBase {
                             if (a.do_stats) LCHK(launch_tile_extras_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
                             else LCHK(launch_tile_extras<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
                         } else {
+                            // the hot launches: weight rule compiled in (col_tile_kernel RULE) where it is the
+                            // Leonardo / Kim update or no update at all
+                            const int rule = !opt_tile_rule ? 0 : !a.cp.do_update ? 2
+                                             : (a.cp.method == HGS_WGS_LEONARDO || a.cp.method == HGS_WGS_KIM) ? 1 : 0;
                             if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                            else if (rule != 0) LCHK(tile_rule(g.Ph, phase_mode, rule, dim3(tile_blocks, B), stream, a, m0));
                             else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
                         }
                     } else {

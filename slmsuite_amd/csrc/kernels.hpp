@@ -1205,7 +1205,10 @@ template <typename R, int N> constexpr size_t col_tile_lds_bytes() {
     return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
 }
 
-template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true>
+// RULE: 0 = method and update switch read from CParams (a chain of uniform branches per pixel: five per evaluated
+// pixel of a spot column, four of them taken); 1 = the WGS-Leonardo / WGS-Kim update compiled in; 2 = no weight update
+// (GS, iteration 0, the second pass of MRAF).  The hot launches use 1 / 2 (launch_tile_rule).
+template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0>
 __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
     using M = Math<R>;
     constexpr int T = N / 16;
@@ -1221,6 +1224,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
+    const bool do_upd = RULE == 1 ? true : (RULE == 2 ? false : cp.do_update != 0);
     const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     R gtx[NR][4], gty[NR][4];   // the tile (scalar arrays: arrays of 2-vectors are not promoted to registers)
     R wr[16], tr[16];
 
-    const bool upd = cp.do_update != 0 || STATS || cp.mraf != 0;   // target needed by the update, the statistics, MRAF
+    const bool upd = do_upd || STATS || (EXTRAS && cp.mraf != 0);   // target needed by the update, the statistics, MRAF
     const R nogv = cp.nog != nullptr ? cp.nog[b] : (R)0;
     double* stat_slot = scratch + 16 + (j >> 6) * STAT_N;
     StatAcc<R> sacc;
@@ -1333,9 +1337,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
                 const R wraw = wr[m];
                 R wv = wraw * wsc;
-                if (cp.do_update) {
+                if (do_upd) {
                     const R t = tr[m];
-                    if (cp.method == M_LEONARDO || cp.method == M_KIM) {
+                    if (RULE == 1 || cp.method == M_LEONARDO || cp.method == M_KIM) {
                         R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);     // (eager + select, see col_fused_kernel)
                         fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
                         wv *= fc;
@@ -1379,7 +1383,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             });
             if constexpr (STATS) sacc.flush(stat_slot);
             // updated weights of this lane (unchanged lanes -- zeros of a sparse target -- write nothing)
-            if (cp.do_update && w_changed) {
+            if (do_upd && w_changed) {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
             }
             if constexpr (PHASE == 1)
@@ -1425,7 +1429,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     }
     HGS_T(fft.tr_n, 7);
     if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
-    if (cp.do_update) {
+    if (do_upd) {
         const double s = block_sum((double)acc_w, scratch);
         if (j == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }

@@ -18,6 +18,9 @@ template <typename R> int launch_tile_stats(int N, int phase_mode, dim3 grid, hi
 template <typename R> int launch_tile_extras(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
 template <typename R> int launch_tile_extras_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
 
+// ... and with the weight rule compiled in (rule 1: WGS-Leonardo / WGS-Kim update, 2: no update; no statistics, no extras)
+int launch_tile_rule(int N, int phase_mode, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
+
 // blocks of the transform kernels resident per CU are bounded by LDS; exposed for grid sizing
 template <typename R> size_t row_lds_bytes(int N);
 template <typename R> size_t col_lds_bytes(int N);
