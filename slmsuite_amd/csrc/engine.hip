@@ -164,6 +164,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_sep_min = 32;                  // smallest spot count the matrix-core form is used for
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
+    int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
     int* stats_dxy = nullptr;         // hgs_stats group 1: floor(spot_knm)
@@ -299,6 +300,7 @@ template <typename R> struct Engine : EngineBase {
         // HGS_TRACE_INIT=1: where hgs_create spends its time (developer aid, stderr)
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
+        opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!trace_init) return;
@@ -1107,6 +1109,12 @@ template <typename R> struct Engine : EngineBase {
         a.wpartial = finalize ? wpartial : nullptr; a.n_wpartial = wpartial_n; a.wscale = wscale;
         a.xcd_map = row_xcd;
         a.n_row_blocks = row_blocks;
+        {   // shifted form of the row kernel: fp32, one-row workgroups, the SLM columns within eight register slots
+            const int T = g.Pw / 16;
+            const int s0 = g.c0 / T, s1 = (g.c0 + g.Sw - 1) / T;
+            a.shifted = (sizeof(R) == 4 && g.Pw >= 4096 && s1 - s0 + 1 <= 8 && opt_row_shift) ? 1 : 0;
+            a.m0 = s0;
+        }
         return a;
     }
     // load / store: 0 = every column, 1 = active columns, 2 = active columns dilated by the spot windows

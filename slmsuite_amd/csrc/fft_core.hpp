@@ -569,6 +569,7 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
     template <int NOUT> __device__ __forceinline__ void inv_after_fwd_trail(Cx<R> (&v)[16], Cx<R>* lds, int j) {
         run<+1, false, (Sched<N>::r[Sched<N>::S - 1] == 16 ? NOUT : 16)>(v, lds, j);
     }
+    template <int NOUT> __device__ __forceinline__ void inv_trail(Cx<R> (&v)[16], Cx<R>* lds, int j) { inv_after_fwd_trail<NOUT>(v, lds, j); }
 };
 
 // ---- the 4096-point transform with a row-local first exchange ----------------------------------------
@@ -723,6 +724,7 @@ template <typename R, bool RESIDENT = true, int TS = 1> struct WgFftL {
     template <int NOUT> __device__ __forceinline__ void inv_after_fwd_trail(Cx<R> (&v)[16], Cx<R>* lds, int p) {
         mirror_flow<+1, false, NOUT>(v, lds, p);
     }
+    template <int NOUT> __device__ __forceinline__ void inv_trail(Cx<R> (&v)[16], Cx<R>* lds, int p) { mirror_flow<+1, true, NOUT>(v, lds, p); }
 };
 
 // ---- the 8192-point transform: a radix-2 step in registers + two interleaved WgFftL ----------------------
@@ -821,6 +823,7 @@ template <typename R, bool RESIDENT = true> struct WgFftL8k {
     template <int NOUT> __device__ __forceinline__ void inv_after_fwd_trail(Cx<R> (&v)[16], Cx<R>* lds, int j) {
         mirror<false, NOUT>(v, lds, j);
     }
+    template <int NOUT> __device__ __forceinline__ void inv_trail(Cx<R> (&v)[16], Cx<R>* lds, int j) { mirror<true, NOUT>(v, lds, j); }
 };
 
 // Which workgroup transform a kernel uses for length N, and where lane j's elements sit on the space side

@@ -416,6 +416,7 @@ template <typename R> struct RowArgs {
     R* wscale;
     int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
     int n_row_blocks;    // workgroups that own rows (the grid may hold one more, row-less, for the weight norm)
+    int shifted, m0;     // shifted form (row_kernel NS < 16): on / register slot of the first SLM column, c0 / (Pw / 16)
     // sparse targets: which columns the column kernel of this iteration wrote / the next one will read
     const unsigned short* load_mask;    // [b][Pw/16]: bit m of entry j = column j + m*Pw/16 is to be read ...
     const unsigned short* store_mask;   // ... / written; nullptr = every column
@@ -423,10 +424,16 @@ template <typename R> struct RowArgs {
                          // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
 };
 
-template <typename R, int N, int MODE>
+// NS < 16 (one-row workgroups only): the SLM columns occupy at most NS of the 16 register slots of the space side.  The
+// transform input is shifted circularly by m0 slots (RowArgs::m0) so that they are slots 0 .. NS-1 for every geometry;
+// by the shift theorem that multiplies frequency k by exp(-2 pi i k m0 / 16), a per-lane constant folded into the scale
+// multiplies on the GH side.  The empty slots then cost nothing: no phasor, no predicate, and the first radix-4 layer of
+// the forward transform / the last one of the inverse shrink (fwd_lead / inv_trail).
+template <typename R, int N, int MODE, int NS = 16>
 // (8192-wide rows: a workgroup is 8 waves, two per SIMD -- a second resident workgroup needs four waves per SIMD,
 //  i.e. at most 128 VGPRs)
 __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? HGS_ROW_OCC_8192 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
+    static_assert(NS == 16 || (RowCfg<N>::FPW == 1 && NS >= 4 && NS < 16), "row_kernel: shifted form is for one-row workgroups");
     using M = Math<R>;
     constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -464,7 +471,10 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
     Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw;
     const unsigned gh_lane = (unsigned)(j >> 2) * g.Sh * 4u + (unsigned)(j & 3);
     const unsigned gh_step = (unsigned)T * g.Sh;
-    const int c_lane = js - g.c0;  // SLM column of element m is c_lane + m*T
+    // SLM column of element m is c_lane + m*T (shifted form: of slot m, i.e. element m + m0)
+    const int c_lane = js - g.c0 + (NS < 16 ? a.m0 * T : 0);
+    Cx<R> om = mk<R>(1, 0);       // shift-theorem factor of this lane's frequencies (k = j mod 16)
+    if constexpr (NS < 16) om = a.tw[((a.m0 * (j & 15)) & 15) * (N / 16)];
     // sparse targets: bit m of the masks = column j + m*T is active (see ColArgs::col_list);
     // lane_mask[b][16][Pw/16] holds the 16-bit mask of lane j of a length-Pw row transform
     // The loads of the H row are predicated on the mask, so its fetch is on the critical path of every
@@ -608,18 +618,30 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 constexpr int m = m_;
                 Cx<R> h = mk<R>(0, 0);
                 if (valid && ((lmask >> m) & 1u)) h = (ghr + (size_t)m * gh_step)[gh_lane];
-                v[m] = h * sgn;
+                if constexpr (NS < 16) v[m] = h;
+                else v[m] = h * sgn;
             });
+            // (-1)^k H[k] conj(shift factor) -- in a pass of its own: the product is inline asm, and next to its load
+            // inside the per-element branch it made every load wait for the one before
+            if constexpr (NS < 16) {
+                const Cx<R> oms = om * sgn;
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = cmulc(v[m], oms); });
+            }
 #if HGS_TRACE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             HGS_T(fft.tr_n, 2);
             // (MODE 2: the previous user of the LDS image was the forward transform of the row before)
-            if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
-            else fft.inv(v, lds, j);
+            if constexpr (NS < 16) {
+                if constexpr (MODE == 2) fft.template inv_after_fwd_trail<NS>(v, lds, j);
+                else fft.template inv_trail<NS>(v, lds, j);
+            } else {
+                if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
+                else fft.inv(v, lds, j);
+            }
             const R sc = sgs * a.scale;
             if constexpr (MODE == 1) {
-                static_for<0, 16>([&](auto m_) {
+                static_for<0, NS>([&](auto m_) {
                     constexpr int m = m_;
                     const int c = c_lane + m * T;
                     if (valid && c >= 0 && c < g.Sw) {
@@ -643,7 +665,8 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
             // exp(i(phase + kernel)) = nf/|nf| (:1004-1008), so the kernel cancels and one rsqrt replaces
             // atan2 + sincos; atan2(0,0) = 0 gives the phasor 1.  The last row kernel of an
             // hgs_iterate call runs MODE 1 and writes the phase.
-            static_for<0, 16>([&](auto m_) {
+            if constexpr (NS < 16) static_for<NS, 16>([&](auto m_) { constexpr int m = m_; v[m] = mk<R>(0, 0); });
+            static_for<0, NS>([&](auto m_) {
                 constexpr int m = m_;
                 const int c = c_lane + m * T;
                 Cx<R> nf = mk<R>(0, 0);
@@ -674,13 +697,18 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
             HGS_T(fft.tr_n, 3);
-            fft.fwd(v, lds, j);
+            if constexpr (NS < 16) fft.template fwd_lead<NS>(v, lds, j);
+            else fft.fwd(v, lds, j);
             HGS_T(fft.tr_n, 4);
             if (valid) {
                 const R sc = sgn * a.scale;
+                const Cx<R> omsc = om * sc;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    if ((smask >> m) & 1u) (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
+                    if ((smask >> m) & 1u) {
+                        if constexpr (NS < 16) (ghr + (size_t)m * gh_step)[gh_lane] = cmul(v[m], omsc);
+                        else (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
+                    }
                 });
             }
 #if HGS_TRACE

@@ -1,12 +1,19 @@
 // Included by launch_row_f32.hip / launch_row_f64.hip with HGS_REAL defined.
 #include "launch.hpp"
+#include <cstdlib>
 
 namespace hgs {
 
-template <typename R, int N, int MODE>
+template <typename R, int N, int MODE, int NS = 16>
 static int launch_row_one(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
-    constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<R>);
-    auto k = row_kernel<R, N, MODE>;
+    // The shifted 4096-point kernel needs 117 VGPRs, so four workgroups fit a CU.  Measured (cfg 2 / a batch of eight):
+    // a masked launch (active columns only) gains from the fourth -- 20.5 -> 19.0 us, 103 -> 88 us -- a dense one does
+    // not (28.2 us either way; batch 174 -> 195 us: the load bursts of 1,024 rows at once).  Asking for 48 KB of LDS
+    // keeps a dense launch at three.
+    constexpr size_t lds_need = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<R>);
+    const bool masked = a.load_mask != nullptr || a.store_mask != nullptr;
+    const size_t lds = (NS < 16 && N == 4096 && !masked && lds_need < 48 * 1024) ? (size_t)48 * 1024 : lds_need;
+    auto k = row_kernel<R, N, MODE, NS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -16,8 +23,20 @@ static int launch_row_one(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
     return (int)hipGetLastError();
 }
 
+// shifted form (row_kernel NS = 8): fp32, one-row workgroups, SLM within eight of the sixteen register slots (RowArgs::shifted, m0)
 template <typename R, int N>
 static int launch_row_n(int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a) {
+#ifdef HGS_REAL_IS_FLOAT
+    if constexpr (N >= 4096) {
+        if (a.shifted) {
+            switch (mode) {
+                case 0: return launch_row_one<R, N, 0, 8>(grid, s, a);
+                case 1: return launch_row_one<R, N, 1, 8>(grid, s, a);
+                case 2: return launch_row_one<R, N, 2, 8>(grid, s, a);
+            }
+        }
+    }
+#endif
     switch (mode) {
         case 0: return launch_row_one<R, N, 0>(grid, s, a);
         case 1: return launch_row_one<R, N, 1>(grid, s, a);

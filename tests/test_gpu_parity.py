@@ -661,8 +661,10 @@ def test_sparse_spot_feedback_matches_general_path(method, feedback, kw):
     assert np.count_nonzero(a.weights) == np.count_nonzero(b.weights) == xy.shape[1]
     for grp in ("computational", "computational_spot"):
         for nme in STAT_NAMES:
-            np.testing.assert_allclose(a.stats["stats"][grp][nme][:6], b.stats["stats"][grp][nme][:6], rtol=3e-4, atol=1e-7,
-                                       err_msg=f"{grp}.{nme}")
+            # (pkpk_err = N (max - min) of power errors of ~1e-4 each: a difference of nearly equal numbers, the two paths'
+            #  2e-7 rounding differences show up as 2e-3 of it once the run has converged)
+            np.testing.assert_allclose(a.stats["stats"][grp][nme][:6], b.stats["stats"][grp][nme][:6],
+                                       rtol=5e-3 if nme == "pkpk_err" else 3e-4, atol=1e-7, err_msg=f"{grp}.{nme}")
 
 
 def test_batch_with_different_sparse_targets_full_size():
