@@ -638,7 +638,7 @@ def main():
                 # which fused column kernel ran is the engine's choice (tile-resident, per column, sparse list):
                 # count both and keep the one that was launched
                 subs = {"col_tile": "col_tile_kernel", "col_fused": "col_fused_kernel",
-                        "row": "row_kernel<" + ("float" if args.dtype == "f32" else "double") + f", {prob.shape[1]}, 2>"}
+                        "row": "row_kernel<" + ("float" if args.dtype == "f32" else "double") + f", {prob.shape[1]}, 2"}   # (<R, N, MODE 2[, NS]>)
                 res, tnote = pmc_traffic(args, subs)
                 if res is not None:
                     res["col"] = max((res["col_tile"], res["col_fused"]), key=lambda r: r["launches"])

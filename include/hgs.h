@@ -10,7 +10,8 @@
  * Conventions
  *   - every function returns 0 on success, a negative hgs_status otherwise; the message of the
  *     last error of the calling thread is available from hgs_last_error();
- *   - an engine handle is single-threaded; different handles are independent;
+ *   - an engine handle is single-threaded; different handles are independent; every entry point makes the
+ *     engine's HIP device current for the duration of the call and restores the caller's current device;
  *   - the engine owns all device memory and one HIP stream; host buffers are caller-owned,
  *     C-contiguous, in the reference's natural layout (row-major, centred zero order), of the
  *     engine's real type (float when real_bytes == 4, double when 8; complex = 2 reals);

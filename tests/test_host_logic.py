@@ -348,7 +348,7 @@ def test_asan_build_of_the_shim_is_clean():
     if not os.path.exists(os.path.join(ROOT, "slmsuite_amd", "libhgs.so")):
         pytest.skip("libhgs.so not built")
     # made on demand (a file target: nothing happens when it is up to date; one -O1 compile of engine.hip otherwise)
-    mk = subprocess.run(["make", "-C", os.path.join(ROOT, "slmsuite_amd", "csrc"), "asan"], capture_output=True, text=True)
+    mk = subprocess.run(["make", "-C", os.path.join(ROOT, "slmsuite_amd", "csrc"), "-j8", "asan"], capture_output=True, text=True)
     if mk.returncode != 0 or not os.path.exists(asan_lib):
         pytest.skip("ASan build of the shim failed: " + mk.stderr[-300:])
     rt = subprocess.run(["hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
