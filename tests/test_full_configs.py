@@ -275,6 +275,62 @@ def test_cfg4_full_size_against_direct_summation(D, sep):
     h._release_engine()
 
 
+def test_cfg4_configured_run_reaches_its_end_state():
+    """
+    BASELINE config 4 as configured: N = 1e4 spots, S = 1152 x 1920, WGS-Kim (phase fixed at 10), **200 iterations**.
+    No CPU restatement can follow that (2.2e10 kernel evaluations per transform), and two fp32 arithmetics do not stay
+    together either: the matrix-core path (phase tables in double) and the direct kernels (fp32 phase polynomial, |phi| up to
+    thousands of radians at this SLM size) each match float64 direct summation per operator
+    (test_cfg4_full_size_against_direct_summation) yet are 1.4e-3 apart on the spot amplitudes after 14 free-phase / fixed-phase
+    iterations (reported).  The end state is therefore pinned by what is determinate: the flag history; the farfield the run
+    ends on is the float64 direct sum over all 2.2 M pixels of its own final phase (64 random spots); and the weighted loop
+    did its job -- the spot powers are more uniform after 200 iterations than after 12 (0.78 -> 0.83 for these 1e4 densely
+    packed spots).
+    """
+    N, D = 10000, 2
+    slm = SimpleSLM(SLM, pitch_um=(8, 8), wav_um=0.78)
+
+    def make(sep):
+        hh = CompressedSpotHologram(_cfg4_spots(D, N), basis="kxy", cameraslm=SimpleFourierSLM(slm), engine_options={L.OPT_SEPARABLE: sep})
+        hh.reset_phase(synth.seed_phase(4, SLM))
+        return hh
+
+    def uniformity(hh):
+        p = np.abs(hh.farfield.astype(np.complex128)) ** 2 / np.asarray(hh.target, dtype=np.float64) ** 2
+        return 1 - (p.max() - p.min()) / (p.max() + p.min())
+
+    h, hd = make(1), make(0)
+    h.optimize("WGS-Kim", maxiter=12, verbose=False)
+    u12 = uniformity(h)
+    h.optimize("WGS-Kim", maxiter=2, verbose=False)
+    hd.optimize("WGS-Kim", maxiter=14, verbose=False)
+    e_paths = dict(spot_amp=rel_l2(np.abs(h.farfield), np.abs(hd.farfield)), weights=rel_l2(h.weights, hd.weights),
+                   phase=phase_rel_l2(h.phase, hd.phase))
+    hd._release_engine()
+    h.optimize("WGS-Kim", maxiter=186, verbose=False)
+    assert h.iter == 200 and h.flags["fixed_phase"] and sum(bool(x) for x in h.stats["flags"]["fixed_phase"]) == 190
+    u200 = uniformity(h)
+    # the farfield of the final phase by float64 direct summation, 64 spots
+    S = SLM[0] * SLM[1]
+    spots = np.sort(np.random.default_rng(45).choice(N, 64, replace=False))
+    phase = h.phase.astype(np.float64).ravel()
+    amp = np.full(S, float(h.amp)) if np.isscalar(h.amp) else np.asarray(h.amp, dtype=np.float64).ravel()
+    ref = np.zeros(len(spots), dtype=np.complex128)
+    allp = np.arange(S)
+    for c0 in range(0, S, 1 << 18):
+        pp = allp[c0:c0 + (1 << 18)]
+        ref += np.sum(amp[pp][None, :] * np.exp(1j * (phase[pp][None, :] - _kernel_phase(h, spots, pp))), axis=1)
+    got = h.farfield.astype(np.complex128)[spots]
+    scale = np.real(np.vdot(ref, got)) / np.real(np.vdot(ref, ref))
+    err_end = rel_l2(got, scale * ref)
+    report("cfg4 configured run (200 it): paths at 14 it, end state vs float64 direct sum, uniformity", end_farfield=err_end,
+           uniformity_12=u12, uniformity_200=u200, **{f"paths14_{k}": v for k, v in e_paths.items()})
+    assert e_paths["spot_amp"] < 1e-2, e_paths              # same run, two arithmetics: a sanity bound, not a parity claim
+    assert err_end < 2e-5
+    assert u200 > u12, (u12, u200)
+    h._release_engine()
+
+
 # ---- cfg 4's DFT-grid companion (SURVEY 8d): 1e4 spots at distinct pixels of an 8192^2 pad, WGS-Kim ---------
 def _grid_spots(shape, box, n):
     lin = np.unique((synth.uniform01(4, (4 * n,), stream=7) * box * box).astype(np.int64))

@@ -178,20 +178,29 @@ def test_trajectory_matches_reference(name):
     h.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, stat_groups=["computational"],
                **meta["kwargs"])
     assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
-    # dense pixel-wise WGS is chaotic: the reference's own fp32 and fp64 runs are 5.8e-2 apart after
-    # these 8 bodies, so the trajectory is only loosely pinned; per-step tests are the gate
-    tol = 2e-5 if "WGS" not in meta["method"] else 0.2
+    # dense pixel-wise WGS is chaotic: the yardstick for the end state is how far the REFERENCE's own fp32
+    # and fp64 runs of this fixture pair have drifted apart after the same 8 bodies (holo_*_f64.npz), not a constant;
+    # per-step tests are the gate
+    tol_p = tol_a = 2e-5
+    srt = 2e-3
+    if "WGS" in meta["method"]:
+        _, gold64 = load_golden(name.replace("_f32", "_f64"))
+        tol_p = 2 * phase_rel_l2(gold["final_phase"], gold64["final_phase"])
+        tol_a = 2 * rel_l2(gold["final_ampff"], gold64["final_ampff"])
+        srt = 2 * max(float(np.max(np.abs(gold[f"stats_computational_{n}"] / gold64[f"stats_computational_{n}"] - 1)))
+                      for n in ("efficiency", "uniformity", "pkpk_err", "std_err"))
+        report(f"trajectory {name}: 2 x the reference's fp32-fp64 drift", phase=tol_p, amp_ff=tol_a, stats_rtol=srt)
     ep, ea = phase_rel_l2(h.phase, gold["final_phase"]), rel_l2(h.amp_ff, gold["final_ampff"])
     report(f"trajectory {name}", phase=ep, amp_ff=ea)
-    assert ep < tol and ea < tol
+    assert ep < tol_p and ea < tol_a, (ep, tol_p, ea, tol_a)
     for n in ("efficiency", "uniformity", "pkpk_err", "std_err"):
         np.testing.assert_allclose(h.stats["stats"]["computational"][n], gold[f"stats_computational_{n}"],
-                                   rtol=0.3 if "WGS" in meta["method"] else 2e-3, atol=1e-6)
+                                   rtol=srt, atol=1e-6)
     # fused mode must walk the same flag history
     h2 = Hologram(**hologram_inputs(meta))
     h2.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, **meta["kwargs"])
     assert [bool(x) for x in h2.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
-    assert phase_rel_l2(h2.phase, gold["final_phase"]) < tol
+    assert phase_rel_l2(h2.phase, gold["final_phase"]) < tol_p
 
 
 @pytest.mark.parametrize("mode", ["fused", "stepwise"])
@@ -402,9 +411,18 @@ def test_cfg5_mraf_8192_steps(dtype):
         ep = phase_rel_l2(h.phase, o.phase)
         ew = rel_l2(h.weights, o.weights)
         report(f"cfg5 {method} {np.dtype(dtype).name} {n} bodies vs oracle", phase=ep, weights=ew)
-        # WGS body 2 divides by speckle amplitudes inside the signal region: loose bound in fp32
-        assert ep < (tol if method == "GS" else (2e-3 if dtype is np.float32 else 1e-9)), (method, ep)
-        assert ew < (tol if method == "GS" else (1e-3 if dtype is np.float32 else 1e-9)), (method, ew)
+        if method == "GS" or dtype is np.float64:
+            assert ep < (tol if method == "GS" else 1e-9) and ew < (tol if method == "GS" else 1e-9), (method, ep, ew)
+        else:
+            # WGS body 2 divides by speckle amplitudes inside the signal region, so two fp32 runs part ways at once.  The
+            # yardstick is the algorithm's own sensitivity at this point, not a constant: the reference arithmetic's fp32
+            # run against its fp64 run from the same seed (7.8e-5 here; the engine is 9.4e-5 from the fp32 oracle)
+            o64 = orc.OracleHologram(target.astype(np.float64), phase=phase0.astype(np.float64), slm_shape=slm, dtype=np.float64)
+            o64.optimize(method, maxiter=n, mraf_factor=0.5, populate=False)
+            yp, yw = phase_rel_l2(o.phase, o64.phase), rel_l2(o.weights, o64.weights)
+            report(f"cfg5 {method} float32 {n} bodies: oracle fp32 vs oracle fp64", phase=yp, weights=yw)
+            # (weights: 3 x -- the fused rule's x^p runs on the 1-ulp hardware log2 / exp2)
+            assert ep < 2 * yp and ew < 3 * yw, (method, ep, yp, ew, yw)
 
 
 # ---- persistent-state semantics ----------------------------------------------
