@@ -769,6 +769,17 @@ template <typename R> struct Engine : EngineBase {
         return r;
     }
 
+    // per-column fused launch: rule-specialised kernel where the pass is plain (fp32, no statistics, no extras)
+    int fused_launch(int phase_mode, dim3 grid, const ColArgs<R>& a) {
+        if constexpr (sizeof(R) == 4) {
+            const bool plain = !a.do_stats && !a.cp.mraf && !a.cp.nog_pass && !a.cp.weights_only && a.cp.nog == nullptr;
+            if (plain && opt_tile_rule) {
+                if (!a.cp.do_update) return launch_fused_rule2(g.Ph, phase_mode, grid, stream, a);
+                if (a.cp.method == HGS_WGS_LEONARDO || a.cp.method == HGS_WGS_KIM) return launch_fused_rule1(g.Ph, phase_mode, grid, stream, a);
+            }
+        }
+        return launch_fused<R>(g.Ph, phase_mode, grid, stream, a);
+    }
     // (the tile-resident kernel is fp32 only; this branch is never taken for double)
     static int tile_rule(int N, int phase, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
         return launch_tile_rule(N, phase, rule, grid, s, a, m0);
@@ -1515,7 +1526,7 @@ template <typename R> struct Engine : EngineBase {
                                        stat_partial, stat_nslots);
                     LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                 } else {
-                    LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                    LCHK(fused_launch(phase_mode, dim3(blocks, B), a));
                 }
                 return 0;
             });
@@ -1638,7 +1649,7 @@ template <typename R> struct Engine : EngineBase {
                         const int blocks = list_blocks(n_active_max);
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
-                        else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
+                        else LCHK(fused_launch(phase_mode, dim3(blocks, B), a));
                     } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && opt_tile) {
                         wpartial_n = tile_blocks;
                         const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;
@@ -1656,7 +1667,7 @@ template <typename R> struct Engine : EngineBase {
                         }
                     } else {
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
-                        else LCHK(launch_fused<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
+                        else LCHK(fused_launch(phase_mode, dim3(col_blocks, B), a));
                     }
                     if (pass == -1) {
                         if (int e = reduce(wpartial, wpartial_n, sums + 1 * B)) return e;

@@ -915,7 +915,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, (sizeof(R) == 8 ? 2 : N >= 8192 ? HG
 // Weight rule in log domain for Leonardo/Kim:
 //   (|F| * c / T)^-p = exp2(-p * (log2(|F|^2)/2 + log2 c - log2 T)),  T == 0 -> 1 (:1841)
 // =====================================================================================================
-template <typename R, int N, int PHASE, bool STATS = false>
+// RULE (as in col_tile_kernel): 0 = method, update switch, MRAF / Nogrette-sum / forward-only flags read from CParams;
+// 1 = plain WGS-Leonardo / WGS-Kim update compiled in; 2 = plain pass without a weight update.  "Plain" = none of the
+// extras.  The latency-bound launches (column lists, small grids: one wave per SIMD) pay every uniform branch in full.
+template <typename R, int N, int PHASE, bool STATS = false, int RULE = 0>
 __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel(ColArgs<R> a) {
     using M = Math<R>;
     constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
@@ -934,6 +937,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
+    const bool do_upd = RULE == 1 ? true : (RULE == 2 ? false : cp.do_update != 0);
+    const bool x_mraf = RULE != 0 ? false : cp.mraf != 0;
+    const bool x_nog = RULE != 0 ? false : cp.nog_pass != 0;
+    const bool x_wonly = RULE != 0 ? false : cp.weights_only != 0;
     const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
@@ -985,7 +992,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const R* tc = a.t + cb;
         // one (wave-uniform where T >= 64) branch around the whole group: a select per element turns every load into
         // its own predicated dword access instead of four 16-byte ones
-        const bool need_t = cp.do_update || STATS || cp.mraf;
+        const bool need_t = do_upd || STATS || x_mraf;
         if (col_valid(q)) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = wc[lane_pos<T>(j, m)]; });
             if (need_t) static_for<0, 16>([&](auto m_) { constexpr int m = m_; tr[m] = tc[lane_pos<T>(j, m)]; });
@@ -1056,23 +1063,23 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             [&]() {
             // wave-uniform skip of pixels with zero weight and zero target (see col_tile_kernel)
             if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
-                __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((cp.do_update || STATS || cp.mraf) && tr[m] != (R)0)) == 0) {
+                __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || ((do_upd || STATS || x_mraf) && tr[m] != (R)0)) == 0) {
                 vm = mk<R>(0, 0);
-                if (cp.nog_pass && vcol) acc_w += (R)1;      // T == 0 -> fc = 1 (:1841)
+                if (x_nog && vcol) acc_w += (R)1;      // T == 0 -> fc = 1 (:1841)
                 return;
             }
             const Cx<R> F = vm * sc;
             const R p2 = F.x * F.x + F.y * F.y;
-            if (cp.nog_pass) {                              // Nogrette: sum of fc = feedback / target over all pixels
+            if (x_nog) {                                    // Nogrette: sum of fc = feedback / target over all pixels
                 if (vcol) acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
                 vm = mk<R>(0, 0);
                 return;
             }
             const R wraw = wr[m];
             R wv = wraw * wsc;
-            if (cp.do_update) {
+            if (do_upd) {
                 const R t = tr[m];
-                if (cp.method == M_LEONARDO || cp.method == M_KIM) {
+                if (RULE == 1 || cp.method == M_LEONARDO || cp.method == M_KIM) {
                     // evaluated for every lane and selected (a branch per pixel splits the pass into 16 blocks):
                     // T == 0 -> factor 1 (:1841); inf (:1840,:1867) and nan (:1843) -> 1
                     // (fp64: the rule is some hundred instructions of double log2 / exp2 -- worth the branch)
@@ -1109,7 +1116,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
             vm = mk<R>(wv * co * sgn, wv * si * sgn);
-            if (cp.mraf) {                                  // mixed-region amplitude freedom (:1606-1653)
+            if (x_mraf) {                                   // mixed-region amplitude freedom (:1606-1653)
                 const R t = tr[m];
                 if (is_nan(t)) {
                     const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
@@ -1127,7 +1134,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         if constexpr (!LEAN) {
             static_for<0, 16>(cons);
             if constexpr (STATS) sacc.flush(stat_slot);
-            if (cp.do_update && w_changed && vcol) {
+            if (do_upd && w_changed && vcol) {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
             }
         } else {
@@ -1136,7 +1143,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 constexpr int g0 = 4 * decltype(g_)::value;
                 w_changed = false;
                 static_for<0, 4>([&](auto i_) { cons(std::integral_constant<int, g0 + decltype(i_)::value>{}); });
-                if (cp.do_update && w_changed && vcol) {
+                if (do_upd && w_changed && vcol) {
                     static_for<0, 4>([&](auto i_) { constexpr int m = g0 + i_; wc[lane_pos<T>(j, m)] = wr[m]; });
                 }
             });
@@ -1152,10 +1159,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         if constexpr (LEAN) {
             // back from the parking slots; whatever comes next -- the inverse, or (forward-only passes) the next
             // column's forward transform -- scatters into other lanes' slots
-            if (!cp.weights_only) static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T]; });
+            if (!x_wonly) static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T]; });
             __syncthreads();
         }
-        if (!cp.weights_only) {
+        if (!x_wonly) {
             fft.inv_after_fwd(v, lds, j);
             if constexpr (GBUF) {
                 const Buf bg = g_buf(q, ct, c4);
@@ -1176,7 +1183,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         }
     }
     if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
-    if (cp.do_update) {
+    if (do_upd) {
         const double s = block_sum((double)acc_w, scratch);
         if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }

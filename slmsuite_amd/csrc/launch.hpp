@@ -21,6 +21,10 @@ template <typename R> int launch_tile_extras_stats(int N, int phase_mode, dim3 g
 // ... and with the weight rule compiled in (rule 1: WGS-Leonardo / WGS-Kim update, 2: no update; no statistics, no extras)
 int launch_tile_rule(int N, int phase_mode, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
 
+// per-column fused kernel with the rule compiled in (fp32, no statistics, none of the MRAF / Nogrette / forward-only extras)
+int launch_fused_rule1(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<float>& a);    // Leonardo / Kim update
+int launch_fused_rule2(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<float>& a);    // no update
+
 // blocks of the transform kernels resident per CU are bounded by LDS; exposed for grid sizing
 template <typename R> size_t row_lds_bytes(int N);
 template <typename R> size_t col_lds_bytes(int N);
