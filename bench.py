@@ -17,6 +17,8 @@ Workloads (``--workload``):
   cfg1       Hologram 512 x 512 on a 512 x 512 SLM, GS (BASELINE configs[0], the reference's CPU-runnable case)
   cfg2dense  cfg 2 geometry, dense random image target (nothing to skip)
   cfg4       CompressedSpotHologram, 1e4 spots, SLM 1152 x 1920, D = 2, WGS-Kim (cfg4d3: D = 3) -- MFMA bound
+  cfg4zern   CompressedSpotHologram on a basis with a cross term (ANSI 2, 1, 4, 3, 5), 1e3 spots: not separable, the
+             direct kernels (VALU / transcendental bound; roofline against the 157.3 TFLOP/s fp32 vector peak)
   cfg4grid   the DFT-grid companion of cfg 4: SpotHologram with 1e4 spots at distinct pixels of an 8192^2 pad, WGS-Kim
   cfg5mraf   Hologram with MRAF (NaN noise box 3072^2, image 2048^2) on an 8192^2 pad; --dtype f32|f64,
              --method GS|WGS-Leonardo
@@ -80,7 +82,12 @@ SPOT_WORKLOADS = {
 }
 IMAGE_WORKLOADS = {"cfg1": ((512, 512), (512, 512)), "cfg2dense": ((4096, 4096), (1152, 1920)), "cfg5mraf": ((8192, 8192), (1152, 1920))}
 REFBENCH_METHODS = ("GS", "WGS-Leonardo", "WGS-Kim", "WGS-Nogrette")      # test_algorithms.py:121
-COMPRESSED_WORKLOADS = {"cfg4": 2, "cfg4d3": 3}
+COMPRESSED_WORKLOADS = {"cfg4": 2, "cfg4d3": 3, "cfg4zern": 5}
+# cfg4zern: a basis with a cross term (ANSI 2, 1, 4, 3, 5: tilts, focus, both astigmatisms) does not factor into x and y
+# parts, so it runs the direct kernels (exp(i phi) regenerated per pixel and spot, VALU / transcendental bound) -- the
+# shape of the CompressedSpotHologram that wavefront_calibrate_zernike re-optimises (cameraslms.py:1840-1930)
+ZERN_BASIS = [2, 1, 4, 3, 5]
+VALU_F32_PEAK = 157.3e12   # flop/s, packed fp32 vector peak (MI355X_MICROARCH.md)
 # cfg 4's DFT-grid companion: the same number of spots at distinct pixels of an 8192^2 grid, inside the
 # centred 3360^2 box that |k| <= 0.02 rad spans there (pitch 8 um, 0.78 um), WGS-Kim
 VECTOR_WORKLOADS = {"cfg4grid": ((8192, 8192), (1152, 1920), 3360)}
@@ -108,7 +115,7 @@ def parse():
     ap.add_argument("--workload", default="cfg2", choices=ALL_WORKLOADS)
     ap.add_argument("--method", default=None)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--spots", type=int, default=10000, help="cfg4: number of spots")
+    ap.add_argument("--spots", type=int, default=None, help="cfg4 / cfg4grid: number of spots (default 10000; cfg4zern: 1000)")
     ap.add_argument("--cpu-iters", type=int, default=None, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (self-test)")
@@ -126,6 +133,8 @@ def parse():
     if a.steps is None:
         a.steps = 20 if a.workload == "refbench" else 200
     a.reps = max(1, a.reps)
+    if a.spots is None:
+        a.spots = 1000 if a.workload == "cfg4zern" else 10000
     if a.batch is None:
         a.batch = 8 if a.workload == "cfg3" else 1
     if a.method is None:
@@ -255,9 +264,9 @@ class CompressedProblem:
         self.D = COMPRESSED_WORKLOADS[args.workload]
         self.slm = (1152, 1920)
         self.N = args.spots
-        self.v = compressed_spots(self.D, self.N)
         slm = SimpleSLM(self.slm, pitch_um=(8, 8), wav_um=0.78)
-        self.h = CompressedSpotHologram(self.v, basis="kxy", cameraslm=SimpleFourierSLM(slm),
+        self.v, basis = compressed_vectors(args.workload, self.N, SimpleFourierSLM(slm))
+        self.h = CompressedSpotHologram(self.v, basis=basis, cameraslm=SimpleFourierSLM(slm),
                                         dtype=np.float32 if args.dtype == "f32" else np.float64)
         self.h.reset_phase(synth.seed_phase(4, self.slm))
         self.engine = self.h._get_engine()
@@ -329,6 +338,19 @@ def compressed_spots(D, N):
     if D == 3:
         v[2] *= 1e-6
     return v
+
+
+def compressed_vectors(workload, N, fourier_slm):
+    """(spot_vectors, basis) of a compressed workload: kxy vectors, or Zernike coefficients on ZERN_BASIS (cfg4zern:
+    the cfg 4 positions with depth, plus up to half a wave of either astigmatism per spot)."""
+    D = COMPRESSED_WORKLOADS[workload]
+    if workload != "cfg4zern":
+        return compressed_spots(D, N), "kxy"
+    from slmsuite_amd import synth
+    from slmsuite_amd.holography import toolbox
+    zern, _ = toolbox.convert_vector_zernike(compressed_spots(3, N), "kxy", fourier_slm)      # rows: ANSI 2, 1, 4
+    astig = (synth.uniform01(4, (2, N), 10) * 2 - 1) * np.pi
+    return np.vstack([zern, astig]), np.array(ZERN_BASIS)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -404,13 +426,15 @@ def cpu_baseline(args):
         n_s = 96
         slm_shape = (1152, 1920)
         slm = SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78)
-        v = compressed_spots(D, args.spots)[:, :n_s]
-        zern, _ = toolbox.convert_vector_zernike(v, "kxy", SimpleFourierSLM(slm))
+        v, basis = compressed_vectors(w, args.spots, SimpleFourierSLM(slm))
+        v = v[:, :n_s]
+        zern = v if w == "cfg4zern" else toolbox.convert_vector_zernike(v, "kxy", SimpleFourierSLM(slm))[0]
         xg, yg = toolbox.process_grid(slm)
         sc = slm.get_source_zernike_scaling()
         sx, sy = (sc, sc) if np.isscalar(sc) else (sc[0], sc[1])
+        kw_basis = {"zernike_basis": basis} if w == "cfg4zern" else {}
         o = orc.OracleCompressedSpotHologram(zern, np.asarray(xg) * sx, np.asarray(yg) * sy,
-                                             phase=synth.seed_phase(4, slm_shape), dtype=dt)
+                                             phase=synth.seed_phase(4, slm_shape), dtype=dt, **kw_basis)
         o.kernel()                                  # the reference caches K too (_spots.py:595-636)
         o.optimize(args.method, maxiter=1, populate=False)
         t0 = time.perf_counter()
@@ -596,7 +620,23 @@ def main():
         value = iters_total / wall
         want_pmc = args.pmc if args.pmc is not None else (1 if (world == 1 and dist is None) else 0)
         roof = None
-        if compressed and prof is not None:
+        if compressed and prof is not None and args.workload == "cfg4zern":
+            # direct kernels: one evaluation of exp(+-i phi_n(p)) and one complex MAC per (spot, pixel) and direction;
+            # (2 D + 8 + 2) flop each (phase polynomial, sin, cos, complex MAC)
+            S = prob.slm[0] * prob.slm[1]
+            flop_launch = (2.0 * prob.D + 10.0) * prob.N * S
+            n_l = prof["col_fwd"]["launches"] + prof["col_inv"]["launches"]
+            dur = (prof["col_fwd"]["ms"] + prof["col_inv"]["ms"]) * 1e-3 / max(1, n_l)
+            ach = flop_launch / dur
+            roof = {"bound": "valu", "kernel": "c_n2f / c_f2n direct kernels (phase polynomial + v_sin / v_cos + complex MAC per pixel "
+                                               "and spot, nothing tabulated), one timed unit per transform direction",
+                    "achieved": ach / 1e12, "peak": VALU_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / VALU_F32_PEAK,
+                    "traffic": None, "traffic_note": "VALU / transcendental bound: 2 N S kernel evaluations per iteration, "
+                                                     "compulsory traffic ~ 35 MB",
+                    "flop_per_launch": flop_launch, "launch_us": dur * 1e6, "launches": n_l,
+                    "evaluations_per_s": prob.N * S / dur,
+                    "timing": "HIP events per transform on the engine stream, second pass of K steps"}
+        elif compressed and prof is not None:
             # dominant kernel: the two complex GEMMs (cgemm_kouter), timed under col_fwd / col_inv together with
             # their small helper kernels; flop per GEMM launch = 8 N S (complex MAC = 8 real flop)
             S = prob.slm[0] * prob.slm[1]

@@ -188,15 +188,18 @@ int hgs_sync(hgs_engine* e);
  * HGS_OPT_FORCE_STEPWISE (default 0): hgs_iterate / hgs_iterate_stats loop the three general operators
  *   (materialised farfield) even where a fused kernel exists -- the reference's own op sequence; used by tests.
  * HGS_OPT_TILE_KERNEL (default 1): use the tile-resident fused column kernel where it applies (fp32, pad_h >= 4096).
- * HGS_OPT_SEPARABLE (default 1), HGS_OPT_SEPARABLE_MIN_SPOTS (default 32): kind 1, run the two transforms as
+ * HGS_OPT_SEPARABLE (default 1), HGS_OPT_SEPARABLE_MIN_SPOTS (default 96): kind 1, run the two transforms as
  *   complex GEMMs on the matrix cores when the basis and the grid factorise; 0 forces the direct kernels.
+ * HGS_OPT_RUN_KERNELS (default 1): kind 1, fp32, regular pixel grid and a phase polynomial of degree <= 2 (any basis of
+ *   tilts, focus and astigmatisms, separable or not): the direct transforms advance exp(i phi) along runs of 16 pixels by
+ *   a two-term recurrence instead of evaluating the polynomial, sin and cos per pixel; 0 forces the per-pixel kernels.
  * Options are per engine and take effect at the next call; nothing is read from the environment after
  * hgs_create (which reads the developer grid-size overrides HGS_ROW_BLOCKS / HGS_COL_BLOCKS / HGS_TILE_BLOCKS /
  * HGS_ROW_XCD once).
  * HGS_OPT_ROCTX (default 0): roctx ranges (hgs_iterate, hgs_nearfield2farfield, hgs_farfield_constraint,
  *   hgs_farfield2nearfield) for rocprofv3 --marker-trace; the roctx library is dlopen'ed on first use. */
 enum { HGS_OPT_SPARSE_COLUMNS = 1, HGS_OPT_FORCE_STEPWISE = 2, HGS_OPT_TILE_KERNEL = 3, HGS_OPT_SEPARABLE = 4,
-       HGS_OPT_SEPARABLE_MIN_SPOTS = 5, HGS_OPT_ROCTX = 6 };
+       HGS_OPT_SEPARABLE_MIN_SPOTS = 5, HGS_OPT_ROCTX = 6, HGS_OPT_RUN_KERNELS = 7 };
 int hgs_set_option(hgs_engine* e, int option, int value);
 
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */

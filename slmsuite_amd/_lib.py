@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HGS_LIB", os.path.join(_HERE, "libhgs.so"))   # HGS_L
 HGS_OK, HGS_ERR_ARG, HGS_ERR_DEVICE, HGS_ERR_STATE, HGS_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 # hgs_set_option
 OPT_SPARSE_COLUMNS, OPT_FORCE_STEPWISE, OPT_TILE_KERNEL, OPT_SEPARABLE, OPT_SEPARABLE_MIN_SPOTS, OPT_ROCTX = 1, 2, 3, 4, 5, 6
+OPT_RUN_KERNELS = 7
 
 # array selectors (include/hgs.h)
 (PHASE, AMP, AMP_SCALAR, PROP_KERNEL, TARGET, WEIGHTS, PHASE_FF, FARFIELD, AMP_FF, SPOT_INDEX,

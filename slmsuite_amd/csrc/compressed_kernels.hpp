@@ -147,20 +147,34 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_n2f_par
 }
 
 // ff_raw[n] = sum over blocks of the partials / sqrt(S), plus per-block partial of sum |ff_raw|^2.
-// grid = (ceil(N/256), batch)
-template <typename R> __global__ void c_n2f_reduce(CArgs<R> a, double* norm_partial) {
+// grid = (ceil(N / 64), batch), block = 1024: 64 spots x 16 slices of the block list (a thread per spot walking
+// thousands of partials one dependent load at a time was a 0.5 ms floor under every direct transform)
+constexpr int C_RED_SPOTS = 64, C_RED_SLICES = 16;
+template <typename R> __global__ __launch_bounds__(C_RED_SPOTS * C_RED_SLICES) void c_n2f_reduce(CArgs<R> a, double* norm_partial) {
     __shared__ double scratch[16];
+    __shared__ double red[C_RED_SLICES][C_RED_SPOTS][2];
     const int b = blockIdx.y;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tx = threadIdx.x % C_RED_SPOTS, ty = threadIdx.x / C_RED_SPOTS;
+    const int n = blockIdx.x * C_RED_SPOTS + tx;
     const R inv_sqrt_s = (R)(1.0 / ::sqrt((double)a.S));
-    double p2 = 0;
+    double sr = 0, si = 0;
     if (n < a.N) {
-        double sr = 0, si = 0;
-        for (int k = 0; k < a.nblocks; ++k) {
-            const Cx<R> v = a.partial[((size_t)b * a.nblocks + k) * a.N + n];
+        const Cx<R>* src = a.partial + (size_t)b * a.nblocks * a.N + n;
+#pragma unroll 8
+        for (int k = ty; k < a.nblocks; k += C_RED_SLICES) {
+            const Cx<R> v = src[(size_t)k * a.N];
             sr += (double)v.x;
             si += (double)v.y;
         }
+    }
+    red[ty][tx][0] = sr;
+    red[ty][tx][1] = si;
+    __syncthreads();
+    double p2 = 0;
+    if (ty == 0 && n < a.N) {
+        sr = si = 0;
+#pragma unroll
+        for (int q = 0; q < C_RED_SLICES; ++q) { sr += red[q][tx][0]; si += red[q][tx][1]; }
         const Cx<R> f = mk<R>((R)sr * inv_sqrt_s, (R)si * inv_sqrt_s);
         a.ff[(size_t)b * a.N + n] = f;
         p2 = (double)f.x * f.x + (double)f.y * f.y;
@@ -231,6 +245,171 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_f2n(CAr
                 a.phase[(size_t)b * a.S + p] = ph;
             }
         }
+    }
+}
+
+// =====================================================================================================
+// Run kernels (fp32, regular pixel grid, phase polynomial of degree <= 2 in the canonical form).
+// A lane owns CR_RUN consecutive pixels of one SLM row.  Along such a run the kernel value of spot n obeys
+//     E(x + h) = E(x) D(x),   D(x + h) = D(x) C_n,   C_n = exp(i 2 c3 h^2)   (degree 1: D = exp(i c1 h) per spot, C = 1)
+// so one evaluation costs two packed complex products (and the accumulate) instead of a phase polynomial, a range
+// reduction, v_sin and v_cos (quarter rate): 7-8 instead of 22 issue slots per evaluation.  The start values
+// E(x0), D(x0) of every (lane, spot) are formed from the polynomial in DOUBLE and reduced to turns there, i.e. they are
+// exact to fp32 rounding where the direct kernels (and the reference's complex64 kernel) carry the fp32 error of a phase
+// of hundreds of radians; the recurrence adds at most ~16 roundings of 6e-8.
+// Work split: pixel runs over grid.x (one wave per workgroup: 2,160 of them for 1152 x 1920, too few to balance 1,024
+// SIMDs) times grid.z chunks of the spot list; the inverse direction leaves one partial nearfield per chunk and a small
+// kernel adds them in a fixed order (no atomics: results do not depend on the schedule).
+// =====================================================================================================
+constexpr int CR_RUN = 16;
+struct CRunRec {          // one spot, 64 bytes: canonical coefficients in double, C_n (degree 2) / D_n (degree 1)
+    double c[6];
+    float cr, ci, pad0, pad1;
+};
+struct CRunArgs {
+    CArgs<float> a;
+    const CRunRec* rec;   // [N]
+    const double* ys;     // [H] row coordinate
+    double x0, hx;        // column coordinate = x0 + col * hx
+    int H, W, rpr;        // runs per row = ceil(W / CR_RUN)
+    int n_per;            // spots per grid.z chunk
+    Cx<float>* nf_part;   // [b][gridDim.z][S] partial nearfields of c_f2n_run
+};
+
+__device__ __forceinline__ v2f cis_turns(double turns) {
+    const float t = (float)__builtin_amdgcn_fract(turns);
+    return (v2f){__builtin_amdgcn_cosf(t), __builtin_amdgcn_sinf(t)};
+}
+// acc + a * conj(b)
+__device__ __forceinline__ v2f cmac_conj(v2f acc, v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int DEG> __device__ __forceinline__ void run_start(const CRunRec& r, double xd, double yd, double q, double hx,
+                                                             v2f& E, v2f& D) {
+    constexpr double INV2PI = 0.15915494309189533577;
+    if constexpr (DEG == 2) {
+        const double A = fma(yd, fma(r.c[5], yd, r.c[2]), r.c[0]);
+        const double Bq = fma(r.c[4], yd, r.c[1]);
+        E = cis_turns(fma(xd, fma(r.c[3], xd, Bq), A) * INV2PI);
+        D = cis_turns(hx * fma(r.c[3], q, Bq) * INV2PI);            // phi(x + h) - phi(x) = h (B + c3 (2 x + h))
+    } else {
+        E = cis_turns(fma(xd, r.c[1], fma(yd, r.c[2], r.c[0])) * INV2PI);
+        D = (v2f){r.cr, r.ci};
+    }
+    // v_sin / v_cos results need a wait state before a non-transcendental VALU instruction reads them.  The compiler
+    // inserts it for its own instructions but does not look into the inline-asm packed products that consume E and D
+    // (seen: the first product of every spot read the stale register).  Pin one here.
+    asm volatile("s_nop 1" : "+v"(E), "+v"(D));
+}
+
+// nearfield -> partial farfield sums.  grid = (run blocks, batch, spot chunks), block = 64
+template <int DEG> __global__ __launch_bounds__(64) void c_n2f_run(CRunArgs ra) {
+    const CArgs<float>& a = ra.a;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int idx = blockIdx.x * 64 + lane;
+    const int row = idx / ra.rpr, run = idx - row * ra.rpr;
+    const bool live = row < ra.H;
+    const int col0 = run * CR_RUN;
+    const double xd = ra.x0 + (double)col0 * ra.hx, yd = ra.ys[live ? row : 0], q = 2.0 * xd + ra.hx;
+    v2f nf[CR_RUN];
+#pragma unroll
+    for (int k = 0; k < CR_RUN; ++k) {
+        nf[k] = (v2f){0.f, 0.f};
+        if (live && col0 + k < ra.W) {
+            const int p = row * ra.W + col0 + k;
+            float ph = a.phase[(size_t)b * a.S + p];          // _build_nearfield :1000-1011
+            if (a.kern) ph += a.kern[p];
+            float s, c;
+            Math<float>::sincos(ph, &s, &c);
+            const float am = a.amp ? a.amp[p] : a.amp_scalar;
+            nf[k] = (v2f){am * c, am * s};
+        }
+    }
+    Cx<float>* out = a.partial + ((size_t)b * a.nblocks + blockIdx.x) * a.N;
+    const int n_lo = blockIdx.z * ra.n_per, n_hi = min(a.N, n_lo + ra.n_per);
+    v2f keep = (v2f){0.f, 0.f};
+    for (int n = n_lo; n < n_hi; ++n) {
+        const CRunRec r = ra.rec[n];
+        v2f E, D;
+        run_start<DEG>(r, xd, yd, q, ra.hx, E, D);
+        const v2f Cn = (v2f){r.cr, r.ci};
+        v2f acc = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CR_RUN; ++k) {
+            acc = cmac_conj(acc, nf[k], E);                  // nf * exp(-i phi)
+            if (k + 1 < CR_RUN) {
+                E = cmul(E, D);
+                if constexpr (DEG == 2) D = cmul(D, Cn);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64);
+            acc.y += __shfl_xor(acc.y, o, 64);
+        }
+        const int slot = (n - n_lo) & 63;
+        if (lane == slot) keep = acc;
+        if (slot == 63 || n == n_hi - 1) {                   // one 512-byte store per 64 spots
+            const int nn = n - slot + lane;
+            if (nn <= n) out[nn] = keep;
+        }
+    }
+}
+
+// farfield -> partial nearfields.  grid = (run blocks, batch, spot chunks), block = 64
+template <int DEG> __global__ __launch_bounds__(64) void c_f2n_run(CRunArgs ra) {
+    const CArgs<float>& a = ra.a;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int idx = blockIdx.x * 64 + lane;
+    const int row = idx / ra.rpr, run = idx - row * ra.rpr;
+    const bool live = row < ra.H;
+    const int col0 = run * CR_RUN;
+    const double xd = ra.x0 + (double)col0 * ra.hx, yd = ra.ys[live ? row : 0], q = 2.0 * xd + ra.hx;
+    v2f acc[CR_RUN];
+#pragma unroll
+    for (int k = 0; k < CR_RUN; ++k) acc[k] = (v2f){0.f, 0.f};
+    const Cx<float>* ff = a.ff + (size_t)b * a.N;
+    const int n_lo = blockIdx.z * ra.n_per, n_hi = min(a.N, n_lo + ra.n_per);
+    for (int n = n_lo; n < n_hi; ++n) {
+        const CRunRec r = ra.rec[n];
+        v2f E, D;
+        run_start<DEG>(r, xd, yd, q, ra.hx, E, D);
+        const v2f Cn = (v2f){r.cr, r.ci};
+        E = cmul(E, ff[n]);                                  // ff * exp(+i phi): the factor rides the recurrence
+#pragma unroll
+        for (int k = 0; k < CR_RUN; ++k) {
+            acc[k] += E;
+            if (k + 1 < CR_RUN) {
+                E = cmul(E, D);
+                if constexpr (DEG == 2) D = cmul(D, Cn);
+            }
+        }
+    }
+    if (live) {
+        Cx<float>* dst = ra.nf_part + ((size_t)b * gridDim.z + blockIdx.z) * a.S + (size_t)row * ra.W + col0;
+#pragma unroll
+        for (int k = 0; k < CR_RUN; ++k)
+            if (col0 + k < ra.W) dst[k] = acc[k];
+    }
+}
+
+// nearfield = sum of the chunk partials (fixed order); phase or complex nearfield out.  grid = (ceil(S / 256), batch)
+static __global__ void c_f2n_run_finish(CArgs<float> a, const Cx<float>* nf_part, int chunks) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.S) return;
+    v2f s = (v2f){0.f, 0.f};
+    for (int z = 0; z < chunks; ++z) s += nf_part[((size_t)b * chunks + z) * a.S + p];
+    if (a.nf_out != nullptr) {                               // _farfield2nearfield(extract=False) (_spots.py:887-914)
+        const float sc = Math<float>::rsqrt((float)a.S);
+        a.nf_out[(size_t)b * a.S + p] = s * sc;
+    } else {
+        float ph = Math<float>::atan2(s.y, s.x);             // the 1/sqrt(S) scale does not change the phase (:1030)
+        if (a.kern) ph -= a.kern[p];
+        a.phase[(size_t)b * a.S + p] = ph;
     }
 }
 

@@ -161,7 +161,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_stepwise = 0;                  // HGS_OPT_FORCE_STEPWISE
     int opt_tile = 1;                      // HGS_OPT_TILE_KERNEL
     int opt_separable = 1;                 // HGS_OPT_SEPARABLE
-    int opt_sep_min = 32;                  // smallest spot count the matrix-core form is used for
+    int opt_sep_min = 96;                  // smallest spot count the matrix-core form is used for (tools/sep_crossover.py)
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
@@ -206,6 +206,14 @@ template <typename R> struct Engine : EngineBase {
     std::vector<int32_t> mono_host;
     std::vector<R> coeff_host;
     bool has_grid[2] = {false, false}, has_mono = false, has_coeff = false;
+    // run kernels of the direct compressed transforms (compressed_kernels.hpp: regular grid, degree <= 2, fp32)
+    bool run_ok = false;
+    int opt_run = 1;                       // HGS_OPT_RUN_KERNELS
+    CRunRec* run_rec = nullptr;            // [N]
+    double* run_ys = nullptr;              // [H]
+    Cx<float>* run_nf = nullptr;           // [B][run_chunks][S]
+    double run_x0 = 0, run_hx = 0;
+    int run_rpr = 0, run_blocks = 0, run_chunks = 1, run_nper = 0, run_nf_chunks = 0;
     // host state
     double amp_scalar = 0, amp_norm2 = 1.0;
     bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
@@ -223,7 +231,7 @@ template <typename R> struct Engine : EngineBase {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& d : blue_tab) for (auto& dir : d) for (C* t3 : dir) if (t3) hipFree(t3);
@@ -549,8 +557,10 @@ template <typename R> struct Engine : EngineBase {
         if (dalloc(&yg, S)) return HGS_ERR_DEVICE;
         if (dalloc(&mono, (size_t)2 * c.n_monomials)) return HGS_ERR_DEVICE;
         if (dalloc(&coeff, (size_t)c_rows * P)) return HGS_ERR_DEVICE;
-        if (dalloc(&cpartial, (size_t)B * c_nblocks * P)) return HGS_ERR_DEVICE;
-        if (dalloc(&cnorm, (size_t)B * ((P + 255) / 256))) return HGS_ERR_DEVICE;
+        run_rpr = (g.Sw + CR_RUN - 1) / CR_RUN;
+        run_blocks = (g.Sh * run_rpr + 63) / 64;
+        if (dalloc(&cpartial, (size_t)B * std::max(c_nblocks, run_blocks) * P)) return HGS_ERR_DEVICE;
+        if (dalloc(&cnorm, (size_t)B * ((P + C_RED_SPOTS - 1) / C_RED_SPOTS))) return HGS_ERR_DEVICE;
         if (dalloc(&ext_amp, P)) return HGS_ERR_DEVICE;
         if (dalloc(&ext_r, B * P)) return HGS_ERR_DEVICE;
         if (dalloc(&epartial, (size_t)B * ew_blocks)) return HGS_ERR_DEVICE;
@@ -608,7 +618,94 @@ template <typename R> struct Engine : EngineBase {
         *split = (K + kp - 1) / kp;
         *k_per = kp;
     }
+    // called whenever the grids, the term set or the coefficients changed
     int sep_refresh() {
+        if (int e = sep_refresh_impl()) return e;
+        return run_refresh();
+    }
+    // Run kernels: x must be a regular grid over the columns (checked against the uploaded values), y a function of the
+    // row, the polynomial of degree <= 2.  Per spot: canonical coefficients in double and the constant factor of the
+    // recurrence (degree 2: C_n = exp(i 2 c3 h^2); degree 1: D_n = exp(i c1 h)).
+    int run_refresh() {
+        run_ok = false;
+        if constexpr (sizeof(R) != 4) return 0;
+        if (cfg.kind != 1) return 0;
+        if (!(has_grid[0] && has_grid[1] && grid_sep[0] && grid_sep[1] && has_mono && has_coeff)) return 0;
+        if (c_degree < 0 || c_degree > 2) return 0;
+        const int M = cfg.n_monomials, N = cfg.n_spots, H = g.Sh, W = g.Sw;
+        if (W < 2) return 0;
+        const double x0 = xs_host[0], hx = (xs_host[W - 1] - x0) / (double)(W - 1);
+        double xmax = 0;
+        for (int x = 0; x < W; ++x) xmax = std::max(xmax, std::fabs(xs_host[x]));
+        // the uploaded values are fp32 roundings of the grid: half an ulp of the largest coordinate each
+        for (int x = 0; x < W; ++x)
+            if (std::fabs(xs_host[x] - (x0 + x * hx)) > 2.5e-7 * xmax + 1e-30) return 0;
+        std::vector<CRunRec> rec((size_t)N);
+        for (int n = 0; n < N; ++n) {
+            CRunRec& r = rec[n];
+            for (double& c : r.c) c = 0;
+            for (int m = 0; m < M; ++m) {
+                const int px = mono_host[2 * m], py = mono_host[2 * m + 1];
+                const int slot = (px == 0 && py == 0) ? 0 : (px == 1 && py == 0) ? 1 : (px == 0 && py == 1) ? 2
+                                 : (px == 2) ? 3 : (px == 1) ? 4 : 5;
+                r.c[slot] += (double)coeff_host[(size_t)m * N + n];
+            }
+            const double ang = c_degree == 2 ? 2.0 * r.c[3] * hx * hx : r.c[1] * hx;
+            r.cr = (float)std::cos(ang);
+            r.ci = (float)std::sin(ang);
+            r.pad0 = r.pad1 = 0;
+        }
+        if (!run_rec) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&run_rec), (size_t)N * sizeof(CRunRec)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&run_ys), (size_t)H * sizeof(double)));
+        }
+        if (int e_ = h2d(run_rec, rec.data(), rec.size() * sizeof(CRunRec))) return e_;
+        if (int e_ = h2d(run_ys, ys_host.data(), (size_t)H * sizeof(double))) return e_;
+        run_x0 = x0;
+        run_hx = hx;
+        // spot chunks (grid.z): about eight waves per SIMD, whole groups of 64 spots
+        int want = std::max(1, (8 * 4 * n_cu + run_blocks - 1) / run_blocks);
+        want = std::min(want, 8);
+        run_nper = std::max(64, ((N + want - 1) / want + 63) / 64 * 64);
+        run_chunks = (N + run_nper - 1) / run_nper;
+        run_ok = true;
+        return 0;
+    }
+    bool use_run() const { return run_ok && opt_run; }
+    CRunArgs run_args(const CArgs<R>& a) {
+        CRunArgs ra{};
+        if constexpr (sizeof(R) == 4) ra.a = a;
+        ra.a.nblocks = run_blocks;
+        ra.rec = run_rec; ra.ys = run_ys; ra.x0 = run_x0; ra.hx = run_hx; ra.H = g.Sh; ra.W = g.Sw; ra.rpr = run_rpr;
+        ra.n_per = run_nper; ra.nf_part = run_nf;
+        return ra;
+    }
+    int run_n2f(CArgs<R>& a) {
+        CRunArgs ra = run_args(a);
+        a.nblocks = run_blocks;                       // what c_n2f_reduce sums over
+        const dim3 grid(run_blocks, B, run_chunks);
+        if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_run<1>), grid, dim3(64), 0, stream, ra);
+        else hipLaunchKernelGGL((c_n2f_run<2>), grid, dim3(64), 0, stream, ra);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int run_f2n(const CArgs<R>& a) {
+        if (!run_nf || run_nf_chunks < run_chunks) {
+            if (run_nf) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(run_nf)); run_nf = nullptr; }
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&run_nf), (size_t)B * run_chunks * S * sizeof(Cx<float>)));
+            run_nf_chunks = run_chunks;
+        }
+        CRunArgs ra = run_args(a);
+        const dim3 grid(run_blocks, B, run_chunks);
+        if (c_degree <= 1) hipLaunchKernelGGL((c_f2n_run<1>), grid, dim3(64), 0, stream, ra);
+        else hipLaunchKernelGGL((c_f2n_run<2>), grid, dim3(64), 0, stream, ra);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(c_f2n_run_finish, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, ra.a,
+                           (const Cx<float>*)run_nf, run_chunks);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int sep_refresh_impl() {
         c_sep = false;
         if (sizeof(R) != 4 || cfg.kind != 1) return 0;
         if (!(has_grid[0] && has_grid[1] && grid_sep[0] && grid_sep[1] && has_mono && has_coeff)) return 0;
@@ -727,16 +824,17 @@ template <typename R> struct Engine : EngineBase {
         if (int e = compressed_ready()) return e;
         if (int e = need_ff()) return e;
         if (store_pff) { if (int e = need_pff()) return e; }
-        const int nred = (int)((P + 255) / 256);
+        const int nred = (int)((P + C_RED_SPOTS - 1) / C_RED_SPOTS);
         int r = timed(HGS_K_COL_FWD, [&]() -> int {
             if (use_sep()) return sep_n2f();
             CArgs<R> a = cargs();
             const dim3 grid(c_nblocks, B);
-            if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a);
+            if (use_run()) { if (int e = run_n2f(a)) return e; }
+            else if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a);
             else if (c_degree == 2) hipLaunchKernelGGL((c_n2f_partial<R, 2>), grid, dim3(C_WG), 0, stream, a);
             else hipLaunchKernelGGL((c_n2f_partial<R, 0>), grid, dim3(C_WG), 0, stream, a);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(c_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, a, cnorm);
+            hipLaunchKernelGGL(c_n2f_reduce<R>, dim3(nred, B), dim3(C_RED_SPOTS * C_RED_SLICES), 0, stream, a, cnorm);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(256), 0, stream, a, (const double*)cnorm, nred);
             HIPCHK(hipGetLastError());
@@ -759,6 +857,7 @@ template <typename R> struct Engine : EngineBase {
             if (use_sep()) return sep_f2n(nullptr);
             CArgs<R> a = cargs();
             const dim3 grid(c_nblocks, B);
+            if (use_run()) return run_f2n(a);
             if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
             else if (c_degree == 2) hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a);
             else hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a);
@@ -1249,6 +1348,7 @@ template <typename R> struct Engine : EngineBase {
                 CArgs<R> a = cargs();
                 a.nf_out = nfbuf;
                 const dim3 grid(c_nblocks, B);
+                if (use_run()) return run_f2n(a);
                 if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
                 else if (c_degree == 2) hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a);
                 else hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a);
@@ -1941,6 +2041,7 @@ template <typename R> struct Engine : EngineBase {
             case HGS_OPT_TILE_KERNEL: opt_tile = value ? 1 : 0; return 0;
             case HGS_OPT_SEPARABLE: opt_separable = value ? 1 : 0; return 0;
             case HGS_OPT_SEPARABLE_MIN_SPOTS: opt_sep_min = value > 0 ? value : 1; return 0;
+            case HGS_OPT_RUN_KERNELS: opt_run = value ? 1 : 0; return 0;
             case HGS_OPT_ROCTX:
                 if (value && !g_roctx.load()) return fail(HGS_ERR_UNSUPPORTED, "no roctx library (librocprofiler-sdk-roctx / libroctx64) found");
                 opt_roctx = value ? 1 : 0;

@@ -125,3 +125,72 @@ def test_separable_matrix_core_path_matches_direct_kernels(D):
     report(f"compressed separable (MFMA) vs direct kernels D={D}", **errs)
     assert errs["ff"] < 2e-5 and errs["w"] < 2e-5 and errs["ph"] < 5e-5
     assert a.stats["flags"]["fixed_phase"] == b.stats["flags"]["fixed_phase"]
+
+
+def _kernel_phase64(h, orc):
+    """phi_n(p) in float64 for every spot and pixel, from the oracle's monomial tables."""
+    terms, wts = orc.monomial_weights(h.zernike_basis, h.spot_zernike)
+    x = np.asarray(h._xg, dtype=np.float64).ravel()
+    y = np.asarray(h._yg, dtype=np.float64).ravel()
+    phi = np.zeros((wts.shape[1], x.size))
+    for m, (px, py) in enumerate(terms):
+        phi += wts[m][:, None] * (x ** int(px) * y ** int(py))[None, :]
+    return phi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("basis", ["kxy2", "kxy3", "zern5"])
+@pytest.mark.parametrize("slm_shape", [(70, 93), (64, 128)])
+def test_run_kernels_against_float64_sums(basis, slm_shape):
+    """
+    The direct transforms of a regular pixel grid advance exp(i phi) along runs of 16 pixels by recurrence (c_n2f_run /
+    c_f2n_run; degree 1: tilts, degree 2: focus and astigmatisms, the oblique one is what breaks the matrix-core form).
+    Both directions against float64 direct summation over every spot and pixel, next to the per-pixel kernels
+    (HGS_OPT_RUN_KERNELS = 0) on the same inputs: widths that are not a multiple of the run, more spots than one chunk
+    of 64, array amplitude and a propagation kernel ride along.
+    """
+    from oracle import hgs_oracle as orc
+    fs = SimpleFourierSLM(SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78))
+    N = 137
+    v = np.vstack([0.03 * (synth.uniform01(61, (N,), k) - 0.5) for k in range(2)])
+    b = "kxy"
+    if basis != "kxy2":
+        v = np.vstack((v, 4e-6 * (synth.uniform01(61, (N,), 2) - 0.5)))
+    if basis == "zern5":
+        z, _ = toolbox.convert_vector_zernike(v, "kxy", fs)
+        v = np.vstack([z, np.pi * (2 * synth.uniform01(61, (2, N), 3) - 1)])
+        b = np.array([2, 1, 4, 3, 5])
+    amp = 0.5 + synth.uniform01(62, (N,), 0)
+    kern = (0.3 * synth.seed_phase(63, slm_shape)).astype(np.float32)
+    phase0 = synth.seed_phase(60, slm_shape)
+    S = slm_shape[0] * slm_shape[1]
+
+    errs = {}
+    for run in (1, 0):
+        h = CompressedSpotHologram(v, basis=b, spot_amp=amp, cameraslm=fs, propagation_kernel=kern,
+                                   engine_options={L.OPT_SEPARABLE: 0, L.OPT_RUN_KERNELS: run})
+        h.reset_phase(phase0)
+        h.optimize("WGS-Leonardo", maxiter=2, verbose=False)          # weights away from the target
+        h.phase = phase0
+        e = h._get_engine()
+        phi = _kernel_phase64(h, orc)
+        amp_nf = np.full(S, float(h.amp)) if np.isscalar(h.amp) else np.asarray(h.amp, dtype=np.float64).ravel()
+        e.nearfield2farfield()
+        ff = e.get(L.FARFIELD)[0].astype(np.complex128)
+        nf = amp_nf * np.exp(1j * (phase0.astype(np.float64).ravel() + kern.astype(np.float64).ravel()))
+        ref = np.sum(nf[None, :] * np.exp(-1j * phi), axis=1)
+        ref /= np.sqrt(np.sum(np.abs(ref) ** 2))
+        err_ff = rel_l2(ff, ref)
+        st = h._make_step()
+        e.farfield_constraint(st)
+        ffc = e.get(L.FARFIELD)[0].astype(np.complex128)
+        e.farfield2nearfield()
+        ph = e.get(L.PHASE)[0].astype(np.float64).ravel()
+        nfb = np.sum(ffc[:, None] * np.exp(1j * phi), axis=0)
+        err_ph = phase_rel_l2(ph, np.angle(nfb) - kern.astype(np.float64).ravel())
+        errs[run] = (err_ff, err_ph)
+        h._release_engine()
+    report(f"compressed run kernels {basis} {slm_shape} vs float64 sums", run_ff=errs[1][0], run_phase=errs[1][1],
+           per_pixel_ff=errs[0][0], per_pixel_phase=errs[0][1])
+    assert errs[1][0] < 2e-6 and errs[1][1] < 1e-5
+    assert errs[0][0] < 2e-5 and errs[0][1] < 1e-4
