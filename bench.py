@@ -644,11 +644,16 @@ def main():
             n_l = prof["col_fwd"]["launches"] + prof["col_inv"]["launches"]
             dur = (prof["col_fwd"]["ms"] + prof["col_inv"]["ms"]) * 1e-3 / max(1, n_l)
             ach = flop_launch / dur
-            roof = {"bound": "mfma", "kernel": "cgemm_kouter (complex fp32 GEMM, v_mfma_f32_32x32x2_f32) + its table/contraction helpers, "
-                                               "one timed unit per transform direction",
+            roof = {"bound": "mfma", "kernel": "cgemm_kouter (complex fp32 GEMM, v_mfma_f32_32x32x2_f32, three real products per "
+                                               "complex one) + its table/contraction helpers, one timed unit per transform direction",
                     "achieved": ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK,
                     "traffic": None, "traffic_note": "matrix-core bound; HBM traffic not the limiter (tables 153 + 153 + 92 MB)",
                     "flop_per_launch": flop_launch, "launch_us": dur * 1e6, "launches": n_l,
+                    "flop_note": "algorithmic count: 8 N S real flop per transform (a complex multiply-add = 4 real ones). "
+                                 "The kernel forms each complex product from THREE real matrix products (P1 = Ar Br, P2 = Ai Bi, "
+                                 "P3 = (Ar + Ai)(Br + Bi)), i.e. it issues 6 N S flop to the matrix pipe: `pipe_utilisation` is "
+                                 "that count over the same time and peak",
+                    "pipe_utilisation": 0.75 * ach / MFMA_F32_PEAK,
                     "iteration": {"flop": 2 * flop_launch, "achieved": 2 * flop_launch * args.steps / (ms_events * 1e-3) / 1e12,
                                   "frac": 2 * flop_launch * args.steps / (ms_events * 1e-3) / MFMA_F32_PEAK},
                     "timing": "HIP events per transform on the engine stream, second pass of K steps"}

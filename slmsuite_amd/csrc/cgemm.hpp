@@ -36,7 +36,10 @@ __device__ __forceinline__ int cg_swz(int k, int c) { return c ^ ((k & 1) << 5);
 // PADDED: the caller guarantees that every 16 x 128 tile the grid touches is addressable and that the
 // padding is zero (lda >= 128-multiple of M, ldb likewise, split * k_per rows) -- no bounds checks, 32-byte
 // loads.  The staging (global -> registers -> planar LDS) is 30 % of the kernel time otherwise.
-template <bool PADDED>
+// GAUSS: three real products per complex one -- P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi), Cr = P1 - P2,
+// Ci = P3 - P1 - P2 -- i.e. 12 instead of 16 MFMAs per k pair and wave; the operand sums are two VALU adds per fetched
+// fragment (the VALU is idle next to the matrix pipe), the three accumulator sets take 192 registers.
+template <bool PADDED, bool GAUSS = false>
 __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cg_lds[];
     // buffer layout: [buf][plane (Ar, Ai, Br, Bi)][16][128]
@@ -49,60 +52,89 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
     const float2* A = a.A + (size_t)b * a.strideA;
     const float2* B = a.B + (size_t)b * a.strideB;
 
-    // staging: thread t moves 8 consecutive complex values of row (t >> 4) of each operand tile
+    // staging: thread t moves 8 consecutive complex values of row (t >> 4) of each operand tile.
+    // (GAUSS: the two operands go one after the other through the same eight registers -- the third accumulator set
+    //  leaves no room for both)
     const int sk = t >> 4, sc = (t & 15) * 8;
-    float2 ra[8], rb[8];
-    auto gload = [&](int k0) {
+    float2 ra[8], rb[GAUSS ? 1 : 8];
+    float2 rq[4];       // GAUSS: a quarter of the tile pair at a time (A low, A high, B low, B high halves of the 8 values)
+    auto gload_one = [&](int k0, int which, float2 (&dst)[8]) {
         const int k = k0 + sk;
+        const float2* src = which == 0 ? A + (size_t)k * a.lda + m0 + sc : B + (size_t)k * a.ldb + n0 + sc;
         if constexpr (PADDED) {
-            const float4* pa = reinterpret_cast<const float4*>(A + (size_t)k * a.lda + m0 + sc);
-            const float4* pb = reinterpret_cast<const float4*>(B + (size_t)k * a.ldb + n0 + sc);
+            const float4* p4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 va = pa[i], vb = pb[i];
-                ra[2 * i] = make_float2(va.x, va.y); ra[2 * i + 1] = make_float2(va.z, va.w);
-                rb[2 * i] = make_float2(vb.x, vb.y); rb[2 * i + 1] = make_float2(vb.z, vb.w);
+                const float4 v = p4[i];
+                dst[2 * i] = make_float2(v.x, v.y); dst[2 * i + 1] = make_float2(v.z, v.w);
             }
             return;
         }
         const bool kin = k < kend;
+        const int lim = which == 0 ? a.M - m0 - sc : a.N - n0 - sc;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + sc + i, n = n0 + sc + i;
-            ra[i] = (kin && m < a.M) ? A[(size_t)k * a.lda + m] : make_float2(0.f, 0.f);
-            rb[i] = (kin && n < a.N) ? B[(size_t)k * a.ldb + n] : make_float2(0.f, 0.f);
+        for (int i = 0; i < 8; ++i) dst[i] = (kin && i < lim) ? src[i] : make_float2(0.f, 0.f);
+    };
+    auto lstore_one = [&](int buf, int which, const float2 (&v)[8]) {
+        float* base = cg_lds + buf * BUF + sk * 128 + cg_swz(sk, sc) + (which == 0 ? 0 : 2 * PLANE);
+        float4* re = reinterpret_cast<float4*>(base);
+        float4* im = reinterpret_cast<float4*>(base + PLANE);
+        re[0] = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+        re[1] = make_float4(v[4].x, v[5].x, v[6].x, v[7].x);
+        im[0] = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+        im[1] = make_float4(v[4].y, v[5].y, v[6].y, v[7].y);
+    };
+    auto gload_q = [&](int k0, int q) {
+        const int k = k0 + sk, which = q >> 1, off = (q & 1) * 4;
+        const float2* src = (which == 0 ? A + (size_t)k * a.lda + m0 + sc : B + (size_t)k * a.ldb + n0 + sc) + off;
+        if constexpr (PADDED) {
+            const float4* p4 = reinterpret_cast<const float4*>(src);
+            const float4 v0 = p4[0], v1 = p4[1];
+            rq[0] = make_float2(v0.x, v0.y); rq[1] = make_float2(v0.z, v0.w);
+            rq[2] = make_float2(v1.x, v1.y); rq[3] = make_float2(v1.z, v1.w);
+            return;
         }
+        const bool kin = k < kend;
+        const int lim = (which == 0 ? a.M - m0 - sc : a.N - n0 - sc) - off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rq[i] = (kin && i < lim) ? src[i] : make_float2(0.f, 0.f);
+    };
+    auto lstore_q = [&](int buf, int q) {
+        const int which = q >> 1, off = (q & 1) * 4;
+        float* base = cg_lds + buf * BUF + sk * 128 + cg_swz(sk, sc) + off + (which == 0 ? 0 : 2 * PLANE);
+        *reinterpret_cast<float4*>(base) = make_float4(rq[0].x, rq[1].x, rq[2].x, rq[3].x);
+        *reinterpret_cast<float4*>(base + PLANE) = make_float4(rq[0].y, rq[1].y, rq[2].y, rq[3].y);
+    };
+    auto gload = [&](int k0) {
+        if constexpr (!GAUSS) { gload_one(k0, 0, ra); gload_one(k0, 1, rb); }
     };
     auto lstore = [&](int buf) {
-        float* base = cg_lds + buf * BUF + sk * 128 + cg_swz(sk, sc);
-        float4* ar = reinterpret_cast<float4*>(base);
-        float4* ai = reinterpret_cast<float4*>(base + PLANE);
-        float4* br = reinterpret_cast<float4*>(base + 2 * PLANE);
-        float4* bi = reinterpret_cast<float4*>(base + 3 * PLANE);
-        ar[0] = make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x);
-        ar[1] = make_float4(ra[4].x, ra[5].x, ra[6].x, ra[7].x);
-        ai[0] = make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y);
-        ai[1] = make_float4(ra[4].y, ra[5].y, ra[6].y, ra[7].y);
-        br[0] = make_float4(rb[0].x, rb[1].x, rb[2].x, rb[3].x);
-        br[1] = make_float4(rb[4].x, rb[5].x, rb[6].x, rb[7].x);
-        bi[0] = make_float4(rb[0].y, rb[1].y, rb[2].y, rb[3].y);
-        bi[1] = make_float4(rb[4].y, rb[5].y, rb[6].y, rb[7].y);
+        if constexpr (!GAUSS) { lstore_one(buf, 0, ra); lstore_one(buf, 1, rb); }
     };
 
-    f32x16 cr[2][2], ci[2][2];
+    f32x16 cr[2][2], ci[2][2], cs[GAUSS ? 2 : 1][GAUSS ? 2 : 1];    // GAUSS: P1, P2, P3
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { cr[i][j][r] = 0.f; ci[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) {
+                cr[i][j][r] = 0.f;
+                ci[i][j][r] = 0.f;
+                if constexpr (GAUSS) cs[i][j][r] = 0.f;
+            }
 
     // MFMA operand coordinates of this lane: A[i = lane & 31][k = lane >> 5], B[k][j = lane & 31]
     const int kq = lane >> 5, rr = lane & 31;
     const int nk = (kend - kbeg + CG_BK - 1) / CG_BK;
     if (nk > 0) {
-        gload(kbeg);
-        lstore(0);
+        if constexpr (GAUSS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { gload_q(kbeg, q); lstore_q(0, q); }
+        } else {
+            gload(kbeg);
+            lstore(0);
+        }
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -110,7 +142,11 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
 #ifndef CG_ABL
 #define CG_ABL 0     // microbenchmark ablations: 1 = no global loads / LDS stores in the loop, 2 = also no barrier
 #endif
-        if (CG_ABL == 0 && kt + 1 < nk) gload(kbeg + (kt + 1) * CG_BK);
+        const bool more = CG_ABL == 0 && kt + 1 < nk;
+        if (more) {
+            if constexpr (GAUSS) gload_q(kbeg + (kt + 1) * CG_BK, 0);
+            else gload(kbeg + (kt + 1) * CG_BK);
+        }
         const float* L = cg_lds + buf * BUF;
         // operand fragments of k-pair kk+1 are fetched from LDS before the MFMAs of pair kk issue
         float ar[2][2], ai[2][2], br[2][2], bi[2][2];
@@ -135,6 +171,25 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
         for (int kk = 0; kk < CG_BK / 2; ++kk) {
             const int cur = kk & 1;
             if (kk + 1 < CG_BK / 2) fetch(kk + 1, cur ^ 1);
+            if constexpr (GAUSS) {
+                if ((kk == 2 || kk == 4 || kk == 6) && more) {   // a quarter of the next tile pair parked, the next on its way
+                    lstore_q(buf ^ 1, kk / 2 - 1);
+                    gload_q(kbeg + (kt + 1) * CG_BK, kk / 2);
+                }
+            }
+            if constexpr (GAUSS) {
+                float as_[2], bs_[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { as_[i] = ar[cur][i] + ai[cur][i]; bs_[i] = br[cur][i] + bi[cur][i]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        cr[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[cur][i], br[cur][jj], cr[i][jj], 0, 0, 0);
+                        ci[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[cur][i], bi[cur][jj], ci[i][jj], 0, 0, 0);
+                        cs[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i], bs_[jj], cs[i][jj], 0, 0, 0);
+                    }
+            } else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -145,7 +200,10 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
                     ci[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[cur][i], br[cur][jj], ci[i][jj], 0, 0, 0);
                 }
         }
-        if (CG_ABL == 0 && kt + 1 < nk) lstore(buf ^ 1);
+        if (more) {
+            if constexpr (GAUSS) lstore_q(buf ^ 1, 3);
+            else lstore(buf ^ 1);
+        }
         if (CG_ABL < 2) __syncthreads();
     }
 
@@ -159,7 +217,14 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-                if (m < a.M && n < a.N) C[(size_t)m * a.N + n] = make_float2(cr[i][j][r], ci[i][j][r]);
+                if (m < a.M && n < a.N) {
+                    if constexpr (GAUSS) {
+                        const float p1 = cr[i][j][r], p2 = ci[i][j][r];
+                        C[(size_t)m * a.N + n] = make_float2(p1 - p2, cs[i][j][r] - p1 - p2);
+                    } else {
+                        C[(size_t)m * a.N + n] = make_float2(cr[i][j][r], ci[i][j][r]);
+                    }
+                }
             }
         }
 }

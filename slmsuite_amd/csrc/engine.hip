@@ -746,7 +746,7 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c1), (size_t)B * sep_split1 * N * H * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c2), (size_t)B * sep_split2 * H * W * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_norm), (size_t)B * ((N + 3) / 4) * sizeof(double)));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_kouter<true>),
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_kouter<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES));
         }
         HIPCHK(hipMemcpyAsync(sep_c, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -771,7 +771,7 @@ template <typename R> struct Engine : EngineBase {
     int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int K, int lda, int ldb, int split, int k_per,
                      size_t strideA, size_t strideB) {
         CgemmArgs a{A, Bm, C, M, N, K, lda, ldb, split, k_per, strideA, strideB};
-        hipLaunchKernelGGL(cgemm_kouter<true>, dim3((M + CG_BM - 1) / CG_BM, (N + CG_BN - 1) / CG_BN, split * B), dim3(256),
+        hipLaunchKernelGGL((cgemm_kouter<true, true>), dim3((M + CG_BM - 1) / CG_BM, (N + CG_BN - 1) / CG_BN, split * B), dim3(256),
                            CG_LDS_BYTES, stream, a);
         HIPCHK(hipGetLastError());
         return 0;
