@@ -621,15 +621,16 @@ def main():
         want_pmc = args.pmc if args.pmc is not None else (1 if (world == 1 and dist is None) else 0)
         roof = None
         if compressed and prof is not None and args.workload == "cfg4zern":
-            # direct kernels: one evaluation of exp(+-i phi_n(p)) and one complex MAC per (spot, pixel) and direction;
-            # (2 D + 8 + 2) flop each (phase polynomial, sin, cos, complex MAC)
+            # direct kernels: one value of exp(+-i phi_n(p)) and one complex MAC per (spot, pixel) and direction; counted as
+            # SURVEY 8(d) counts the reference's evaluation: (2 D + 8 + 2) flop each (phase polynomial, sin, cos, complex MAC)
             S = prob.slm[0] * prob.slm[1]
             flop_launch = (2.0 * prob.D + 10.0) * prob.N * S
             n_l = prof["col_fwd"]["launches"] + prof["col_inv"]["launches"]
             dur = (prof["col_fwd"]["ms"] + prof["col_inv"]["ms"]) * 1e-3 / max(1, n_l)
             ach = flop_launch / dur
-            roof = {"bound": "valu", "kernel": "c_n2f / c_f2n direct kernels (phase polynomial + v_sin / v_cos + complex MAC per pixel "
-                                               "and spot, nothing tabulated), one timed unit per transform direction",
+            roof = {"bound": "valu", "kernel": "c_n2f_run / c_f2n_run direct kernels (exp(i phi) of every pixel and spot advanced along "
+                                               "16-pixel runs by recurrence, start values in double, nothing tabulated) + their "
+                                               "reductions, one timed unit per transform direction",
                     "achieved": ach / 1e12, "peak": VALU_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / VALU_F32_PEAK,
                     "traffic": None, "traffic_note": "VALU / transcendental bound: 2 N S kernel evaluations per iteration, "
                                                      "compulsory traffic ~ 35 MB",

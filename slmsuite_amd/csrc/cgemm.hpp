@@ -229,6 +229,145 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
         }
 }
 
+// ---- stream-K form ------------------------------------------------------------------------------------------------
+// The (output tile, k tile) iteration space is one line of tiles * KT steps; workgroup w of G = 2 * #CU takes the w-th
+// G-th of it (to a step), whatever the shape -- 711 tiles x 120 steps or 135 x 625 both fill 512 resident workgroups
+// exactly, where whole-tile splits ran 2.78 resp. 1.85 rounds.  A workgroup that ends a tile (or its range) inside it
+// stores the partial sums to plane (w - first workgroup of that tile) of C; the consumers add the planes a tile has
+// (sk_nseg).  Operands: k-outer, zero padded to whole 16 x 128 tiles and KT * 16 rows; Gauss products, quarter staging.
+struct CgemmSkArgs {
+    const float2* A;   // [KT*16][lda]
+    const float2* B;   // [KT*16][ldb]
+    float2* C;         // [batch][planes][M][N]
+    int M, N, KT;
+    int lda, ldb;
+    int tiles_m, tiles_n, planes;
+    const int* first_wg;   // [tiles_m * tiles_n] workgroup that owns step 0 of the tile (sk_owner)
+    size_t strideA, strideB;
+};
+__host__ __device__ inline long long sk_begin(long long total, int G, int w) { return total * w / G; }
+// workgroup whose range [sk_begin(w), sk_begin(w + 1)) holds step idx
+__host__ __device__ inline int sk_owner(long long idx, long long total, int G) {
+    long long w = idx * G / total;
+    while (sk_begin(total, G, (int)w + 1) <= idx) ++w;
+    while (sk_begin(total, G, (int)w) > idx) --w;
+    return (int)w;
+}
+
+__global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float cg_lds[];
+    constexpr int PLANE = CG_BK * 128, BUF = 4 * PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x, w = blockIdx.x, b = blockIdx.y;
+    const long long total = (long long)a.tiles_m * a.tiles_n * a.KT;
+    const long long lo = sk_begin(total, G, w), hi = sk_begin(total, G, w + 1);
+    if (lo >= hi) return;
+    const float2* A = a.A + (size_t)b * a.strideA;
+    const float2* B = a.B + (size_t)b * a.strideB;
+    const int sk = t >> 4, sc = (t & 15) * 8;
+    float2 rq[4];
+    auto gload_q = [&](int m0, int n0, int k0, int q) {
+        const int k = k0 + sk, which = q >> 1, off = (q & 1) * 4;
+        const float2* src = (which == 0 ? A + (size_t)k * a.lda + m0 + sc : B + (size_t)k * a.ldb + n0 + sc) + off;
+        const float4* p4 = reinterpret_cast<const float4*>(src);
+        const float4 v0 = p4[0], v1 = p4[1];
+        rq[0] = make_float2(v0.x, v0.y); rq[1] = make_float2(v0.z, v0.w);
+        rq[2] = make_float2(v1.x, v1.y); rq[3] = make_float2(v1.z, v1.w);
+    };
+    auto lstore_q = [&](int buf, int q) {
+        const int which = q >> 1, off = (q & 1) * 4;
+        float* base = cg_lds + buf * BUF + sk * 128 + cg_swz(sk, sc) + off + (which == 0 ? 0 : 2 * PLANE);
+        *reinterpret_cast<float4*>(base) = make_float4(rq[0].x, rq[1].x, rq[2].x, rq[3].x);
+        *reinterpret_cast<float4*>(base + PLANE) = make_float4(rq[0].y, rq[1].y, rq[2].y, rq[3].y);
+    };
+    f32x16 c1[2][2], c2[2][2], c3[2][2];
+    auto clear = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c1[i][j][r] = 0.f; c2[i][j][r] = 0.f; c3[i][j][r] = 0.f; }
+    };
+    clear();
+    const int kq = lane >> 5, rr = lane & 31;
+    int tile = (int)(lo / a.KT), kt = (int)(lo - (long long)tile * a.KT);
+    int m0 = (tile % a.tiles_m) * CG_BM, n0 = (tile / a.tiles_m) * CG_BN;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { gload_q(m0, n0, kt * CG_BK, q); lstore_q(0, q); }
+    __syncthreads();
+    int buf = 0;
+    for (long long it = lo; it < hi; ++it) {
+        const bool more = it + 1 < hi;
+        int ntile = tile, nkt = kt + 1;
+        if (nkt == a.KT) { nkt = 0; ntile = tile + 1; }
+        const int nm0 = (ntile % a.tiles_m) * CG_BM, nn0 = (ntile / a.tiles_m) * CG_BN;
+        if (more) gload_q(nm0, nn0, nkt * CG_BK, 0);
+        const float* L = cg_lds + buf * BUF;
+        float ar[2][2], ai[2][2], br[2][2], bi[2][2];
+        auto fetch = [&](int kk, int slot) {
+            const int k = 2 * kk + kq;
+            const float* row = L + k * 128;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = cg_swz(k, wm * 64 + i * 32 + rr);
+                ar[slot][i] = row[c];
+                ai[slot][i] = row[PLANE + c];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c = cg_swz(k, wn * 64 + jj * 32 + rr);
+                br[slot][jj] = row[2 * PLANE + c];
+                bi[slot][jj] = row[3 * PLANE + c];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < CG_BK / 2; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < CG_BK / 2) fetch(kk + 1, cur ^ 1);
+            if ((kk == 2 || kk == 4 || kk == 6) && more) {
+                lstore_q(buf ^ 1, kk / 2 - 1);
+                gload_q(nm0, nn0, nkt * CG_BK, kk / 2);
+            }
+            float as_[2], bs_[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { as_[i] = ar[cur][i] + ai[cur][i]; bs_[i] = br[cur][i] + bi[cur][i]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    c1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[cur][i], br[cur][jj], c1[i][jj], 0, 0, 0);
+                    c2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[cur][i], bi[cur][jj], c2[i][jj], 0, 0, 0);
+                    c3[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i], bs_[jj], c3[i][jj], 0, 0, 0);
+                }
+        }
+        if (more) lstore_q(buf ^ 1, 3);
+        __syncthreads();
+        if (nkt == 0 || !more) {     // this workgroup's share of `tile` is complete
+            const int seg = w - a.first_wg[tile];
+            float2* C = a.C + ((size_t)b * a.planes + seg) * (size_t)a.M * a.N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + j * 32 + rr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                        if (m < a.M && n < a.N) {
+                            const float p1 = c1[i][j][r], p2 = c2[i][j][r];
+                            C[(size_t)m * a.N + n] = make_float2(p1 - p2, c3[i][j][r] - p1 - p2);
+                        }
+                    }
+                }
+            clear();
+        }
+        tile = ntile; kt = nkt; m0 = nm0; n0 = nn0; buf ^= 1;
+    }
+}
+
 constexpr size_t CG_LDS_BYTES = 2 * 4 * CG_BK * 128 * sizeof(float);   // 64 KB
 
 }  // namespace hgs

@@ -287,6 +287,21 @@ __device__ __forceinline__ v2f cmac_conj(v2f acc, v2f a, v2f b) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(a), "v"(b));
     return r;
 }
+// sum over the 64 lanes, delivered to every lane: prefix sums inside the rows of 16 (row_shr 1, 2, 4, 8), row 0 -> 1 and
+// 2 -> 3 (row_bcast:15), rows 0-1 -> 2-3 (row_bcast:31), then lane 63 through a scalar register.  Six DPP adds and a lane
+// read instead of six ds_bpermute + add pairs per value.
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+    v = dpp_add<0x111>(v);
+    v = dpp_add<0x112>(v);
+    v = dpp_add<0x114>(v);
+    v = dpp_add<0x118>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 template <int DEG> __device__ __forceinline__ void run_start(const CRunRec& r, double xd, double yd, double q, double hx,
                                                              v2f& E, v2f& D) {
     constexpr double INV2PI = 0.15915494309189533577;
@@ -345,11 +360,7 @@ template <int DEG> __global__ __launch_bounds__(64) void c_n2f_run(CRunArgs ra) 
                 if constexpr (DEG == 2) D = cmul(D, Cn);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            acc.x += __shfl_xor(acc.x, o, 64);
-            acc.y += __shfl_xor(acc.y, o, 64);
-        }
+        acc = (v2f){wave_sum_all(acc.x), wave_sum_all(acc.y)};
         const int slot = (n - n_lo) & 63;
         if (lane == slot) keep = acc;
         if (slot == 63 || n == n_hi - 1) {                   // one 512-byte store per 64 spots

@@ -12,6 +12,7 @@ run --workload cfg2dense --steps 100 --warmup 12 --method GS
 run --workload cfg2dense --steps 100 --warmup 12 --method WGS-Kim
 run --workload cfg4 --steps 30 --warmup 12
 run --workload cfg4d3 --steps 30 --warmup 12 --cpu-iters 0
+run --workload cfg4zern --steps 50 --warmup 12
 run --workload cfg4grid --steps 40 --warmup 12
 run --workload cfg5mraf --steps 40 --warmup 5
 run --workload cfg5mraf --steps 40 --warmup 5 --method GS --cpu-iters 0

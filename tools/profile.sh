@@ -16,6 +16,8 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $ROOT
 cd $ROOTDIR
 python tools/summarize_prof.py $OUT > $OUT/summary.md 2>&1
 cat $OUT/summary.md
-# keep only the small files
+# keep only the small files: the summaries and the per-kernel statistics (gpurun copies at most 64 MiB back)
 find $OUT -name "*.db" -delete 2>/dev/null
+cp $(ls $OUT/stats/*/*kernel_stats.csv $OUT/stats/*kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats.csv 2>/dev/null
+rm -rf $OUT/stats $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch $OUT/pmc_write
 du -sh $OUT
