@@ -68,9 +68,11 @@ __global__ void sep_build_nft(const R* phase, const R* amp, const R* kern, R amp
 
 // ff_raw[n] = sum_s sum_y T[s][n][y] Ey[n][y] / sqrt(S)  (double accumulation), one wave per spot;
 // also the per-block partial of sum |ff_raw|^2 for c_n2f_finish.  grid = (ceil(N/4), batch), block 256
+// (stream-K GEMM: a 128 x 128 tile of T is spread over nseg[tile] of the `split` partial planes, tile = n / 128 +
+//  (y / 128) * tiles_m; the other planes of that tile were never written)
 template <typename R>
-__global__ void sep_n2f_reduce(const float2* T, int split, const float2* Ey, int N, int H, double inv_sqrt_s,
-                               Cx<R>* ff, double* norm_partial) {
+__global__ void sep_n2f_reduce(const float2* T, int split, const int* nseg, int tiles_m, const float2* Ey, int N, int H,
+                               double inv_sqrt_s, Cx<R>* ff, double* norm_partial) {
     __shared__ double scratch[16];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
@@ -80,6 +82,7 @@ __global__ void sep_n2f_reduce(const float2* T, int split, const float2* Ey, int
             const float2* row = T + (((size_t)b * split + s) * N + n) * H;
             const float2* ey = Ey + (size_t)n * H;
             for (int y = lane; y < H; y += 64) {
+                if (s >= nseg[(n >> 7) + (y >> 7) * tiles_m]) continue;
                 const float2 t = row[y], e = ey[y];
                 sr += (double)t.x * e.x - (double)t.y * e.y;
                 si += (double)t.x * e.y + (double)t.y * e.x;
@@ -113,12 +116,15 @@ __global__ void sep_build_b2(const Cx<R>* ff, const float2* Ey, int N, int H, fl
 // nf = conj(sum_s C[s]) / sqrt(S): phase = atan2(nf) - kernel (:1030-1036), or the complex nearfield
 // (extract = False).  grid = (ceil(S/256), batch)
 template <typename R>
-__global__ void sep_f2n_finish(const float2* C, int split, size_t S, const R* kern, R* phase, Cx<R>* nf_out) {
+__global__ void sep_f2n_finish(const float2* C, int split, const int* nseg, int tiles_m, int W, size_t S, const R* kern, R* phase,
+                               Cx<R>* nf_out) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (p >= S) return;
     float re = 0, im = 0;
-    for (int s = 0; s < split; ++s) {
+    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
+    const int ns = nseg[(y >> 7) + (x >> 7) * tiles_m];
+    for (int s = 0; s < ns; ++s) {
         const float2 v = C[((size_t)b * split + s) * S + p];
         re += v.x;
         im -= v.y;

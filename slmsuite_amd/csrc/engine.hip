@@ -202,6 +202,9 @@ template <typename R> struct Engine : EngineBase {
     float2* sep_c2 = nullptr;       // [B][split2][H][W]
     double* sep_norm = nullptr;     // [B][ceil(N/4)]
     int sep_split1 = 1, sep_kper1 = 0, sep_split2 = 1, sep_kper2 = 0, sep_degx = 0, sep_degy = 0;
+    // stream-K schedule of the two GEMMs (cgemm_streamk): sep_split1 / sep_split2 are then the partial planes of C
+    int sk_G1 = 0, sk_G2 = 0, sk_kt1 = 0, sk_kt2 = 0, sk_tm1 = 0, sk_tn1 = 0, sk_tm2 = 0, sk_tn2 = 0;
+    int* sk_tab = nullptr;          // [first_wg 1][nseg 1][first_wg 2][nseg 2]
     int sep_Np = 0, sep_Hp = 0, sep_Wp = 0, sep_Wk = 0, sep_Nk = 0;   // padded leading dimensions / row counts
     std::vector<int32_t> mono_host;
     std::vector<R> coeff_host;
@@ -231,7 +234,7 @@ template <typename R> struct Engine : EngineBase {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
         void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf};
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& d : blue_tab) for (auto& dir : d) for (C* t3 : dir) if (t3) hipFree(t3);
@@ -726,11 +729,34 @@ template <typename R> struct Engine : EngineBase {
         if (!sep_c) {
             // operands of the matrix-core GEMM are padded to whole tiles (zero filled once, never rewritten)
             auto up = [](int v, int q) { return (v + q - 1) / q * q; };
-            split_for(((N + CG_BM - 1) / CG_BM) * ((H + CG_BN - 1) / CG_BN), W, n_cu, &sep_split1, &sep_kper1);
-            split_for(((H + CG_BM - 1) / CG_BM) * ((W + CG_BN - 1) / CG_BN), N, n_cu, &sep_split2, &sep_kper2);
+            // stream-K: the (tile, k tile) steps of each GEMM in 2 * #CU equal shares; per tile the first workgroup and the
+            // number of partial planes it is spread over (consumers add exactly those)
+            sk_tm1 = (N + CG_BM - 1) / CG_BM; sk_tn1 = (H + CG_BN - 1) / CG_BN; sk_kt1 = (W + CG_BK - 1) / CG_BK;
+            sk_tm2 = (H + CG_BM - 1) / CG_BM; sk_tn2 = (W + CG_BN - 1) / CG_BN; sk_kt2 = (N + CG_BK - 1) / CG_BK;
+            {
+                const int t1 = sk_tm1 * sk_tn1, t2 = sk_tm2 * sk_tn2;
+                std::vector<int> tab((size_t)2 * (t1 + t2));
+                // (at most one workgroup per step: every workgroup owns work, the owners of a tile are consecutive)
+                sk_G1 = (int)std::min<long long>(2 * n_cu, (long long)t1 * sk_kt1);
+                sk_G2 = (int)std::min<long long>(2 * n_cu, (long long)t2 * sk_kt2);
+                auto fill = [&](int tiles, int KT, int G, int* first, int* nseg) {
+                    const long long total = (long long)tiles * KT;
+                    int planes = 1;
+                    for (int t = 0; t < tiles; ++t) {
+                        first[t] = sk_owner((long long)t * KT, total, G);
+                        nseg[t] = sk_owner((long long)(t + 1) * KT - 1, total, G) - first[t] + 1;
+                        planes = std::max(planes, nseg[t]);
+                    }
+                    return planes;
+                };
+                sep_split1 = fill(t1, sk_kt1, sk_G1, tab.data(), tab.data() + t1);
+                sep_split2 = fill(t2, sk_kt2, sk_G2, tab.data() + 2 * t1, tab.data() + 2 * t1 + t2);
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&sk_tab), tab.size() * sizeof(int)));
+                if (int e_ = h2d(sk_tab, tab.data(), tab.size() * sizeof(int))) return e_;
+            }
             sep_Np = up(N, CG_BM); sep_Hp = up(H, CG_BN); sep_Wp = up(W, CG_BN);
-            sep_Wk = sep_split1 * sep_kper1;
-            sep_Nk = sep_split2 * sep_kper2;
+            sep_Wk = sk_kt1 * CG_BK;
+            sep_Nk = sk_kt2 * CG_BK;
             auto zalloc = [&](float2** p, size_t n) -> int {
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(float2)));
                 HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(float2), stream));
@@ -746,7 +772,7 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c1), (size_t)B * sep_split1 * N * H * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c2), (size_t)B * sep_split2 * H * W * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_norm), (size_t)B * ((N + 3) / 4) * sizeof(double)));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_kouter<true, true>),
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_streamk),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES));
         }
         HIPCHK(hipMemcpyAsync(sep_c, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -768,11 +794,10 @@ template <typename R> struct Engine : EngineBase {
     bool use_sep() const {
         return c_sep && opt_separable && cfg.n_spots >= opt_sep_min;
     }
-    int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int K, int lda, int ldb, int split, int k_per,
-                     size_t strideA, size_t strideB) {
-        CgemmArgs a{A, Bm, C, M, N, K, lda, ldb, split, k_per, strideA, strideB};
-        hipLaunchKernelGGL((cgemm_kouter<true, true>), dim3((M + CG_BM - 1) / CG_BM, (N + CG_BN - 1) / CG_BN, split * B), dim3(256),
-                           CG_LDS_BYTES, stream, a);
+    int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int KT, int lda, int ldb, int tiles_m, int tiles_n,
+                     int planes, const int* first_wg, int G, size_t strideA, size_t strideB) {
+        CgemmSkArgs a{A, Bm, C, M, N, KT, lda, ldb, tiles_m, tiles_n, planes, first_wg, strideA, strideB};
+        hipLaunchKernelGGL(cgemm_streamk, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -783,11 +808,12 @@ template <typename R> struct Engine : EngineBase {
                            has_amp ? (const R*)amp : (const R*)nullptr, has_kern ? (const R*)kern : (const R*)nullptr,
                            (R)amp_scalar, H, W, sep_nfT, sep_Hp, (size_t)sep_Wk * sep_Hp);
         HIPCHK(hipGetLastError());
-        if (int e = launch_cgemm(sep_exT, sep_nfT, sep_c1, N, H, W, sep_Np, sep_Hp, sep_split1, sep_kper1, 0,
+        const int t1 = sk_tm1 * sk_tn1;
+        if (int e = launch_cgemm(sep_exT, sep_nfT, sep_c1, N, H, sk_kt1, sep_Np, sep_Hp, sk_tm1, sk_tn1, sep_split1, sk_tab, sk_G1, 0,
                                  (size_t)sep_Wk * sep_Hp)) return e;
         const int nred = (N + 3) / 4;
         hipLaunchKernelGGL(sep_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_split1,
-                           (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
+                           (const int*)(sk_tab + t1), sk_tm1, (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(256), 0, stream, cargs(), (const double*)sep_norm, nred);
         HIPCHK(hipGetLastError());
@@ -799,10 +825,12 @@ template <typename R> struct Engine : EngineBase {
         hipLaunchKernelGGL(sep_build_b2<R>, dim3((H + 255) / 256, N, B), dim3(256), 0, stream, (const Cx<R>*)ff,
                            (const float2*)sep_ey, N, H, sep_b2, sep_Hp, (size_t)sep_Nk * sep_Hp);
         HIPCHK(hipGetLastError());
-        if (int e = launch_cgemm(sep_b2, sep_ex, sep_c2, H, W, N, sep_Hp, sep_Wp, sep_split2, sep_kper2,
+        const int t1 = sk_tm1 * sk_tn1, t2 = sk_tm2 * sk_tn2;
+        if (int e = launch_cgemm(sep_b2, sep_ex, sep_c2, H, W, sk_kt2, sep_Hp, sep_Wp, sk_tm2, sk_tn2, sep_split2, sk_tab + 2 * t1, sk_G2,
                                  (size_t)sep_Nk * sep_Hp, 0)) return e;
         hipLaunchKernelGGL(sep_f2n_finish<R>, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, (const float2*)sep_c2,
-                           sep_split2, S, has_kern ? (const R*)kern : (const R*)nullptr, phase, nf_out);
+                           sep_split2, (const int*)(sk_tab + 2 * t1 + t2), sk_tm2, W, S,
+                           has_kern ? (const R*)kern : (const R*)nullptr, phase, nf_out);
         HIPCHK(hipGetLastError());
         return 0;
     }
