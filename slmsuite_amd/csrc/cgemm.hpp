@@ -233,17 +233,24 @@ __global__ __launch_bounds__(256, 2) void cgemm_kouter(CgemmArgs a) {
 // The (output tile, k tile) iteration space is one line of tiles * KT steps; workgroup w of G = 2 * #CU takes the w-th
 // G-th of it (to a step), whatever the shape -- 711 tiles x 120 steps or 135 x 625 both fill 512 resident workgroups
 // exactly, where whole-tile splits ran 2.78 resp. 1.85 rounds.  A workgroup that ends a tile (or its range) inside it
-// stores the partial sums to plane (w - first workgroup of that tile) of C; the consumers add the planes a tile has
-// (sk_nseg).  Operands: k-outer, zero padded to whole 16 x 128 tiles and KT * 16 rows; Gauss products, quarter staging.
+// stores the partial sums to plane (w - first workgroup of that tile) of C; the consumers add the planes a tile has.
+// Operands: PLANAR (a real and an imaginary [KT*16][ld] float array each), k-outer, zero padded to whole 16 x 128
+// tiles -- so that a tile row is 512 contiguous bytes that go global -> LDS directly (global_load_lds_dwordx4: 1 KiB =
+// two tile rows per wave instruction, wave v fills plane v of the next buffer; the bank swizzle of the odd rows is
+// applied to the SOURCE column, the destination being linear by construction).  No staging registers, no ds_write
+// pass, and the loads of step t+1 are in flight for the whole of step t (with the three accumulator sets of the Gauss
+// form there were registers for a quarter tile at a time only, i.e. two k pairs of latency cover).
 struct CgemmSkArgs {
-    const float2* A;   // [KT*16][lda]
-    const float2* B;   // [KT*16][ldb]
+    const float* Ar;   // [KT*16][lda]
+    const float* Ai;
+    const float* Br;   // [KT*16][ldb]
+    const float* Bi;
     float2* C;         // [batch][planes][M][N]
     int M, N, KT;
-    int lda, ldb;
+    int lda, ldb;      // in floats
     int tiles_m, tiles_n, planes;
     const int* first_wg;   // [tiles_m * tiles_n] workgroup that owns step 0 of the tile (sk_owner)
-    size_t strideA, strideB;
+    size_t strideA, strideB;   // per batch element, in floats (0 = shared)
 };
 __host__ __device__ inline long long sk_begin(long long total, int G, int w) { return total * w / G; }
 // workgroup whose range [sk_begin(w), sk_begin(w + 1)) holds step idx
@@ -257,29 +264,25 @@ __host__ __device__ inline int sk_owner(long long idx, long long total, int G) {
 __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cg_lds[];
     constexpr int PLANE = CG_BK * 128, BUF = 4 * PLANE;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int G = gridDim.x, w = blockIdx.x, b = blockIdx.y;
     const long long total = (long long)a.tiles_m * a.tiles_n * a.KT;
     const long long lo = sk_begin(total, G, w), hi = sk_begin(total, G, w + 1);
     if (lo >= hi) return;
-    const float2* A = a.A + (size_t)b * a.strideA;
-    const float2* B = a.B + (size_t)b * a.strideB;
-    const int sk = t >> 4, sc = (t & 15) * 8;
-    float2 rq[4];
-    auto gload_q = [&](int m0, int n0, int k0, int q) {
-        const int k = k0 + sk, which = q >> 1, off = (q & 1) * 4;
-        const float2* src = (which == 0 ? A + (size_t)k * a.lda + m0 + sc : B + (size_t)k * a.ldb + n0 + sc) + off;
-        const float4* p4 = reinterpret_cast<const float4*>(src);
-        const float4 v0 = p4[0], v1 = p4[1];
-        rq[0] = make_float2(v0.x, v0.y); rq[1] = make_float2(v0.z, v0.w);
-        rq[2] = make_float2(v1.x, v1.y); rq[3] = make_float2(v1.z, v1.w);
-    };
-    auto lstore_q = [&](int buf, int q) {
-        const int which = q >> 1, off = (q & 1) * 4;
-        float* base = cg_lds + buf * BUF + sk * 128 + cg_swz(sk, sc) + off + (which == 0 ? 0 : 2 * PLANE);
-        *reinterpret_cast<float4*>(base) = make_float4(rq[0].x, rq[1].x, rq[2].x, rq[3].x);
-        *reinterpret_cast<float4*>(base + PLANE) = make_float4(rq[0].y, rq[1].y, rq[2].y, rq[3].y);
+    // this wave's plane of the tile pair: 0 = Ar, 1 = Ai, 2 = Br, 3 = Bi
+    const float* plane = (wave == 0 ? a.Ar : wave == 1 ? a.Ai : wave == 2 ? a.Br : a.Bi) +
+                         (size_t)b * (wave < 2 ? a.strideA : a.strideB);
+    const int ld = wave < 2 ? a.lda : a.ldb;
+    // lane -> (row parity, 16-byte chunk) of a two-row piece; odd rows take the swizzled source chunk
+    const int lrow = lane >> 5, lchunk = (lane & 31) ^ (lrow << 3);
+    auto gload = [&](int buf, int m0, int n0, int k0) {
+        const float* src = plane + (size_t)(k0 + lrow) * ld + (wave < 2 ? m0 : n0) + 4 * lchunk;
+        float* dst = cg_lds + buf * BUF + wave * PLANE;
+#pragma unroll
+        for (int i = 0; i < CG_BK / 2; ++i)
+            __builtin_amdgcn_global_load_lds(src + (size_t)(2 * i) * ld,
+                                             (__attribute__((address_space(3))) void*)(dst + 2 * i * 128), 16, 0, 0);
     };
     f32x16 c1[2][2], c2[2][2], c3[2][2];
     auto clear = [&]() {
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
     const int kq = lane >> 5, rr = lane & 31;
     int tile = (int)(lo / a.KT), kt = (int)(lo - (long long)tile * a.KT);
     int m0 = (tile % a.tiles_m) * CG_BM, n0 = (tile / a.tiles_m) * CG_BN;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { gload_q(m0, n0, kt * CG_BK, q); lstore_q(0, q); }
+    gload(0, m0, n0, kt * CG_BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (long long it = lo; it < hi; ++it) {
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
         int ntile = tile, nkt = kt + 1;
         if (nkt == a.KT) { nkt = 0; ntile = tile + 1; }
         const int nm0 = (ntile % a.tiles_m) * CG_BM, nn0 = (ntile / a.tiles_m) * CG_BN;
-        if (more) gload_q(nm0, nn0, nkt * CG_BK, 0);
+        if (more) gload(buf ^ 1, nm0, nn0, nkt * CG_BK);      // (every wave left buf ^ 1 at the barrier of the step before)
         const float* L = cg_lds + buf * BUF;
         float ar[2][2], ai[2][2], br[2][2], bi[2][2];
         auto fetch = [&](int kk, int slot) {
@@ -327,10 +330,6 @@ __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
         for (int kk = 0; kk < CG_BK / 2; ++kk) {
             const int cur = kk & 1;
             if (kk + 1 < CG_BK / 2) fetch(kk + 1, cur ^ 1);
-            if ((kk == 2 || kk == 4 || kk == 6) && more) {
-                lstore_q(buf ^ 1, kk / 2 - 1);
-                gload_q(nm0, nn0, nkt * CG_BK, kk / 2);
-            }
             float as_[2], bs_[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) { as_[i] = ar[cur][i] + ai[cur][i]; bs_[i] = br[cur][i] + bi[cur][i]; }
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
                     c3[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i], bs_[jj], c3[i][jj], 0, 0, 0);
                 }
         }
-        if (more) lstore_q(buf ^ 1, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step's tile pair has landed
         __syncthreads();
         if (nkt == 0 || !more) {     // this workgroup's share of `tile` is complete
             const int seg = w - a.first_wg[tile];

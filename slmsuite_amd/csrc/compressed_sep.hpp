@@ -18,9 +18,11 @@ constexpr int SEP_MAXDEG = 8;
 
 // tab[n][i] = exp(-i f_n(g[i])), f_n(u) = sum_p c[p][n] u^p; optionally also the transpose tabT[i][n].
 // grid = (ceil(len/256), N)
-// ld / ldT: leading dimensions of tab / tabT (>= len / N; the matrix-core GEMM wants 128-multiples, zero padded)
-__global__ void sep_build_table(const double* c, int deg, int N, const double* g, int len, float2* tab, int ld,
-                                float2* tabT, int ldT) {
+// ld / ldT: leading dimensions of tab / tabT (>= len / N; the matrix-core GEMM wants 128-multiples, zero padded).
+// GEMM operands are PLANAR (cgemm_streamk): tab_plane / tabT_plane > 0 = distance in floats from the real to the imaginary
+// array of that table; 0 = interleaved float2 (Ey, which only the elementwise helpers read).
+__global__ void sep_build_table(const double* c, int deg, int N, const double* g, int len, float2* tab, int ld, size_t tab_plane,
+                                float2* tabT, int ldT, size_t tabT_plane) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
     if (i >= len) return;
     const double u = g[i];
@@ -32,16 +34,26 @@ __global__ void sep_build_table(const double* c, int deg, int N, const double* g
     double s, co;
     ::sincos(tr * 6.28318530717958647692, &s, &co);
     const float2 v = make_float2((float)co, (float)(-s));
-    tab[(size_t)n * ld + i] = v;
-    if (tabT != nullptr) tabT[(size_t)i * ldT + n] = v;
+    if (tab_plane > 0) {
+        float* q = reinterpret_cast<float*>(tab);
+        q[(size_t)n * ld + i] = v.x;
+        q[tab_plane + (size_t)n * ld + i] = v.y;
+    } else {
+        tab[(size_t)n * ld + i] = v;
+    }
+    if (tabT != nullptr) {
+        float* q = reinterpret_cast<float*>(tabT);
+        q[(size_t)i * ldT + n] = v.x;
+        q[tabT_plane + (size_t)i * ldT + n] = v.y;
+    }
 }
 
 // nfT[b][x][y] = amp[y][x] * exp(i (phase[b][y][x] + kern[y][x]))   (32 x 32 LDS transpose tiles)
 // grid = (ceil(W/32), ceil(H/32), batch), block = (32, 8)
-// nfT has leading dimension ldH and batch stride strideB (padded for the GEMM)
+// nfT is planar (real array, then the imaginary one `plane` floats on), leading dimension ldH, batch stride 2 * plane
 template <typename R>
-__global__ void sep_build_nft(const R* phase, const R* amp, const R* kern, R amp_scalar, int H, int W, float2* nfT,
-                              int ldH, size_t strideB) {
+__global__ void sep_build_nft(const R* phase, const R* amp, const R* kern, R amp_scalar, int H, int W, float* nfT,
+                              int ldH, size_t plane) {
     __shared__ float2 tile[32][33];
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
@@ -62,7 +74,11 @@ __global__ void sep_build_nft(const R* phase, const R* amp, const R* kern, R amp
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int x = x0 + r, y = y0 + threadIdx.x;
-        if (x < W && y < H) nfT[(size_t)b * strideB + (size_t)x * ldH + y] = tile[threadIdx.x][r];
+        if (x < W && y < H) {
+            float* q = nfT + (size_t)b * 2 * plane + (size_t)x * ldH + y;
+            q[0] = tile[threadIdx.x][r].x;
+            q[plane] = tile[threadIdx.x][r].y;
+        }
     }
 }
 
@@ -102,15 +118,17 @@ __global__ void sep_n2f_reduce(const float2* T, int split, const int* nseg, int 
     if (threadIdx.x == 0) norm_partial[(size_t)b * gridDim.x + blockIdx.x] = tot;
 }
 
-// B2[b][n][y] = conj(ff[b][n]) * Ey[n][y].   grid = (ceil(H/256), N, batch)
+// B2[b][n][y] = conj(ff[b][n]) * Ey[n][y], planar like nfT.   grid = (ceil(H/256), N, batch)
 template <typename R>
-__global__ void sep_build_b2(const Cx<R>* ff, const float2* Ey, int N, int H, float2* B2, int ldH, size_t strideB) {
+__global__ void sep_build_b2(const Cx<R>* ff, const float2* Ey, int N, int H, float* B2, int ldH, size_t plane) {
     const int y = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, b = blockIdx.z;
     if (y >= H) return;
     const Cx<R> f = ff[(size_t)b * N + n];
     const float2 e = Ey[(size_t)n * H + y];
     const float fr = (float)f.x, fi = -(float)f.y;
-    B2[(size_t)b * strideB + (size_t)n * ldH + y] = make_float2(fr * e.x - fi * e.y, fr * e.y + fi * e.x);
+    float* q = B2 + (size_t)b * 2 * plane + (size_t)n * ldH + y;
+    q[0] = fr * e.x - fi * e.y;
+    q[plane] = fr * e.y + fi * e.x;
 }
 
 // nf = conj(sum_s C[s]) / sqrt(S): phase = atan2(nf) - kernel (:1030-1036), or the complex nearfield

@@ -781,11 +781,11 @@ template <typename R> struct Engine : EngineBase {
         sep_degx = dx;
         sep_degy = dy;
         hipLaunchKernelGGL(sep_build_table, dim3((W + 255) / 256, N), dim3(256), 0, stream, (const double*)sep_c, dx, N,
-                           (const double*)sep_g, W, sep_ex, sep_Wp, sep_exT, sep_Np);
+                           (const double*)sep_g, W, sep_ex, sep_Wp, (size_t)sep_Nk * sep_Wp, sep_exT, sep_Np, (size_t)sep_Wk * sep_Np);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(sep_build_table, dim3((H + 255) / 256, N), dim3(256), 0, stream,
                            (const double*)(sep_c + (size_t)(SEP_MAXDEG + 1) * N), dy, N, (const double*)(sep_g + W), H, sep_ey,
-                           H, (float2*)nullptr, 0);
+                           H, (size_t)0, (float2*)nullptr, 0, (size_t)0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));   // c / xs_host are host temporaries
         c_sep = true;
@@ -794,9 +794,10 @@ template <typename R> struct Engine : EngineBase {
     bool use_sep() const {
         return c_sep && opt_separable && cfg.n_spots >= opt_sep_min;
     }
-    int launch_cgemm(const float2* A, const float2* Bm, float2* C, int M, int N, int KT, int lda, int ldb, int tiles_m, int tiles_n,
-                     int planes, const int* first_wg, int G, size_t strideA, size_t strideB) {
-        CgemmSkArgs a{A, Bm, C, M, N, KT, lda, ldb, tiles_m, tiles_n, planes, first_wg, strideA, strideB};
+    // operands planar: real array at A / Bm, imaginary one planeA / planeB floats on
+    int launch_cgemm(const float* A, size_t planeA, const float* Bm, size_t planeB, float2* C, int M, int N, int KT, int lda, int ldb,
+                     int tiles_m, int tiles_n, int planes, const int* first_wg, int G, size_t strideA, size_t strideB) {
+        CgemmSkArgs a{A, A + planeA, Bm, Bm + planeB, C, M, N, KT, lda, ldb, tiles_m, tiles_n, planes, first_wg, strideA, strideB};
         hipLaunchKernelGGL(cgemm_streamk, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
         HIPCHK(hipGetLastError());
         return 0;
@@ -806,11 +807,12 @@ template <typename R> struct Engine : EngineBase {
         const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
         hipLaunchKernelGGL(sep_build_nft<R>, dim3((W + 31) / 32, (H + 31) / 32, B), dim3(32, 8), 0, stream, (const R*)phase,
                            has_amp ? (const R*)amp : (const R*)nullptr, has_kern ? (const R*)kern : (const R*)nullptr,
-                           (R)amp_scalar, H, W, sep_nfT, sep_Hp, (size_t)sep_Wk * sep_Hp);
+                           (R)amp_scalar, H, W, reinterpret_cast<float*>(sep_nfT), sep_Hp, (size_t)sep_Wk * sep_Hp);
         HIPCHK(hipGetLastError());
         const int t1 = sk_tm1 * sk_tn1;
-        if (int e = launch_cgemm(sep_exT, sep_nfT, sep_c1, N, H, sk_kt1, sep_Np, sep_Hp, sk_tm1, sk_tn1, sep_split1, sk_tab, sk_G1, 0,
-                                 (size_t)sep_Wk * sep_Hp)) return e;
+        if (int e = launch_cgemm(reinterpret_cast<const float*>(sep_exT), (size_t)sep_Wk * sep_Np,
+                                 reinterpret_cast<const float*>(sep_nfT), (size_t)sep_Wk * sep_Hp, sep_c1, N, H, sk_kt1, sep_Np, sep_Hp,
+                                 sk_tm1, sk_tn1, sep_split1, sk_tab, sk_G1, 0, (size_t)2 * sep_Wk * sep_Hp)) return e;
         const int nred = (N + 3) / 4;
         hipLaunchKernelGGL(sep_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_split1,
                            (const int*)(sk_tab + t1), sk_tm1, (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
@@ -823,11 +825,12 @@ template <typename R> struct Engine : EngineBase {
     int sep_f2n(Cx<R>* nf_out) {
         const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
         hipLaunchKernelGGL(sep_build_b2<R>, dim3((H + 255) / 256, N, B), dim3(256), 0, stream, (const Cx<R>*)ff,
-                           (const float2*)sep_ey, N, H, sep_b2, sep_Hp, (size_t)sep_Nk * sep_Hp);
+                           (const float2*)sep_ey, N, H, reinterpret_cast<float*>(sep_b2), sep_Hp, (size_t)sep_Nk * sep_Hp);
         HIPCHK(hipGetLastError());
         const int t1 = sk_tm1 * sk_tn1, t2 = sk_tm2 * sk_tn2;
-        if (int e = launch_cgemm(sep_b2, sep_ex, sep_c2, H, W, sk_kt2, sep_Hp, sep_Wp, sk_tm2, sk_tn2, sep_split2, sk_tab + 2 * t1, sk_G2,
-                                 (size_t)sep_Nk * sep_Hp, 0)) return e;
+        if (int e = launch_cgemm(reinterpret_cast<const float*>(sep_b2), (size_t)sep_Nk * sep_Hp,
+                                 reinterpret_cast<const float*>(sep_ex), (size_t)sep_Nk * sep_Wp, sep_c2, H, W, sk_kt2, sep_Hp, sep_Wp,
+                                 sk_tm2, sk_tn2, sep_split2, sk_tab + 2 * t1, sk_G2, (size_t)2 * sep_Nk * sep_Hp, 0)) return e;
         hipLaunchKernelGGL(sep_f2n_finish<R>, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, (const float2*)sep_c2,
                            sep_split2, (const int*)(sk_tab + 2 * t1 + t2), sk_tm2, W, S,
                            has_kern ? (const R*)kern : (const R*)nullptr, phase, nf_out);

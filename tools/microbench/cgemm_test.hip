@@ -7,8 +7,9 @@
 using namespace hgs;
 
 // ---- stream-K form: correctness on a ragged shape (few and many workgroups), then the cfg 4 shapes ----
-static int run_sk(const float2* dA, const float2* dB, float2* dC, int M, int N, int K, int lda, int ldb, int G, int* planes_out,
-                  std::vector<int>* nseg_out, float* ms_out) {
+// dA / dB: planar operands (real array, then the imaginary one planeA / planeB floats on)
+static int run_sk(const float* dA, size_t planeA, const float* dB, size_t planeB, float2* dC, int M, int N, int K, int lda, int ldb, int G,
+                  int* planes_out, std::vector<int>* nseg_out, float* ms_out) {
     const int tm = (M + 127) / 128, tn = (N + 127) / 128, KT = (K + 15) / 16, tiles = tm * tn;
     const long long total = (long long)tiles * KT;
     if (G > total) G = (int)total;            // every workgroup owns at least one step: the owners of a tile are consecutive
@@ -22,7 +23,7 @@ static int run_sk(const float2* dA, const float2* dB, float2* dC, int M, int N, 
     int* dF;
     hipMalloc(&dF, tiles * 4);
     hipMemcpy(dF, first.data(), tiles * 4, hipMemcpyHostToDevice);
-    CgemmSkArgs a{dA, dB, dC, M, N, KT, lda, ldb, tm, tn, planes, dF, 0, 0};
+    CgemmSkArgs a{dA, dA + planeA, dB, dB + planeB, dC, M, N, KT, lda, ldb, tm, tn, planes, dF, 0, 0};
     hipFuncSetAttribute((const void*)cgemm_streamk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
@@ -41,13 +42,16 @@ static void test_streamk() {
         for (int m = 0; m < M; ++m) { size_t i = (size_t)k * M + m; A[(size_t)k * Mp + m] = make_float2((float)((i * 7919) % 101) / 101.f - 0.5f, (float)((i * 104729) % 97) / 97.f - 0.3f); }
         for (int n = 0; n < N; ++n) { size_t i = (size_t)k * N + n; B[(size_t)k * Np + n] = make_float2((float)((i * 31337) % 89) / 89.f - 0.4f, (float)((i * 7) % 83) / 83.f - 0.6f); }
     }
-    float2 *dA, *dB, *dC;
+    float *dA, *dB; float2* dC;
+    std::vector<float> Ap(2 * A.size()), Bp(2 * B.size());
+    for (size_t i = 0; i < A.size(); ++i) { Ap[i] = A[i].x; Ap[A.size() + i] = A[i].y; }
+    for (size_t i = 0; i < B.size(); ++i) { Bp[i] = B[i].x; Bp[B.size() + i] = B[i].y; }
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dC, (size_t)8 * M * N * 8);
-    hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dA, Ap.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dB, Bp.data(), B.size() * 8, hipMemcpyHostToDevice);
     for (int G : {1, 5, 7, 512}) {
         int planes; std::vector<int> nseg; float ms;
         hipMemset(dC, 0xff, (size_t)8 * M * N * 8);       // NaN pattern: planes a tile does not own must not be read
-        run_sk(dA, dB, dC, M, N, K, Mp, Np, G, &planes, &nseg, &ms);
+        run_sk(dA, A.size(), dB, B.size(), dC, M, N, K, Mp, Np, G, &planes, &nseg, &ms);
         std::vector<float2> C((size_t)planes * M * N);
         hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
         double err = 0, nrm = 0;
@@ -65,11 +69,11 @@ static void test_streamk() {
     struct Shape { int M, N, K; const char* name; } shapes[] = {{10000, 1152, 1920, "n2f"}, {1152, 1920, 10000, "f2n"}};
     for (auto& sh : shapes) {
         const int Mp2 = (sh.M + 127) / 128 * 128, Np2 = (sh.N + 127) / 128 * 128, Kp2 = (sh.K + 15) / 16 * 16;
-        float2 *A2, *B2, *C2;
+        float *A2, *B2; float2* C2;
         hipMalloc(&A2, (size_t)Kp2 * Mp2 * 8); hipMalloc(&B2, (size_t)Kp2 * Np2 * 8); hipMalloc(&C2, (size_t)8 * sh.M * sh.N * 8);
         hipMemset(A2, 0, (size_t)Kp2 * Mp2 * 8); hipMemset(B2, 0, (size_t)Kp2 * Np2 * 8);
         int planes; float ms = 0, best = 1e9f;
-        for (int rep = 0; rep < 3; ++rep) { run_sk(A2, B2, C2, sh.M, sh.N, sh.K, Mp2, Np2, 512, &planes, nullptr, &ms); if (ms < best) best = ms; }
+        for (int rep = 0; rep < 3; ++rep) { run_sk(A2, (size_t)Kp2 * Mp2, B2, (size_t)Kp2 * Np2, C2, sh.M, sh.N, sh.K, Mp2, Np2, 512, &planes, nullptr, &ms); if (ms < best) best = ms; }
         printf("%s-shaped GEMM %d x %d x %d stream-K (512 workgroups, %d planes): %.3f ms  %.1f TFLOP/s\n", sh.name, sh.M, sh.N, sh.K, planes, best, 8.0 * sh.M * sh.N * sh.K / best / 1e9);
         hipFree(A2); hipFree(B2); hipFree(C2);
     }
