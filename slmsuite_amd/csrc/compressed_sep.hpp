@@ -94,14 +94,28 @@ __global__ void sep_n2f_reduce(const float2* T, int split, const int* nseg, int 
     const int n = blockIdx.x * 4 + wave;
     double sr = 0, si = 0;
     if (n < N) {
-        for (int s = 0; s < split; ++s) {
-            const float2* row = T + (((size_t)b * split + s) * N + n) * H;
-            const float2* ey = Ey + (size_t)n * H;
-            for (int y = lane; y < H; y += 64) {
-                if (s >= nseg[(n >> 7) + (y >> 7) * tiles_m]) continue;
-                const float2 t = row[y], e = ey[y];
-                sr += (double)t.x * e.x - (double)t.y * e.y;
-                si += (double)t.x * e.y + (double)t.y * e.x;
+        // tile column by tile column (128 values of y = two per lane, one 16-byte load), the planes that tile has
+        const float2* ey = Ey + (size_t)n * H;
+        const bool vec = (H & 1) == 0;           // rows of T and Ey are 16-byte aligned for even H
+        for (int y0 = 0; y0 < H; y0 += 128) {
+            const int ns = nseg[(n >> 7) + (y0 >> 7) * tiles_m];
+            const int y = y0 + 2 * lane;
+            if (vec && y + 1 < H) {
+                const float4 e = *reinterpret_cast<const float4*>(ey + y);
+                for (int s = 0; s < ns; ++s) {
+                    const float4 t = *reinterpret_cast<const float4*>(T + (((size_t)b * split + s) * N + n) * H + y);
+                    sr += (double)t.x * e.x - (double)t.y * e.y + (double)t.z * e.z - (double)t.w * e.w;
+                    si += (double)t.x * e.y + (double)t.y * e.x + (double)t.z * e.w + (double)t.w * e.z;
+                }
+            } else {
+                for (int yy = y; yy < min(H, y + 2); ++yy) {
+                    const float2 e = ey[yy];
+                    for (int s = 0; s < ns; ++s) {
+                        const float2 t = T[(((size_t)b * split + s) * N + n) * H + yy];
+                        sr += (double)t.x * e.x - (double)t.y * e.y;
+                        si += (double)t.x * e.y + (double)t.y * e.x;
+                    }
+                }
             }
         }
     }

@@ -817,7 +817,7 @@ template <typename R> struct Engine : EngineBase {
         hipLaunchKernelGGL(sep_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_split1,
                            (const int*)(sk_tab + t1), sk_tm1, (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(256), 0, stream, cargs(), (const double*)sep_norm, nred);
+        hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(1024), 0, stream, cargs(), (const double*)sep_norm, nred);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -867,7 +867,7 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(c_n2f_reduce<R>, dim3(nred, B), dim3(C_RED_SPOTS * C_RED_SLICES), 0, stream, a, cnorm);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(256), 0, stream, a, (const double*)cnorm, nred);
+            hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(1024), 0, stream, a, (const double*)cnorm, nred);
             HIPCHK(hipGetLastError());
             return 0;
         });
