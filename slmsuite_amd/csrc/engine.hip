@@ -165,6 +165,8 @@ template <typename R> struct Engine : EngineBase {
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
+    int opt_row_pref = 1;                  // developer A/B (HGS_ROW_PREF=0 at create): prefetching row kernel off
+    int row_blocks_pref = 0;               // its grid: two workgroups per CU, whole XCD line groups
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
     int* stats_dxy = nullptr;         // hgs_stats group 1: floor(spot_knm)
@@ -311,6 +313,7 @@ template <typename R> struct Engine : EngineBase {
         // HGS_TRACE_INIT=1: where hgs_create spends its time (developer aid, stderr)
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
+        opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
@@ -336,6 +339,12 @@ template <typename R> struct Engine : EngineBase {
         const int grp = fpw <= 4 ? 4 / fpw : 1;
         row_xcd = (grp > 1 && row_blocks >= 8 * grp && env_int("HGS_ROW_XCD", 1)) ? 1 : 0;
         if (row_xcd) row_blocks = (row_blocks + 8 * grp - 1) / (8 * grp) * (8 * grp);
+        // prefetching row kernel (one hologram; a batch keeps the one-row workgroups): 2 workgroups per CU
+        row_blocks_pref = 0;
+        if (sizeof(R) == 4 && g.Pw == 4096 && fpw == 1 && B == 1 && row_xcd) {
+            const int want = env_int("HGS_ROW_PREF_BLOCKS", 2 * n_cu);
+            row_blocks_pref = std::max(8 * grp, want / (8 * grp) * (8 * grp));
+        }
         const int tiles = g.Pw / 4;
         cap = env_int("HGS_COL_BLOCKS", n_cu * 3);
         cap = cap / B > 0 ? cap / B : 1;
@@ -1265,7 +1274,17 @@ template <typename R> struct Engine : EngineBase {
             a.load_mask = load_sparse == 1 ? lane_mask : load_sparse == 2 ? lane_mask_d : nullptr;
             a.store_mask = store_sparse == 1 ? lane_mask : store_sparse == 2 ? lane_mask_d : nullptr;
             // one extra (row-less) block folds the weight-norm partials when asked to
-            LCHK(launch_row<R>(g.Pw, mode, dim3(row_blocks + (finalize ? 1 : 0), B), stream, a));
+            // dense fp32 launches between iterations at 4096: workgroups walk several rows, next row prefetched into LDS
+            int blocks = row_blocks;
+            // (measured, tools/row_tail_probe.py: it pays where a one-row-per-workgroup launch ends in a partial round that the
+            //  walk turns into a third row for a quarter to a half of the workgroups -- 1152 rows 28.1 -> 26.3 us, 1280 rows
+            //  29.1 -> 27.5 us; level at 1024 rows, behind at 1536)
+            if (sizeof(R) == 4 && g.Pw == 4096 && mode == 2 && opt_row_pref && row_blocks_pref > 0 && !a.load_mask && !a.store_mask &&
+                g.Sh > 2 * row_blocks_pref && 10 * g.Sh <= 26 * row_blocks_pref) {
+                a.prefetch = 1;
+                a.n_row_blocks = blocks = row_blocks_pref;
+            }
+            LCHK(launch_row<R>(g.Pw, mode, dim3(blocks + (finalize ? 1 : 0), B), stream, a));
             return 0;
         });
     }

@@ -596,7 +596,14 @@ __device__ __forceinline__ void wave_lds_order() {
 }
 
 // TS: the twiddle table holds W_(4096 TS)^i (the 8192-point transform runs two of these on the W_8192 table)
-template <typename R, bool RESIDENT = true, int TS = 1> struct WgFftL {
+// RAWBAR: workgroup barriers as "s_waitcnt lgkmcnt(0); s_barrier" instead of __syncthreads().  For kernels that keep
+// LDS-DMA loads (global_load_lds) in flight across the transform: with such a load outstanding hipcc drains vmcnt(0)
+// ahead of every __syncthreads(), i.e. the prefetch would be waited for at the first exchange.
+template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false> struct WgFftL {
+    static __device__ __forceinline__ void wg_barrier() {
+        if constexpr (RAWBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    }
     static constexpr int N = 4096, T = 256, E = 16, ROW = 272;
     static constexpr int NTW = RESIDENT ? 12 : 1;
     Cx<R> tw[NTW];
@@ -669,10 +676,10 @@ template <typename R, bool RESIDENT = true, int TS = 1> struct WgFftL {
         if (!HGS_ABL_XCHG) {   // cross-wave exchange: lane (row n0, k_a) register k_b -> lane k_a + 16 k_b register n0
             Cx<R>* w = rowb + (p & 15);
             static_for<0, 16>([&](auto r_) { constexpr int r = r_; w[16 * r] = v[r]; });
-            __syncthreads();
+            wg_barrier();
             const Cx<R>* g = lds + p;
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = g[ROW * m]; });
-            __syncthreads();
+            wg_barrier();
         }
         HGS_T(tr_n, 14);
         butterfly_pre<DIR, 2>(v, p);
@@ -685,10 +692,10 @@ template <typename R, bool RESIDENT = true, int TS = 1> struct WgFftL {
         butterfly_post<DIR, 2>(v, p);
         HGS_T(tr_n, 21);
         if (!HGS_ABL_XCHG) {
-            if constexpr (LEAD) __syncthreads();
+            if constexpr (LEAD) wg_barrier();
             Cx<R>* g = lds + p;
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; g[ROW * m] = v[m]; });
-            __syncthreads();
+            wg_barrier();
             const Cx<R>* r = rowb + (p & 15);
             static_for<0, 16>([&](auto r_) { constexpr int rr = r_; v[rr] = r[16 * rr]; });
         }
@@ -831,14 +838,14 @@ template <typename R, bool RESIDENT = true> struct WgFftL8k {
 #ifndef HGS_LOCAL_FFT
 #define HGS_LOCAL_FFT 1
 #endif
-template <typename R, int N, bool RESIDENT> struct FftSel {
+template <typename R, int N, bool RESIDENT, bool RAWBAR = false> struct FftSel {
     using type = WgFft<R, N, RESIDENT>;
     static constexpr bool local = false;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return j; }
 };
 #if HGS_LOCAL_FFT
-template <typename R, bool RESIDENT> struct FftSel<R, 4096, RESIDENT> {
-    using type = WgFftL<R, RESIDENT>;
+template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 4096, RESIDENT, RAWBAR> {
+    using type = WgFftL<R, RESIDENT, 1, RAWBAR>;
     static constexpr bool local = true;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL<R, RESIDENT>::space_lane(j); }
 };
@@ -846,7 +853,7 @@ template <typename R, bool RESIDENT> struct FftSel<R, 4096, RESIDENT> {
 #define HGS_LOCAL_FFT8K 1
 #endif
 #if HGS_LOCAL_FFT8K
-template <typename R, bool RESIDENT> struct FftSel<R, 8192, RESIDENT> {
+template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 8192, RESIDENT, RAWBAR> {
     using type = WgFftL8k<R, RESIDENT>;
     static constexpr bool local = true;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL8k<R, RESIDENT>::space_lane(j); }

@@ -417,6 +417,7 @@ template <typename R> struct RowArgs {
     int xcd_map;         // rows 4q..4q+3 (which share 128-B lines of GH) on one XCD at the same time
     int n_row_blocks;    // workgroups that own rows (the grid may hold one more, row-less, for the weight norm)
     int shifted, m0;     // shifted form (row_kernel NS < 16): on / register slot of the first SLM column, c0 / (Pw / 16)
+    int prefetch;        // row_kernel PREF: workgroups walk several rows each, the next row's H on its way into LDS
     // sparse targets: which columns the column kernel of this iteration wrote / the next one will read
     const unsigned short* load_mask;    // [b][Pw/16]: bit m of entry j = column j + m*Pw/16 is to be read ...
     const unsigned short* store_mask;   // ... / written; nullptr = every column
@@ -429,11 +430,24 @@ template <typename R> struct RowArgs {
 // by the shift theorem that multiplies frequency k by exp(-2 pi i k m0 / 16), a per-lane constant folded into the scale
 // multiplies on the GH side.  The empty slots then cost nothing: no phasor, no predicate, and the first radix-4 layer of
 // the forward transform / the last one of the inverse shrink (fwd_lead / inv_trail).
-template <typename R, int N, int MODE, int NS = 16>
+// 16 bytes per lane global -> LDS (global_load_lds_dwordx4): the destination is the wave-uniform `lds_dst` + 16 * lane.
+// (A plain function on purpose: with the builtin inside a kernel TEMPLATE the host pass silently drops the kernel's stub.)
+__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// PREF (fp32, one-row workgroups, MODE 2, dense launches): a workgroup walks several rows (grid = 2 x #CU) and the H row
+// it will need NEXT goes global -> LDS by global_load_lds_dwordx4 while it transforms the current one -- 32 KB in flight
+// that no register holds.  The rows of a CU then sit in different phases by construction (one loads while the other
+// transforms), which is what the one-row-per-workgroup launch cannot have: there the rows of a round load, transform and
+// store in lock step and the traffic adds to the transform time.  Costs: 32 KB more LDS per
+// workgroup (two per CU), one LDS read per element, raw barriers in the transform (see WgFftL RAWBAR).
+template <typename R, int N, int MODE, int NS = 16, bool PREF = false>
 // (8192-wide rows: a workgroup is 8 waves, two per SIMD -- a second resident workgroup needs four waves per SIMD,
 //  i.e. at most 128 VGPRs)
-__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? HGS_ROW_OCC_8192 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
+__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? HGS_ROW_OCC_8192 : PREF ? 2 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
     static_assert(NS == 16 || (RowCfg<N>::FPW == 1 && NS >= 4 && NS < 16), "row_kernel: shifted form is for one-row workgroups");
+    static_assert(!PREF || (sizeof(R) == 4 && N == 4096 && MODE == 2), "row_kernel: the prefetching form is fp32, 4096 wide, MODE 2");
     using M = Math<R>;
     constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
     }
 
     // (fp64: 64 data registers per lane already; the stage twiddles are fetched per use instead of kept)
-    using Sel = FftSel<R, N, (sizeof(R) == 8 ? false : HGS_ROW_TW_RESIDENT)>;
+    using Sel = FftSel<R, N, (sizeof(R) == 8 ? false : HGS_ROW_TW_RESIDENT), PREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
 
@@ -517,6 +531,23 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
     }
     const int row_stride = (a.n_row_blocks > 0 ? a.n_row_blocks : (int)gridDim.x) * FPW;
     if (a.n_row_blocks > 0 && (int)blockIdx.x >= a.n_row_blocks) first = g.Sh;     // the weight-norm block owns no row
+    // PREF: the H row of `r` into the linear image P behind the transform image: instruction i of the workgroup (8 per
+    // wave) brings elements 128 i .. 128 i + 127, lane L the two at 128 i + 2 L (one 16-byte half of a 32-byte tile row)
+    Cx<R>* pimg = lds + lds_elems<N>();
+    auto prefetch_row = [&](int r) {
+        if constexpr (PREF) {
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = wv * 8 + q, k = 128 * i + 2 * ln;
+                const Cx<R>* src = gh + ((size_t)(k >> 2) * g.Sh + r) * 4 + (k & 3);
+                glds16(src, pimg + 128 * i);
+            }
+        }
+    };
+    if constexpr (PREF) {
+        if (first < g.Sh) prefetch_row(first);      // (no wait here: the set-up below runs under the first row's flight)
+    }
     HGS_T(fft.tr_n, 1);
 #pragma unroll 1
     for (int rbase = first; rbase < g.Sh; rbase += row_stride) {
@@ -614,6 +645,20 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
         } else {
         if constexpr (MODE != 0) {
             // ---- load H row, centred inverse transform along x ----
+            if constexpr (PREF) {
+                // the row has been on its way since the previous one was picked up: wait for this wave's pieces, meet the
+                // other waves, read; when every lane has its values the image is free for the row after this one
+                // (vmcnt(16) -- leaving the sixteen G stores of the row before in flight -- measured the same)
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    const Cx<R> h = pimg[j + m * T];
+                    if constexpr (NS < 16) v[m] = h;
+                    else v[m] = h * sgn;
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (rbase + row_stride < g.Sh) prefetch_row(rbase + row_stride);
+            } else
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
                 Cx<R> h = mk<R>(0, 0);

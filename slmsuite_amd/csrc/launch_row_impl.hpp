@@ -4,6 +4,17 @@
 
 namespace hgs {
 
+// prefetching form (row_kernel PREF): transform image + the 32 KB image of the next row
+template <typename R, int N, int NS>
+static int launch_row_pref(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
+    const size_t lds = (lds_elems<N>() + N) * sizeof(Cx<R>);
+    auto k = row_kernel<R, N, 2, NS, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
+    return (int)hipGetLastError();
+}
+
 template <typename R, int N, int MODE, int NS = 16>
 static int launch_row_one(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
     // The shifted 4096-point kernel needs 117 VGPRs, so four workgroups fit a CU.  Measured (cfg 2 / a batch of eight):
@@ -27,6 +38,10 @@ static int launch_row_one(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
 template <typename R, int N>
 static int launch_row_n(int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a) {
 #ifdef HGS_REAL_IS_FLOAT
+    if constexpr (N == 4096) {
+        if (a.prefetch && mode == 2 && a.load_mask == nullptr && a.store_mask == nullptr)
+            return a.shifted ? launch_row_pref<R, N, 8>(grid, s, a) : launch_row_pref<R, N, 16>(grid, s, a);
+    }
     if constexpr (N >= 4096) {
         if (a.shifted) {
             switch (mode) {
