@@ -251,6 +251,12 @@ struct CgemmSkArgs {
     int tiles_m, tiles_n, planes;
     const int* first_wg;   // [tiles_m * tiles_n] workgroup that owns step 0 of the tile (sk_owner)
     size_t strideA, strideB;   // per batch element, in floats (0 = shared)
+    // EPI 1 (n2f): instead of storing C, contract it with E[m][n] over n on the spot:
+    //   part[b][slot][m] = sum over the 64 columns of this wave of C[m][n] * E[m][n],  slot = (tile column * 2 + wave column) * planes + plane
+    const float2* E;       // [M][ldE]
+    int ldE;
+    float2* part;          // [batch][tiles_n * 2 * planes][ldP]
+    int ldP;
 };
 __host__ __device__ inline long long sk_begin(long long total, int G, int w) { return total * w / G; }
 // workgroup whose range [sk_begin(w), sk_begin(w + 1)) holds step idx
@@ -261,6 +267,20 @@ __host__ __device__ inline int sk_owner(long long idx, long long total, int G) {
     return (int)w;
 }
 
+// sum over the 32 lanes of each half of the wave (row_shr 1, 2, 4, 8 inside the rows of 16, row_bcast:15 from row 0 to 1
+// and from row 2 to 3): lanes 31 and 63 end up with the totals of their halves
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float cg_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float cg_half_sum(float v) {
+    v = cg_dpp_add<0x111>(v);
+    v = cg_dpp_add<0x112>(v);
+    v = cg_dpp_add<0x114>(v);
+    v = cg_dpp_add<0x118>(v);
+    return cg_dpp_add<0x142, 0xa>(v);
+}
+
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cg_lds[];
     constexpr int PLANE = CG_BK * 128, BUF = 4 * PLANE;
@@ -346,6 +366,32 @@ __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
         __syncthreads();
         if (nkt == 0 || !more) {     // this workgroup's share of `tile` is complete
             const int seg = w - a.first_wg[tile];
+            if constexpr (EPI == 1) {
+                // y contraction of n2f on the accumulators: per row m the products with E[m][n] summed over this wave's 64
+                // columns (two register tiles, then the 32 lanes of the half wave that shares the row)
+                const int slot = ((n0 / CG_BN) * 2 + wn) * a.planes + seg;
+                float2* dst = a.part + ((size_t)b * a.tiles_n * 2 * a.planes + slot) * (size_t)a.ldP;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                        float sr = 0.f, si = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int n = n0 + wn * 64 + j * 32 + rr;
+                            float2 e = make_float2(0.f, 0.f);
+                            if (m < a.M && n < a.N) e = a.E[(size_t)m * a.ldE + n];
+                            const float p1 = c1[i][j][r], p2 = c2[i][j][r];
+                            const float tr = p1 - p2, ti = c3[i][j][r] - p1 - p2;
+                            sr += tr * e.x - ti * e.y;
+                            si += tr * e.y + ti * e.x;
+                        }
+                        sr = cg_half_sum(sr);
+                        si = cg_half_sum(si);
+                        if (rr == 31 && m < a.M) dst[m] = make_float2(sr, si);
+                    }
+            } else {
             float2* C = a.C + ((size_t)b * a.planes + seg) * (size_t)a.M * a.N;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -361,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void cgemm_streamk(CgemmSkArgs a) {
                         }
                     }
                 }
+            }
             clear();
         }
         tile = ntile; kt = nkt; m0 = nm0; n0 = nn0; buf ^= 1;

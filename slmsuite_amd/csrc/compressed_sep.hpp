@@ -82,47 +82,28 @@ __global__ void sep_build_nft(const R* phase, const R* amp, const R* kern, R amp
     }
 }
 
-// ff_raw[n] = sum_s sum_y T[s][n][y] Ey[n][y] / sqrt(S)  (double accumulation), one wave per spot;
-// also the per-block partial of sum |ff_raw|^2 for c_n2f_finish.  grid = (ceil(N/4), batch), block 256
-// (stream-K GEMM: a 128 x 128 tile of T is spread over nseg[tile] of the `split` partial planes, tile = n / 128 +
-//  (y / 128) * tiles_m; the other planes of that tile were never written)
+// ff_raw[n] = sum of the partial y contractions the n2f GEMM left (cgemm_streamk<1>: one per tile column, wave column and
+// partial plane of the tile) / sqrt(S), in double; also the per-block partial of sum |ff_raw|^2 for c_n2f_finish.
+// grid = (ceil(N/256), batch), block 256
 template <typename R>
-__global__ void sep_n2f_reduce(const float2* T, int split, const int* nseg, int tiles_m, const float2* Ey, int N, int H,
-                               double inv_sqrt_s, Cx<R>* ff, double* norm_partial) {
+__global__ void sep_n2f_sum(const float2* part, int ldP, int planes, const int* nseg, int tiles_m, int tiles_n, int N,
+                            double inv_sqrt_s, Cx<R>* ff, double* norm_partial) {
     __shared__ double scratch[16];
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    double sr = 0, si = 0;
-    if (n < N) {
-        // tile column by tile column (128 values of y = two per lane, one 16-byte load), the planes that tile has
-        const float2* ey = Ey + (size_t)n * H;
-        const bool vec = (H & 1) == 0;           // rows of T and Ey are 16-byte aligned for even H
-        for (int y0 = 0; y0 < H; y0 += 128) {
-            const int ns = nseg[(n >> 7) + (y0 >> 7) * tiles_m];
-            const int y = y0 + 2 * lane;
-            if (vec && y + 1 < H) {
-                const float4 e = *reinterpret_cast<const float4*>(ey + y);
-                for (int s = 0; s < ns; ++s) {
-                    const float4 t = *reinterpret_cast<const float4*>(T + (((size_t)b * split + s) * N + n) * H + y);
-                    sr += (double)t.x * e.x - (double)t.y * e.y + (double)t.z * e.z - (double)t.w * e.w;
-                    si += (double)t.x * e.y + (double)t.y * e.x + (double)t.z * e.w + (double)t.w * e.z;
-                }
-            } else {
-                for (int yy = y; yy < min(H, y + 2); ++yy) {
-                    const float2 e = ey[yy];
-                    for (int s = 0; s < ns; ++s) {
-                        const float2 t = T[(((size_t)b * split + s) * N + n) * H + yy];
-                        sr += (double)t.x * e.x - (double)t.y * e.y;
-                        si += (double)t.x * e.y + (double)t.y * e.x;
-                    }
-                }
-            }
-        }
-    }
-    sr = wave_sum(sr);
-    si = wave_sum(si);
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
     double p2 = 0;
-    if (n < N && lane == 0) {
+    if (n < N) {
+        double sr = 0, si = 0;
+        const float2* base = part + (size_t)b * tiles_n * 2 * planes * (size_t)ldP + n;
+        for (int bn = 0; bn < tiles_n; ++bn) {
+            const int ns = nseg[(n >> 7) + bn * tiles_m];
+            for (int wn = 0; wn < 2; ++wn)
+                for (int s = 0; s < ns; ++s) {
+                    const float2 v = base[(size_t)((bn * 2 + wn) * planes + s) * ldP];
+                    sr += (double)v.x;
+                    si += (double)v.y;
+                }
+        }
         const Cx<R> f = mk<R>((R)(sr * inv_sqrt_s), (R)(si * inv_sqrt_s));
         ff[(size_t)b * N + n] = f;
         p2 = (double)f.x * f.x + (double)f.y * f.y;

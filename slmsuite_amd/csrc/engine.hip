@@ -200,7 +200,7 @@ template <typename R> struct Engine : EngineBase {
     float2* sep_ey = nullptr;       // [N][H]
     float2* sep_nfT = nullptr;      // [B][W][H]
     float2* sep_b2 = nullptr;       // [B][N][H]
-    float2* sep_c1 = nullptr;       // [B][split1][N][H]
+    float2* sep_c1 = nullptr;       // [B][tiles_n1 * 2 * split1][Np] partial y contractions of the n2f GEMM epilogue
     float2* sep_c2 = nullptr;       // [B][split2][H][W]
     double* sep_norm = nullptr;     // [B][ceil(N/4)]
     int sep_split1 = 1, sep_kper1 = 0, sep_split2 = 1, sep_kper2 = 0, sep_degx = 0, sep_degy = 0;
@@ -778,10 +778,12 @@ template <typename R> struct Engine : EngineBase {
             if (zalloc(&sep_ey, (size_t)N * H)) return HGS_ERR_DEVICE;
             if (zalloc(&sep_nfT, (size_t)B * sep_Wk * sep_Hp)) return HGS_ERR_DEVICE;  // [B][Wk][Hp]
             if (zalloc(&sep_b2, (size_t)B * sep_Nk * sep_Hp)) return HGS_ERR_DEVICE;   // [B][Nk][Hp]
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c1), (size_t)B * sep_split1 * N * H * sizeof(float2)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c1), (size_t)B * sk_tn1 * 2 * sep_split1 * sep_Np * sizeof(float2)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_c2), (size_t)B * sep_split2 * H * W * sizeof(float2)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_norm), (size_t)B * ((N + 3) / 4) * sizeof(double)));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_streamk),
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sep_norm), (size_t)B * ((N + 255) / 256) * sizeof(double)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_streamk<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cgemm_streamk<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES));
         }
         HIPCHK(hipMemcpyAsync(sep_c, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -803,15 +805,19 @@ template <typename R> struct Engine : EngineBase {
     bool use_sep() const {
         return c_sep && opt_separable && cfg.n_spots >= opt_sep_min;
     }
-    // operands planar: real array at A / Bm, imaginary one planeA / planeB floats on
+    // operands planar: real array at A / Bm, imaginary one planeA / planeB floats on.  E != nullptr: the epilogue contracts
+    // the result with E over its columns into `part` instead of storing it (n2f)
     int launch_cgemm(const float* A, size_t planeA, const float* Bm, size_t planeB, float2* C, int M, int N, int KT, int lda, int ldb,
-                     int tiles_m, int tiles_n, int planes, const int* first_wg, int G, size_t strideA, size_t strideB) {
-        CgemmSkArgs a{A, A + planeA, Bm, Bm + planeB, C, M, N, KT, lda, ldb, tiles_m, tiles_n, planes, first_wg, strideA, strideB};
-        hipLaunchKernelGGL(cgemm_streamk, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
+                     int tiles_m, int tiles_n, int planes, const int* first_wg, int G, size_t strideA, size_t strideB,
+                     const float2* E = nullptr, int ldE = 0, float2* part = nullptr, int ldP = 0) {
+        CgemmSkArgs a{A, A + planeA, Bm, Bm + planeB, C, M, N, KT, lda, ldb, tiles_m, tiles_n, planes, first_wg, strideA, strideB,
+                      E, ldE, part, ldP};
+        if (E) hipLaunchKernelGGL(cgemm_streamk<1>, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL(cgemm_streamk<0>, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
         HIPCHK(hipGetLastError());
         return 0;
     }
-    // n2f: T = Ex^T-table x nf^T on the matrix cores, then the y contraction with Ey
+    // n2f: T = Ex^T-table x nf^T on the matrix cores, contracted with Ey over y in the GEMM's epilogue
     int sep_n2f() {
         const int N = cfg.n_spots, H = g.Sh, W = g.Sw;
         hipLaunchKernelGGL(sep_build_nft<R>, dim3((W + 31) / 32, (H + 31) / 32, B), dim3(32, 8), 0, stream, (const R*)phase,
@@ -820,11 +826,12 @@ template <typename R> struct Engine : EngineBase {
         HIPCHK(hipGetLastError());
         const int t1 = sk_tm1 * sk_tn1;
         if (int e = launch_cgemm(reinterpret_cast<const float*>(sep_exT), (size_t)sep_Wk * sep_Np,
-                                 reinterpret_cast<const float*>(sep_nfT), (size_t)sep_Wk * sep_Hp, sep_c1, N, H, sk_kt1, sep_Np, sep_Hp,
-                                 sk_tm1, sk_tn1, sep_split1, sk_tab, sk_G1, 0, (size_t)2 * sep_Wk * sep_Hp)) return e;
-        const int nred = (N + 3) / 4;
-        hipLaunchKernelGGL(sep_n2f_reduce<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_split1,
-                           (const int*)(sk_tab + t1), sk_tm1, (const float2*)sep_ey, N, H, 1.0 / std::sqrt((double)S), ff, sep_norm);
+                                 reinterpret_cast<const float*>(sep_nfT), (size_t)sep_Wk * sep_Hp, nullptr, N, H, sk_kt1, sep_Np, sep_Hp,
+                                 sk_tm1, sk_tn1, sep_split1, sk_tab, sk_G1, 0, (size_t)2 * sep_Wk * sep_Hp,
+                                 (const float2*)sep_ey, H, sep_c1, sep_Np)) return e;
+        const int nred = (N + 255) / 256;
+        hipLaunchKernelGGL(sep_n2f_sum<R>, dim3(nred, B), dim3(256), 0, stream, (const float2*)sep_c1, sep_Np, sep_split1,
+                           (const int*)(sk_tab + t1), sk_tm1, sk_tn1, N, 1.0 / std::sqrt((double)S), ff, sep_norm);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(c_n2f_finish<R>, dim3(B), dim3(1024), 0, stream, cargs(), (const double*)sep_norm, nred);
         HIPCHK(hipGetLastError());

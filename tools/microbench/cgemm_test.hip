@@ -23,11 +23,11 @@ static int run_sk(const float* dA, size_t planeA, const float* dB, size_t planeB
     int* dF;
     hipMalloc(&dF, tiles * 4);
     hipMemcpy(dF, first.data(), tiles * 4, hipMemcpyHostToDevice);
-    CgemmSkArgs a{dA, dA + planeA, dB, dB + planeB, dC, M, N, KT, lda, ldb, tm, tn, planes, dF, 0, 0};
-    hipFuncSetAttribute((const void*)cgemm_streamk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES);
+    CgemmSkArgs a{dA, dA + planeA, dB, dB + planeB, dC, M, N, KT, lda, ldb, tm, tn, planes, dF, 0, 0, nullptr, 0, nullptr, 0};
+    hipFuncSetAttribute((const void*)cgemm_streamk<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(cgemm_streamk, dim3(G), dim3(256), CG_LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(cgemm_streamk<0>, dim3(G), dim3(256), CG_LDS_BYTES, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(ms_out, e0, e1);
     *planes_out = planes;
