@@ -649,7 +649,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 // the row has been on its way since the previous one was picked up: wait for this wave's pieces, meet the
                 // other waves, read; when every lane has its values the image is free for the row after this one
                 // (vmcnt(16) -- leaving the sixteen G stores of the row before in flight -- measured the same)
+                HGS_T(fft.tr_n, 30);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                HGS_T(fft.tr_n, 31);
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
                     const Cx<R> h = pimg[j + m * T];
@@ -657,7 +659,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                     else v[m] = h * sgn;
                 });
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                HGS_T(fft.tr_n, 32);
                 if (rbase + row_stride < g.Sh) prefetch_row(rbase + row_stride);
+                HGS_T(fft.tr_n, 33);
             } else
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
