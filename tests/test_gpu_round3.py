@@ -252,3 +252,29 @@ def test_engine_calls_leave_the_callers_device_alone():
     e.nearfield2farfield()
     assert torch.cuda.current_device() == before
     e.close()
+
+
+# ---- the prefetching row kernel ------------------------------------------------------------------------------
+@pytest.mark.parametrize("slm_shape", [(1152, 1920), (1200, 2304), (1300, 1000)])
+def test_prefetching_row_kernel_is_bit_identical(slm_shape, monkeypatch):
+    """
+    Dense launches between iterations on a 4096-wide pad with 1025 .. 1331 SLM rows run the row kernel that walks several
+    rows per workgroup and brings the next H row global -> LDS (row_kernel PREF) -- a different way of LOADING the same
+    values, so the phase must come out bit for bit as with the one-row-per-workgroup launch (HGS_ROW_PREF=0, read by
+    hgs_create).  The three SLM shapes cover the shifted form (SLM columns within eight register slots), the unshifted
+    one and a narrow SLM.
+    """
+    shape = (4096, 4096)
+    host = SpotHologram.make_rectangular_array(shape, (8, 8), (96, 64), basis="knm", slm_shape=slm_shape,
+                                               phase=synth.seed_phase(31, slm_shape), dtype=np.float32)
+    out = {}
+    for pref in ("1", "0"):
+        monkeypatch.setenv("HGS_ROW_PREF", pref)
+        h = SpotHologram(shape, host.spot_knm_rounded.astype(float), basis="knm", slm_shape=slm_shape,
+                         phase=synth.seed_phase(31, slm_shape), dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: 0})
+        h.optimize("WGS-Leonardo", maxiter=5, verbose=False)
+        out[pref] = (h.phase.copy(), h.weights[host.spot_knm_rounded[1], host.spot_knm_rounded[0]].copy())
+        h._release_engine()
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    np.testing.assert_array_equal(out["1"][1], out["0"][1])
+    assert np.all(np.isfinite(out["1"][0]))
