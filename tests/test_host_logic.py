@@ -41,6 +41,15 @@ def test_struct_layouts_match_header():
     assert [n for n, _ in L.hgs_step._fields_] == names
 
 
+def test_option_constants_match_header():
+    """hgs_set_option's enumerators: the ctypes module and the header must not drift apart (HGS_OPT_X = n <-> L.OPT_X)."""
+    hdr = open(os.path.join(ROOT, "include", "hgs.h")).read()
+    opts = dict(re.findall(r"\bHGS_OPT_([A-Z_]+)\s*=\s*(\d+)", hdr))
+    assert len(opts) >= 7
+    for name, val in opts.items():
+        assert getattr(L, "OPT_" + name) == int(val), name
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
