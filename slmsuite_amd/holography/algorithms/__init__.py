@@ -514,6 +514,60 @@ class Hologram:
                 self.stats["raw_farfield"].extend([np.nan for _ in range(diff)])
             self.stats["raw_farfield"][it] = np.array(self.farfield, copy=True)
 
+    def _update_stats_batch(self, n, fixed_hist, per_iter, groups):
+        """
+        What ``n`` consecutive calls of :meth:`_update_stats_dictionary` leave behind after a device-resident loop of ``n``
+        iterations starting at ``self.iter`` -- the flags are constant over such a loop except ``fixed_phase``
+        (``fixed_hist[k]``), the statistics of iteration k are ``per_iter[k][group]`` -- written range by range instead
+        of entry by entry (twenty iterations of the reference's bookkeeping cost as much as their kernels on a small grid).
+        """
+        it0 = self.iter
+        nan = np.nan
+
+        def assign(lst, values):
+            if len(lst) < it0:
+                lst.extend([nan] * (it0 - len(lst)))
+            k = min(len(lst) - it0, len(values))
+            if k > 0:
+                lst[it0:it0 + k] = values[:k]
+            lst.extend(values[k:])
+
+        def pad(lst):
+            if len(lst) < it0 + n:
+                lst.extend([nan] * (it0 + n - len(lst)))
+
+        method = self.stats["method"]
+        if len(method) < it0:
+            method.extend([""] * (it0 - len(method)))
+        assign(method, [self.flags["method"]] * n)
+        sflags = self.stats["flags"]
+        for flag in set(self.flags.keys()).union(sflags.keys()):
+            if flag not in sflags:
+                # (created by the first of the n calls with the length of the method list at that moment)
+                sflags[flag] = [nan] * max(it0, len(method) - n)
+            if flag in self.flags:
+                assign(sflags[flag], list(fixed_hist[:n]) if flag == "fixed_phase" else [self.flags[flag]] * n)
+            else:
+                pad(sflags[flag])
+        sstats = self.stats["stats"]
+        new_groups = list(groups) if per_iter is not None else []
+        grouplist = set(new_groups).union(sstats.keys())
+        if len(grouplist) > 0:
+            statlists = [set(per_iter[0][g].keys()) for g in new_groups]
+            if len(sstats) > 0:
+                statlists.append(set(sstats[next(iter(sstats))].keys()))
+            statlist = set.union(*statlists)
+            for group in grouplist:
+                if group not in sstats:
+                    sstats[group] = {}
+                for stat in statlist:
+                    if stat not in sstats[group]:
+                        sstats[group][stat] = [nan] * max(it0, len(method) - n)
+                    if group in new_groups and stat in per_iter[0][group]:
+                        assign(sstats[group][stat], [per_iter[k][group][stat] for k in range(n)])
+                    else:
+                        pad(sstats[group][stat])
+
     def _update_stats(self, stat_groups=[]):
         stats = {}
         self._calculate_stats_computational(stats, stat_groups)
@@ -565,13 +619,15 @@ class Hologram:
         NaN placeholders (iterations recorded before the flag existed) end the run: `not nan` is False.
         """
         hist = self.stats["flags"].get("fixed_phase", [])
-        if skip_last:
-            hist = hist[:-1]
+        # only WGS-Kim consults the run, and only against fix_phase_iteration: counting past it would make every call
+        # walk the whole history (thousands of entries in a re-optimisation loop)
+        method = self.flags.get("method")
+        cap = (int(self.flags.get("fix_phase_iteration", 0) or 0) + 1 if method == "WGS-Kim" else
+               1 if method is not None else len(hist))
         run = 0
-        for v in reversed(hist):
-            if isinstance(v, float) and np.isnan(v):
-                break
-            if v:
+        for i in range(len(hist) - (2 if skip_last else 1), -1, -1):
+            v = hist[i]
+            if (isinstance(v, float) and np.isnan(v)) or v or run >= cap:
                 break
             run += 1
         return run
@@ -668,10 +724,9 @@ class Hologram:
                     hist, per_iter = e.iterate_stats(st, n, groups, width, xy)
                 else:
                     hist, per_iter = e.iterate(st, n), None
-                for k in range(n):
-                    self.flags["fixed_phase"] = hist[k]
-                    self._update_stats_dictionary({} if per_iter is None else {g: per_iter[k][g][0] for g in groups})
-                    self.iter += 1
+                self._update_stats_batch(n, hist, None if per_iter is None else
+                                         [{g: per_iter[k][g][0] for g in groups} for k in range(n)], groups)
+                self.iter += n
                 self.flags["fixed_phase"] = bool(st.fixed_phase)
                 done += n
                 if bar is not None:

@@ -191,6 +191,77 @@ def test_stats_dictionary_bookkeeping():
     assert np.isnan(eff[0]) and eff[2] == 0.5
 
 
+def test_batched_stats_bookkeeping_equals_the_per_iteration_one():
+    """
+    The device-resident loop writes n iterations of flag / statistics history at once (_update_stats_batch); the result
+    must be what n calls of the reference-shaped _update_stats_dictionary produce -- fresh history, an existing one,
+    histories with holes (iterations recorded before a flag / group existed), new groups, stale groups, and an
+    ``iter`` that lags the lists.
+    """
+    import copy
+    rng = np.random.default_rng(5)
+
+    def scenario(prep):
+        a = Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
+        a._update_flags("WGS-Kim", False, None, [])
+        prep(a)
+        b = copy.deepcopy(a)
+        n = 7
+        hist = [bool(x) for x in rng.integers(0, 2, n)]
+        groups = ["computational"] if "computational" in a.stats["stats"] or rng.integers(0, 2) else []
+        per = [{g: dict(efficiency=float(rng.random()), uniformity=float(rng.random())) for g in groups} for _ in range(n)] if groups else None
+        for k in range(n):
+            a.flags["fixed_phase"] = hist[k]
+            a._update_stats_dictionary({} if per is None else per[k])
+            a.iter += 1
+        b._update_stats_batch(n, hist, per, groups)
+        b.iter += n
+        assert a.iter == b.iter
+
+        def same(x, y):
+            if isinstance(x, dict):
+                assert x.keys() == y.keys()
+                for k in x:
+                    same(x[k], y[k])
+            else:
+                assert len(x) == len(y), (len(x), len(y))
+                for u, v in zip(x, y):
+                    assert (u == v) or (isinstance(u, float) and isinstance(v, float) and np.isnan(u) and np.isnan(v)), (u, v)
+        same(a.stats, b.stats)
+
+    scenario(lambda h: None)                                            # fresh
+
+    def with_history(h):
+        for k in range(5):
+            h.flags["fixed_phase"] = False
+            h._update_stats_dictionary({"computational": dict(efficiency=0.1 * k, uniformity=0.5)} if k >= 2 else {})
+            h.iter += 1
+    scenario(with_history)
+
+    def stale_and_new(h):
+        with_history(h)
+        h.stats["flags"]["old_flag"] = [1] * 3                          # a flag that is gone, list shorter than iter
+        h.flags["brand_new_flag"] = "x"
+        h.stats["stats"]["experimental_ij"] = {"efficiency": [0.3] * 5, "uniformity": [0.2] * 5}
+    scenario(stale_and_new)
+
+    def lagging_iter(h):
+        with_history(h)
+        h.iter = 3                                                      # lists longer than iter: entries are overwritten
+    scenario(lagging_iter)
+
+
+def test_false_run_is_capped_where_only_the_threshold_matters():
+    h = Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
+    h._update_flags("WGS-Kim", False, None, [], fix_phase_iteration=4)
+    h.stats["flags"]["fixed_phase"] = [True] + [False] * 3
+    assert h._false_run() == 3
+    h.stats["flags"]["fixed_phase"] = [False] * 5000
+    assert h._false_run() == 5                                          # >= fix_phase_iteration is all the engine asks
+    h.stats["flags"]["fixed_phase"] = [False] * 10 + [np.nan, False, False]
+    assert h._false_run() == 2 and h._false_run(skip_last=True) == 1
+
+
 def test_convert_vector_knm_roundtrip():
     class Slm:
         shape = (1152, 1920)
