@@ -749,9 +749,9 @@ template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false> str
 // tools/fft_local8k_model.py is the index model.  Zero / unwanted slots: NZ leading non-zero registers (NZ <= 8: the
 // partner x[n + 4096] is zero, the radix-2 step is a copy and a twiddle) become 2 NZ leading slots of the 4096-point
 // transforms; likewise NOUT on the way back.
-template <typename R, bool RESIDENT = true> struct WgFftL8k {
+template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k {
     static constexpr int N = 8192, T = 512, IMG = 16 * 272 + 16, X1 = IMG + 1;
-    using Core = WgFftL<R, RESIDENT, 2>;
+    using Core = WgFftL<R, RESIDENT, 2, RAWBAR>;
     Core core;
     Cx<R> w2;            // W_8192^(space_lane(j))
     int tr_n = 0;
@@ -854,7 +854,7 @@ template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 4096, RESIDEN
 #endif
 #if HGS_LOCAL_FFT8K
 template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 8192, RESIDENT, RAWBAR> {
-    using type = WgFftL8k<R, RESIDENT>;
+    using type = WgFftL8k<R, RESIDENT, RAWBAR>;
     static constexpr bool local = true;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL8k<R, RESIDENT>::space_lane(j); }
 };

@@ -1285,8 +1285,12 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
 
 // EXTRAS = false compiles the MRAF / Nogrette / forward-only branches out (2.7 us of the 58 us dense launch)
 // dynamic LDS of col_tile_kernel: transform image + reduction scratch
+// (8192 points: one workgroup per CU, so nobody covers the 5.8 k cycles a tile's rows take to arrive; the NEXT tile of
+//  the workgroup is staged global -> LDS meanwhile -- TILE_PREF_SLOTS register slots of 32 bytes per lane)
+constexpr int TILE_PREF_SLOTS = 4;
+template <typename R, int N> constexpr size_t col_tile_pref_bytes() { return N >= 8192 ? (size_t)TILE_PREF_SLOTS * 2 * (N / 16) * 16 : 0; }
 template <typename R, int N> constexpr size_t col_tile_lds_bytes() {
-    return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
+    return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double) + col_tile_pref_bytes<R, N>();
 }
 
 // RULE: 0 = method and update switch read from CParams (a chain of uniform branches per pixel: five per evaluated
@@ -1304,7 +1308,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem);
     double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
 
-    using Sel = FftSel<R, N, true>;
+    constexpr bool TPREF = N >= 8192;
+    using Sel = FftSel<R, N, true, TPREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
@@ -1338,14 +1343,42 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     const R* wbase = a.w + (size_t)b * P;
     const R* tbase = a.t + (size_t)b * P;
 
+    // TPREF: staging image of the workgroup's next tile, wave-private 1 KiB blocks [slot][half][wave][lane * 16 bytes];
+    // used when the SLM rows fit the first TILE_PREF_SLOTS register slots (uniform)
+    char* pstage = reinterpret_cast<char*>(scratch + SCRATCH_DOUBLES);
+    const bool tpref = TPREF && (TILE_PREF_SLOTS * T + m0 * T - g.r0 >= g.Sh);
+    const int wv = __builtin_amdgcn_readfirstlane(j >> 6);
+    auto stage_next = [&](int nct) {
+        if constexpr (TPREF) {
+            const Cx<R>* ghn = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)nct * g.Sh * 4;
+#pragma unroll
+            for (int m = 0; m < TILE_PREF_SLOTS; ++m) {
+                const int r = r_lane + m * T;
+                if (r >= 0 && r < g.Sh) {
+                    glds16(ghn + (unsigned)r * 4u, pstage + ((m * 2 + 0) * (T / 64) + wv) * 1024);
+                    glds16(ghn + (unsigned)r * 4u + 2, pstage + ((m * 2 + 1) * (T / 64) + wv) * 1024);
+                }
+            }
+        }
+    };
 #pragma unroll 1
     for (int ct = blockIdx.x; ct < ntiles; ct += gridDim.x) {
         HGS_T(fft.tr_n, 1);
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+        const bool staged = tpref && ct != (int)blockIdx.x;
+        if constexpr (TPREF) {
+            if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own pieces (no other wave reads them)
+        }
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
             float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+            if (TPREF && staged) {
+                if (m < TILE_PREF_SLOTS && r >= 0 && r < g.Sh) {
+                    lo = *reinterpret_cast<const float4*>(pstage + ((m * 2 + 0) * (T / 64) + wv) * 1024 + (j & 63) * 16);
+                    hi = *reinterpret_cast<const float4*>(pstage + ((m * 2 + 1) * (T / 64) + wv) * 1024 + (j & 63) * 16);
+                }
+            } else
             if (HGS_ABL_GH) {
                 lo = make_float4((float)j * 1e-4f, (float)m, 0.5f, (float)ct * 1e-3f);
                 hi = make_float4(0.25f, (float)j * 2e-4f, (float)m * 0.1f, 1.f);
@@ -1357,6 +1390,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
             gtx[m][0] = lo.x; gty[m][0] = lo.y; gtx[m][1] = lo.z; gty[m][1] = lo.w;
             gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
+        }
+        if constexpr (TPREF) {
+            if (tpref && ct + (int)gridDim.x < ntiles) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the image has been read into registers
+                stage_next(ct + (int)gridDim.x);
+            }
         }
         if (ct == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
             issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
