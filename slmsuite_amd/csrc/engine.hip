@@ -1285,9 +1285,9 @@ template <typename R> struct Engine : EngineBase {
             int blocks = row_blocks;
             // (measured, tools/row_tail_probe.py: it pays where a one-row-per-workgroup launch ends in a partial round that the
             //  walk turns into a third row for a quarter to a half of the workgroups -- 1152 rows 28.1 -> 26.3 us, 1280 rows
-            //  29.1 -> 27.5 us; level at 1024 rows, behind at 1536)
+            //  29.1 -> 27.5 us, 1040 / 1088 / 1200 / 1248 rows 1.0 - 1.7 us ahead; level at 1024 rows, behind at 1312 and 1536)
             if (sizeof(R) == 4 && g.Pw == 4096 && mode == 2 && opt_row_pref && row_blocks_pref > 0 && !a.load_mask && !a.store_mask &&
-                g.Sh > 2 * row_blocks_pref && 10 * g.Sh <= 26 * row_blocks_pref) {
+                g.Sh > 2 * row_blocks_pref && 2 * g.Sh <= 5 * row_blocks_pref) {
                 a.prefetch = 1;
                 a.n_row_blocks = blocks = row_blocks_pref;
             }
