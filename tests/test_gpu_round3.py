@@ -278,3 +278,38 @@ def test_prefetching_row_kernel_is_bit_identical(slm_shape, monkeypatch):
     np.testing.assert_array_equal(out["1"][0], out["0"][0])
     np.testing.assert_array_equal(out["1"][1], out["0"][1])
     assert np.all(np.isfinite(out["1"][0]))
+
+
+# ---- engine lifetime ---------------------------------------------------------------------------------------------
+def test_engines_give_their_memory_back():
+    """
+    Create / use / destroy: every device buffer an engine allocates (incl. the lazily allocated ones -- partial planes of
+    the stream-K GEMMs, run-kernel records, column lists, statistics slots) is freed with it.  Thirty rounds of a grid
+    hologram and a compressed one may not cost device memory.
+    """
+    import torch
+    from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
+    from slmsuite_amd.holography.algorithms import CompressedSpotHologram
+
+    def one_round(k):
+        shape, slm = (512, 512), (288, 480)
+        h = SpotHologram.make_rectangular_array(shape, (6, 6), (32, 32), basis="knm", slm_shape=slm,
+                                                phase=synth.seed_phase(k, slm), dtype=np.float32)
+        h.optimize("WGS-Kim", maxiter=6, verbose=False, stat_groups=["computational"])
+        h.optimize("WGS-Leonardo", maxiter=3, verbose=False, feedback="computational_spot")
+        h._release_engine()
+        fs = SimpleFourierSLM(SimpleSLM((96, 160), pitch_um=(8, 8), wav_um=0.78))
+        for n in (40, 150):            # run kernels / matrix-core form
+            v = np.vstack([0.02 * (synth.uniform01(k, (n,), i) - 0.5) for i in range(2)])
+            c = CompressedSpotHologram(v, basis="kxy", cameraslm=fs)
+            c.optimize("WGS-Leonardo", maxiter=3, verbose=False)
+            c._release_engine()
+
+    one_round(0)                       # module load, allocator pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(1, 31):
+        one_round(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"device memory went down by {(free0 - free1) / 2**20:.1f} MiB over 30 rounds"
