@@ -224,7 +224,7 @@ template <typename R> struct Engine : EngineBase {
     bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
     bool w_pending = false;  // weights stored un-normalised, wscale holds 1/||w||
     bool has_target = false, has_spots = false;
-    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256, row_xcd = 0, tile_blocks = 0, wpartial_n = 0;
+    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256, row_xcd = 0, tile_blocks = 0, wpartial_n = 0, col_xmap = 0;
     // profiling
     bool prof = false;
     struct Ev { int kind; hipEvent_t a, b; };
@@ -350,6 +350,23 @@ template <typename R> struct Engine : EngineBase {
         cap = cap / B > 0 ? cap / B : 1;
         per = (tiles + cap - 1) / cap;
         col_blocks = (tiles + per - 1) / per;
+        // per-column fused kernel with several passes per tile (ColCfg: fewer than four columns side by side): a grid that
+        // is a multiple of 8 * passes lets the passes of a tile run on one XCD at a time (ColArgs::col_xmap); among those
+        // the one that wastes the least of its last sweep, the larger on a tie
+        col_xmap = 0;
+        {
+            const int Tc = g.Ph / 16, cpar = Tc >= 256 ? 1 : std::min(4, 256 / Tc), passes = 4 / cpar, q = 8 * passes;
+            if (passes > 1 && env_int("HGS_COL_XMAP", 1)) {
+                double best = 0;
+                int best_g = 0;
+                for (int G = q; G <= cap && G / passes <= tiles; G += q) {
+                    const int gp = G / passes, sweeps = (tiles + gp - 1) / gp;
+                    const double eff = (double)tiles / ((double)sweeps * gp);
+                    if (eff >= best - 1e-9) { best = eff; best_g = G; }
+                }
+                if (best_g > 0 && best >= 0.9) { col_blocks = best_g; col_xmap = 1; }
+            }
+        }
         tile_blocks = std::max(1, std::min(tiles, env_int("HGS_TILE_BLOCKS", n_cu * 2) / B));
         ew_blocks = (int)std::min<size_t>((P + 255) / 256, (size_t)std::max(1, n_cu * 8 / B));
 
@@ -1351,6 +1368,7 @@ template <typename R> struct Engine : EngineBase {
         ColArgs<R> a{};
         a.g = g; a.gh = gh; a.ff = ff; a.amp_ff = aff; a.pff = pff; a.w = w; a.t = t; a.wscale = wscale;
         a.wpartial = wpartial; a.fpartial = fpartial; a.tw = tw_col; a.scale = (R)(1.0 / std::sqrt((double)g.Ph));
+        a.col_xmap = col_xmap;
         return a;
     }
     int reduce(const double* partial, int n, double* out) {

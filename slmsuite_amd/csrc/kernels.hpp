@@ -814,6 +814,8 @@ template <typename R> struct ColArgs {
     // col_fused_kernel only: sparse targets.  When col_list != nullptr the kernel transforms just the
     // listed columns (those holding a non-zero weight or target): every other column of the constrained
     // farfield is exactly zero, so its inverse transform is zero and the row kernel does not read it.
+    int col_xmap;          // dense launches of col_fused_kernel with fewer than four columns per pass: the passes of one
+                           // 4-column tile go to workgroups of ONE XCD that run together (gridDim.x a multiple of 8 * PASSES)
     const int* col_list;   // [batch][Pw] compacted active columns
     const int* n_active;   // [batch]
     // fused kernels only: statistics of this iteration (hgs_iterate_stats)
@@ -1006,7 +1008,16 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
     const int n_act = listed ? a.n_active[b] : 0;
     const int n_grp = (n_act + CPAR - 1) / CPAR;
+    // XCD-aware form of the dense launch (PASSES > 1: a lane group covers CPAR of the four columns of a tile, i.e. a
+    // quarter or a half of every 64- / 32-byte tile row it touches): the PASSES column groups of a tile go to PASSES
+    // workgroups of one XCD (workgroups run round-robin over the 8 XCDs -- a speed-only assumption, as in row_kernel)
+    // that start together, so the partial rows meet in that XCD's L2 instead of being fetched PASSES times over.
+    // Sweep q of workgroup (xcd, idx): tile q * (gridDim.x / PASSES) + (idx / PASSES) * 8 + xcd, group idx % PASSES.
+    const bool xmap = !listed && PASSES > 1 && a.col_xmap != 0;
+    const int x_gp = (int)gridDim.x / PASSES;
+    const int x_t0 = (((int)blockIdx.x >> 3) / PASSES) * 8 + ((int)blockIdx.x & 7), x_p = ((int)blockIdx.x >> 3) % PASSES;
     const int ncols = listed ? ((int)blockIdx.x < n_grp ? (n_grp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
+                             : xmap ? (x_t0 < ntiles ? (ntiles - x_t0 + x_gp - 1) / x_gp : 0)
                              : my_tiles * PASSES;
     auto col_valid = [&](int q) { return !listed || ((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar < n_act; };
     R acc_w = 0;
@@ -1028,6 +1039,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             const int col = clist[min(((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar, n_act - 1)];
             ct = col >> 2;
             c4 = col & 3;
+            return;
+        }
+        if (xmap) {
+            ct = q * x_gp + x_t0;
+            c4 = x_p * CPAR + cpar;
             return;
         }
         ct = blockIdx.x + (q / PASSES) * gridDim.x;
