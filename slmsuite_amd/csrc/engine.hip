@@ -122,6 +122,7 @@ template <typename R> struct Engine : EngineBase {
     R* amp = nullptr;
     R* kern = nullptr;
     C* gh = nullptr;
+    C* gh2 = nullptr;         // single-pass MRAF: the noise-region part of the field between the column and the row kernel
     R* w = nullptr;
     R* t = nullptr;
     R* pff = nullptr;
@@ -166,6 +167,8 @@ template <typename R> struct Engine : EngineBase {
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
     int opt_row_pref = 1;                  // developer A/B (HGS_ROW_PREF=0 at create): prefetching row kernel off
+    int opt_mraf_split = 1;                // developer A/B (HGS_MRAF_SPLIT=0 at create): MRAF weight updates in two column passes
+    bool row_split = false;                // the next row kernel joins gh and gh2 (single-pass MRAF)
     int row_blocks_pref = 0;               // its grid: two workgroups per CU, whole XCD line groups
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
@@ -235,7 +238,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
-        void* ptrs[] = {phase, amp, kern, gh, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
+        void* ptrs[] = {phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -314,6 +317,7 @@ template <typename R> struct Engine : EngineBase {
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
+        opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
@@ -948,6 +952,10 @@ template <typename R> struct Engine : EngineBase {
         return launch_tile_rule(N, phase, rule, grid, s, a, m0);
     }
     static int tile_rule(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
+    static int tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) { return launch_tile_split(N, phase, nr, grid, s, a, m0); }
+    static int tile_split(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
+    static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) { return launch_row_split(N, mode, grid, s, a); }
+    static int row_split_launch(int, int, dim3, hipStream_t, const RowArgs<double>&) { return (int)hipErrorInvalidValue; }
 
     int fill_wscale_one() {
         hipLaunchKernelGGL(set_scalar<R>, dim3((B + 63) / 64), dim3(64), 0, stream, wscale, B, (R)1);
@@ -1307,6 +1315,14 @@ template <typename R> struct Engine : EngineBase {
                 g.Sh > 2 * row_blocks_pref && 2 * g.Sh <= 5 * row_blocks_pref) {
                 a.prefetch = 1;
                 a.n_row_blocks = blocks = row_blocks_pref;
+            }
+            if (row_split) {          // single-pass MRAF: H = gh * wscale + gh2 (wscale final: scale_from_sum ran)
+                a.prefetch = 0;
+                a.n_row_blocks = blocks = row_blocks;
+                a.gh2 = gh2;
+                row_split = false;
+                LCHK(row_split_launch(g.Pw, mode, dim3(blocks, B), stream, a));
+                return 0;
             }
             LCHK(launch_row<R>(g.Pw, mode, dim3(blocks + (finalize ? 1 : 0), B), stream, a));
             return 0;
@@ -1773,6 +1789,14 @@ template <typename R> struct Engine : EngineBase {
             // to be known first.  Pass 0: forward transform + weight update (+ statistics), no inverse;
             // then wscale = 1/||w'||; pass 1: forward transform again, rebuild, inverse.
             const bool two_pass = st->mraf_enabled && p.do_update;
+            // ... unless the tile-resident kernel runs the column pass: the inverse transform is linear, so it transforms the
+            // signal part (un-normalised new weights) and the noise part separately in ONE pass and the row kernel joins
+            // them once ||w'|| is known (col_tile_kernel RULE 3, row_kernel SPLIT)
+            const int Tc = g.Ph / 16;
+            const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;      // slots of the load layout the SLM rows occupy
+            const bool tile_path = !sp && sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && opt_tile;
+            const bool split = two_pass && tile_path && g.Pw >= 4096 && opt_mraf_split && !stat_ctx;
+            if (split && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
             // one more forward-only pass that just accumulates it
             const bool nog = st->method == HGS_WGS_NOGRETTE && p.do_update;
@@ -1788,7 +1812,7 @@ template <typename R> struct Engine : EngineBase {
                 });
                 if (r) return r;
             }
-            for (int pass = nog ? -1 : 0; pass < (two_pass ? 2 : 1) && !r; ++pass) {
+            for (int pass = nog ? -1 : 0; pass < (two_pass && !split ? 2 : 1) && !r; ++pass) {
                 r = timed(HGS_K_COL_FUSED, [&]() -> int {
                     ColArgs<R> a = col_args();
                     a.cp = cparams(st, p);
@@ -1800,7 +1824,7 @@ template <typename R> struct Engine : EngineBase {
                     } else if (nog) {
                         a.cp.nog = nog_dev;
                     }
-                    if (two_pass && pass == 0) {
+                    if (two_pass && !split && pass == 0) {
                         a.cp.weights_only = 1;
                         phase_mode = 0;
                     }
@@ -1814,9 +1838,6 @@ template <typename R> struct Engine : EngineBase {
                         hipLaunchKernelGGL(stat_fill_neutral, dim3((unsigned)((stat_nslots + 255) / 256)), dim3(256), 0, stream,
                                            stat_partial, stat_nslots);
                     }
-                    // slots of the load layout the SLM rows occupy (tile-resident kernel needs <= 6)
-                    const int Tc = g.Ph / 16;
-                    const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;
                     wpartial_n = col_blocks;
                     if (sp) {
                         a.col_list = col_list;
@@ -1825,7 +1846,12 @@ template <typename R> struct Engine : EngineBase {
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                         else LCHK(fused_launch(phase_mode, dim3(blocks, B), a));
-                    } else if (sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && opt_tile) {
+                    } else if (split && pass == 0) {
+                        wpartial_n = tile_blocks;
+                        a.gh2 = gh2;
+                        LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, dim3(tile_blocks, B), stream, a, m0));
+                        row_split = true;
+                    } else if (tile_path) {
                         wpartial_n = tile_blocks;
                         const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;
                         if (extras) {

@@ -423,6 +423,7 @@ template <typename R> struct RowArgs {
     const unsigned short* store_mask;   // ... / written; nullptr = every column
     Cx<R>* nf_out;       // MODE 1 only: store the complex nearfield rows [b][Sh][Sw] instead of extracting
                          // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
+    const Cx<R>* gh2;    // row_kernel SPLIT: the noise-region part of an MRAF field (layout of gh); H = gh * wscale + gh2
 };
 
 // NS < 16 (one-row workgroups only): the SLM columns occupy at most NS of the 16 register slots of the space side.  The
@@ -442,12 +443,16 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 // transforms), which is what the one-row-per-workgroup launch cannot have: there the rows of a round load, transform and
 // store in lock step and the traffic adds to the transform time.  Costs: 32 KB more LDS per
 // workgroup (two per CU), one LDS read per element, raw barriers in the transform (see WgFftL RAWBAR).
-template <typename R, int N, int MODE, int NS = 16, bool PREF = false>
+// SPLIT (single-pass MRAF, col_tile_kernel RULE 3): the column kernel left the two parts of the constrained field apart,
+// A = the signal region with the UN-normalised new weights (gh) and B = the noise region (gh2), both already transformed
+// along the columns; the row to transform is A / ||w'|| + B (the transforms are linear, and ||w'|| is known by now).
+template <typename R, int N, int MODE, int NS = 16, bool PREF = false, bool SPLIT = false>
 // (8192-wide rows: a workgroup is 8 waves, two per SIMD -- a second resident workgroup needs four waves per SIMD,
 //  i.e. at most 128 VGPRs)
 __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? HGS_ROW_OCC_8192 : PREF ? 2 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
     static_assert(NS == 16 || (RowCfg<N>::FPW == 1 && NS >= 4 && NS < 16), "row_kernel: shifted form is for one-row workgroups");
     static_assert(!PREF || (sizeof(R) == 4 && N == 4096 && MODE == 2), "row_kernel: the prefetching form is fp32, 4096 wide, MODE 2");
+    static_assert(!SPLIT || (!PREF && MODE != 0 && RowCfg<N>::T >= 256), "row_kernel: the split form reads H, one-row workgroups");
     using M = Math<R>;
     constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -670,6 +675,17 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 if constexpr (NS < 16) v[m] = h;
                 else v[m] = h * sgn;
             });
+            if constexpr (SPLIT) {
+                const R ws = a.wscale[b];
+                const Cx<R>* gh2r = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)rr * 4;
+                static_for<0, 16>([&](auto m_) {
+                    constexpr int m = m_;
+                    Cx<R> h2 = mk<R>(0, 0);
+                    if (valid && ((lmask >> m) & 1u)) h2 = (gh2r + (size_t)m * gh_step)[gh_lane];
+                    if constexpr (NS < 16) v[m] = v[m] * ws + h2;
+                    else v[m] = v[m] * ws + h2 * sgn;
+                });
+            }
             // (-1)^k H[k] conj(shift factor) -- in a pass of its own: the product is inline asm, and next to its load
             // inside the per-element branch it made every load wait for the one before
             if constexpr (NS < 16) {
@@ -814,6 +830,7 @@ template <typename R> struct ColArgs {
     // col_fused_kernel only: sparse targets.  When col_list != nullptr the kernel transforms just the
     // listed columns (those holding a non-zero weight or target): every other column of the constrained
     // farfield is exactly zero, so its inverse transform is zero and the row kernel does not read it.
+    Cx<R>* gh2;            // col_tile_kernel RULE 3 (single-pass MRAF): column-transformed noise-region part, layout of gh
     int col_xmap;          // dense launches of col_fused_kernel with fewer than four columns per pass: the passes of one
                            // 4-column tile go to workgroups of ONE XCD that run together (gridDim.x a multiple of 8 * PASSES)
     const int* col_list;   // [batch][Pw] compacted active columns
@@ -1308,10 +1325,19 @@ template <typename R, int N> constexpr size_t col_tile_pref_bytes() { return N >
 template <typename R, int N> constexpr size_t col_tile_lds_bytes() {
     return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double) + col_tile_pref_bytes<R, N>();
 }
+// RULE 3: no staging of the next tile; the noise part of the column is parked behind the scratch instead (N elements + a flag)
+template <typename R, int N> constexpr size_t col_tile_split_lds_bytes() {
+    return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double) + (size_t)N * sizeof(Cx<R>) + 16;
+}
 
 // RULE: 0 = method and update switch read from CParams (a chain of uniform branches per pixel: five per evaluated
 // pixel of a spot column, four of them taken); 1 = the WGS-Leonardo / WGS-Kim update compiled in; 2 = no weight update
 // (GS, iteration 0, the second pass of MRAF).  The hot launches use 1 / 2 (launch_tile_rule).
+// 3 = MRAF with a weight update in ONE pass (EXTRAS, rule as 0): the rebuilt field mixes the normalised new weights (signal
+// region) with the kept farfield (noise region), and ||w'|| is only known when every column is through -- but the inverse
+// transform is linear.  The signal part A = w' e^{i phi} (un-normalised) and the noise part B = mraf_factor F are transformed
+// separately (B only for columns that hold noise pixels), stored to gh / gh2, and the row kernel (SPLIT) forms A / ||w'|| + B.
+// One forward transform, one read of the column's weights and target and one of GH less than the two-pass form.
 template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0>
 __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
     using M = Math<R>;
@@ -1325,6 +1351,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
 
     constexpr bool TPREF = N >= 8192;
+    constexpr bool SPLIT = RULE == 3;
+    static_assert(!SPLIT || EXTRAS, "col_tile_kernel: RULE 3 is an EXTRAS form");
     using Sel = FftSel<R, N, true, TPREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
@@ -1344,6 +1372,10 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
     Cx<R> v[16];
     R gtx[NR][4], gty[NR][4];   // the tile (scalar arrays: arrays of 2-vectors are not promoted to registers)
+    // SPLIT: the noise part's tile.  In registers when the SLM rows occupy <= 4 slots (8-byte stores per column reach HBM
+    // as four read-modify-writes of every 32-byte tile row: measured +0.6 GB per pass at 8192^2); six slots do not fit.
+    constexpr bool BTILE = SPLIT && NR <= 4;
+    R gbx[BTILE ? NR : 1][4], gby[BTILE ? NR : 1][4];
     R wr[16], tr[16];
 
     const bool upd = do_upd || STATS || (EXTRAS && cp.mraf != 0);   // target needed by the update, the statistics, MRAF
@@ -1362,7 +1394,10 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     // TPREF: staging image of the workgroup's next tile, wave-private 1 KiB blocks [slot][half][wave][lane * 16 bytes];
     // used when the SLM rows fit the first TILE_PREF_SLOTS register slots (uniform)
     char* pstage = reinterpret_cast<char*>(scratch + SCRATCH_DOUBLES);
-    const bool tpref = TPREF && (TILE_PREF_SLOTS * T + m0 * T - g.r0 >= g.Sh);
+    const bool tpref = TPREF && !SPLIT && (TILE_PREF_SLOTS * T + m0 * T - g.r0 >= g.Sh);
+    // SPLIT: the staging space holds the noise part of the column (lane-private: element m of lane j at m T + j) and a flag
+    Cx<R>* park = reinterpret_cast<Cx<R>*>(pstage);
+    int* nflag = reinterpret_cast<int*>(pstage + (size_t)N * sizeof(Cx<R>));
     const int wv = __builtin_amdgcn_readfirstlane(j >> 6);
     auto stage_next = [&](int nct) {
         if constexpr (TPREF) {
@@ -1440,6 +1475,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     v[m] = mk<R>(0, 0);
                 }
             }
+            // SPLIT: does any lane of the workgroup meet a noise pixel in this column?  Reset here: every reader of the
+            // previous column's flag is behind a barrier of that column's transforms, every writer of this one's is
+            // behind the barriers of the forward transform below.
+            if constexpr (SPLIT) { if (j == 0) *nflag = 0; }
+            bool noise_any = false;
             fft.template fwd_lead<NR>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
 
             R* wc = a.w + cb;
@@ -1464,6 +1504,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
                     __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
                     v[m] = mk<R>(0, 0);
+                    if constexpr (SPLIT) park[m * T + j] = mk<R>(0, 0);
                     if (EXTRAS && cp.nog_pass) acc_w += (R)1;          // T == 0 -> fc = 1 (:1841)
                     return;
                 }
@@ -1511,15 +1552,26 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 v[m] = cmulc(ph, om) * wv;
                 if (EXTRAS && cp.mraf) {                              // mixed-region amplitude freedom (:1606-1653)
                     const R t = tr[m];
+                    Cx<R> nz = mk<R>(0, 0);
                     if (is_nan(t)) {                        // noise region keeps the field (times mraf_factor)
-                        v[m] = cmulc(cp.has_mraf_factor ? F * cp.mraf_factor : F, om);
+                        nz = cmulc(cp.has_mraf_factor ? F * cp.mraf_factor : F, om);
+                        if constexpr (SPLIT) {
+                            v[m] = mk<R>(0, 0);
+                            noise_any = true;
+                        } else {
+                            v[m] = nz;
+                        }
                     } else if (t == (R)0) {                 // zero region (no zero_weights feedback on this path)
                         v[m] = mk<R>(0, 0);
                         if constexpr (PHASE == 1) pf[m] = (R)0;      // atan2 of the zeroed field
                     }
+                    if constexpr (SPLIT) park[m * T + j] = nz;
+                } else if constexpr (SPLIT) {
+                    park[m * T + j] = mk<R>(0, 0);
                 }
                 if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) - 1) __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (SPLIT) { if (noise_any) *nflag = 1; }
             if constexpr (STATS) sacc.flush(stat_slot);
             // updated weights of this lane (unchanged lanes -- zeros of a sparse target -- write nothing)
             if (do_upd && w_changed) {
@@ -1553,8 +1605,44 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
 #endif
             }
+            if constexpr (SPLIT) {
+                // the noise part of this column: second inverse transform where there is one, zeros otherwise (the flag's
+                // writers are at least one barrier of the inverse above behind)
+                Cx<R>* g2 = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c;
+                const int any = __builtin_amdgcn_readfirstlane(*nflag);
+                if (any) {
+                    static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T + j]; });
+                    fft.template inv_trail<NR>(v, lds, j);
+                }
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const Cx<R> h = any ? v[m] * (sgs * a.scale) : mk<R>(0, 0);
+                    if constexpr (BTILE) {
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            gbx[m][cc] = (c == cc) ? h.x : gbx[m][cc];
+                            gby[m][cc] = (c == cc) ? h.y : gby[m][cc];
+                        }
+                    } else {
+                        const int r = r_lane + m * T;
+                        if (r >= 0 && r < g.Sh) g2[(unsigned)r * 4u] = h;
+                    }
+                }
+            }
         }
         if (EXTRAS && cp.weights_only) continue;
+        if constexpr (BTILE) {
+            Cx<R>* g2 = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const int r = r_lane + m * T;
+                if (r >= 0 && r < g.Sh) {
+                    float4* q = reinterpret_cast<float4*>(g2 + (unsigned)r * 4u);
+                    q[0] = make_float4(gbx[m][0], gby[m][0], gbx[m][1], gby[m][1]);
+                    q[1] = make_float4(gbx[m][2], gby[m][2], gbx[m][3], gby[m][3]);
+                }
+            }
+        }
         HGS_T(fft.tr_n, 6);
 #pragma unroll
         for (int m = 0; m < NR; ++m) {

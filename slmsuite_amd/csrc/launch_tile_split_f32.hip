@@ -1,0 +1,55 @@
+// Single-pass MRAF (col_tile_kernel RULE 3 + row_kernel SPLIT): the column kernel transforms the signal part and the
+// noise part of the constrained field separately, the row kernel joins them with 1 / ||w'||.  fp32, 4096 / 8192 points.
+#include "launch.hpp"
+
+namespace hgs {
+
+template <int N, int PHASE, int NR>
+static int launch_tile_split_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    constexpr size_t lds = col_tile_split_lds_bytes<float, N>();
+    auto k = col_tile_kernel<float, N, PHASE, NR, false, true, 3>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
+    return (int)hipGetLastError();
+}
+template <int N, int NR>
+static int launch_tile_split_n(int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    if (phase == 0) return launch_tile_split_one<N, 0, NR>(grid, s, a, m0);
+    if (phase == 1) return launch_tile_split_one<N, 1, NR>(grid, s, a, m0);
+    return launch_tile_split_one<N, 2, NR>(grid, s, a, m0);
+}
+
+// nr: register slots of the load layout the SLM rows occupy (<= 6); up to four keep the noise tile in registers
+int launch_tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    if (N == 4096) return nr <= 4 ? launch_tile_split_n<4096, 4>(phase, grid, s, a, m0) : launch_tile_split_n<4096, 6>(phase, grid, s, a, m0);
+    if (N == 8192) return nr <= 4 ? launch_tile_split_n<8192, 4>(phase, grid, s, a, m0) : launch_tile_split_n<8192, 6>(phase, grid, s, a, m0);
+    return (int)hipErrorInvalidValue;
+}
+
+template <int N, int MODE, int NS>
+static int launch_row_split_one(dim3 grid, hipStream_t s, const RowArgs<float>& a) {
+    constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<float>);
+    auto k = row_kernel<float, N, MODE, NS, false, true>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
+    return (int)hipGetLastError();
+}
+template <int N>
+static int launch_row_split_n(int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) {
+    if (a.shifted) return mode == 1 ? launch_row_split_one<N, 1, 8>(grid, s, a) : launch_row_split_one<N, 2, 8>(grid, s, a);
+    return mode == 1 ? launch_row_split_one<N, 1, 16>(grid, s, a) : launch_row_split_one<N, 2, 16>(grid, s, a);
+}
+
+// mode 1 / 2 (row_kernel MODE); a.gh2 set
+int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) {
+    if (mode != 1 && mode != 2) return (int)hipErrorInvalidValue;
+    if (N == 4096) return launch_row_split_n<4096>(mode, grid, s, a);
+    if (N == 8192) return launch_row_split_n<8192>(mode, grid, s, a);
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace hgs
