@@ -157,6 +157,8 @@ template <typename R> struct Engine : EngineBase {
     bool dil_valid = false;
     int n_active_max = 0, n_active_min = 0;
     bool sparse_dirty = true;
+    bool sparse_tiles = false;             // the active set is whole 4-column tiles (the tile-resident kernel walks the list)
+    int opt_tile_list = 1;                 // developer A/B (HGS_TILE_LIST=0 at create): column lists always go to the per-column kernel
     // engine policy (hgs_set_option); the grid-size tuning knobs are read from the environment once, in init()
     int opt_sparse = 1;                    // HGS_OPT_SPARSE_COLUMNS
     int opt_stepwise = 0;                  // HGS_OPT_FORCE_STEPWISE
@@ -318,6 +320,7 @@ template <typename R> struct Engine : EngineBase {
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
+        opt_tile_list = env_int("HGS_TILE_LIST", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
@@ -949,7 +952,7 @@ template <typename R> struct Engine : EngineBase {
     }
     // (the tile-resident kernel is fp32 only; this branch is never taken for double)
     static int tile_rule(int N, int phase, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-        return launch_tile_rule(N, phase, rule, grid, s, a, m0);
+        return a.col_list != nullptr ? launch_tile_rule_listed(N, phase, rule, grid, s, a, m0) : launch_tile_rule(N, phase, rule, grid, s, a, m0);
     }
     static int tile_rule(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
     static int tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) { return launch_tile_split(N, phase, nr, grid, s, a, m0); }
@@ -1350,6 +1353,12 @@ template <typename R> struct Engine : EngineBase {
         dil_lo = lo; dil_hi = hi; dil_valid = true;
         return 0;
     }
+    // the tile-resident fused column kernel applies: fp32, 4096 / 8192 rows, the SLM rows within six register slots
+    bool tile_geometry_ok() const {
+        if (sizeof(R) != 4 || g.Ph < 4096 || !opt_tile) return false;
+        const int Tc = g.Ph / 16;
+        return (g.r0 + g.Sh - 1) / Tc - g.r0 / Tc + 1 <= 6;
+    }
     // columns a workgroup pass of the column kernels handles side by side (ColCfg<N>::CPAR)
     int col_cpar() const {
         const int T = g.Ph / 16;
@@ -1368,6 +1377,36 @@ template <typename R> struct Engine : EngineBase {
         hipLaunchKernelGGL(scan_active_cols<R>, dim3(g.Pw, B), dim3(256), 0, stream, (const R*)w, (const R*)t, g.Ph, g.Pw,
                            col_active);
         HIPCHK(hipGetLastError());
+        // Where the tile-resident kernel can run the column pass and the active columns fill their 4-column tiles at least
+        // half (images, MRAF noise boxes -- not spot arrays, whose columns sit alone in their tiles), the active set is
+        // rounded to whole tiles and that kernel walks the tile list: 45 ns per column against 80 for the per-column
+        // kernel at 8192 points, and the row kernel moves whole 32-byte tile rows.
+        sparse_tiles = false;
+        if (tile_geometry_ok() && opt_tile_list) {
+            std::vector<unsigned char> act((size_t)B * g.Pw);
+            HIPCHK(hipMemcpyAsync(act.data(), col_active, act.size(), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            bool dense = true;
+            for (int b = 0; b < B && dense; ++b) {
+                int n_col = 0, n_tile = 0;
+                for (int c = 0; c < g.Pw; c += 4) {
+                    const unsigned char* q = act.data() + (size_t)b * g.Pw + c;
+                    const int k = (q[0] != 0) + (q[1] != 0) + (q[2] != 0) + (q[3] != 0);
+                    n_col += k;
+                    n_tile += k > 0;
+                }
+                dense = n_col > 0 && n_col >= 2 * n_tile;
+            }
+            if (dense) {
+                for (size_t c = 0; c < act.size(); c += 4) {
+                    const unsigned char on = (act[c] | act[c + 1] | act[c + 2] | act[c + 3]) ? 1 : 0;
+                    act[c] = act[c + 1] = act[c + 2] = act[c + 3] = on;
+                }
+                HIPCHK(hipMemcpyAsync(col_active, act.data(), act.size(), hipMemcpyHostToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream));      // (act goes out of scope)
+                sparse_tiles = true;
+            }
+        }
         hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
                            col_list, n_active_dev, lane_mask);
         HIPCHK(hipGetLastError());
@@ -1794,7 +1833,9 @@ template <typename R> struct Engine : EngineBase {
             // them once ||w'|| is known (col_tile_kernel RULE 3, row_kernel SPLIT)
             const int Tc = g.Ph / 16;
             const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;      // slots of the load layout the SLM rows occupy
-            const bool tile_path = !sp && sizeof(R) == 4 && g.Ph >= 4096 && m1 - m0 + 1 <= 6 && opt_tile;
+            const bool tile_path = (!sp || sparse_tiles) && tile_geometry_ok();
+            // (a column list rounded to whole tiles: the same kernels walk the list)
+            const int tile_grid = sp ? std::max(1, std::min(tile_blocks, n_active_max / 4)) : tile_blocks;
             const bool split = two_pass && tile_path && g.Pw >= 4096 && opt_mraf_split && !stat_ctx;
             if (split && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
@@ -1842,29 +1883,31 @@ template <typename R> struct Engine : EngineBase {
                     if (sp) {
                         a.col_list = col_list;
                         a.n_active = n_active_dev;
+                    }
+                    if (sp && !tile_path) {
                         const int blocks = list_blocks(n_active_max);
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                         else LCHK(fused_launch(phase_mode, dim3(blocks, B), a));
                     } else if (split && pass == 0) {
-                        wpartial_n = tile_blocks;
+                        wpartial_n = tile_grid;
                         a.gh2 = gh2;
-                        LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, dim3(tile_blocks, B), stream, a, m0));
+                        LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, dim3(tile_grid, B), stream, a, m0));
                         row_split = true;
                     } else if (tile_path) {
-                        wpartial_n = tile_blocks;
+                        wpartial_n = tile_grid;
                         const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;
                         if (extras) {
-                            if (a.do_stats) LCHK(launch_tile_extras_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
-                            else LCHK(launch_tile_extras<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                            if (a.do_stats) LCHK(launch_tile_extras_stats<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
+                            else LCHK(launch_tile_extras<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
                         } else {
                             // the hot launches: weight rule compiled in (col_tile_kernel RULE) where it is the
                             // Leonardo / Kim update or no update at all
                             const int rule = !opt_tile_rule ? 0 : !a.cp.do_update ? 2
                                              : (a.cp.method == HGS_WGS_LEONARDO || a.cp.method == HGS_WGS_KIM) ? 1 : 0;
-                            if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
-                            else if (rule != 0) LCHK(tile_rule(g.Ph, phase_mode, rule, dim3(tile_blocks, B), stream, a, m0));
-                            else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_blocks, B), stream, a, m0));
+                            if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
+                            else if (rule != 0) LCHK(tile_rule(g.Ph, phase_mode, rule, dim3(tile_grid, B), stream, a, m0));
+                            else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
                         }
                     } else {
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(col_blocks, B), stream, a));
@@ -2139,7 +2182,7 @@ template <typename R> struct Engine : EngineBase {
         switch (option) {
             case HGS_OPT_SPARSE_COLUMNS: opt_sparse = value ? 1 : 0; return 0;
             case HGS_OPT_FORCE_STEPWISE: opt_stepwise = value ? 1 : 0; return 0;
-            case HGS_OPT_TILE_KERNEL: opt_tile = value ? 1 : 0; return 0;
+            case HGS_OPT_TILE_KERNEL: opt_tile = value ? 1 : 0; sparse_dirty = true; return 0;
             case HGS_OPT_SEPARABLE: opt_separable = value ? 1 : 0; return 0;
             case HGS_OPT_SEPARABLE_MIN_SPOTS: opt_sep_min = value > 0 ? value : 1; return 0;
             case HGS_OPT_RUN_KERNELS: opt_run = value ? 1 : 0; return 0;

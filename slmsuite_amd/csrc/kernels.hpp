@@ -1338,7 +1338,9 @@ template <typename R, int N> constexpr size_t col_tile_split_lds_bytes() {
 // transform is linear.  The signal part A = w' e^{i phi} (un-normalised) and the noise part B = mraf_factor F are transformed
 // separately (B only for columns that hold noise pixels), stored to gh / gh2, and the row kernel (SPLIT) forms A / ||w'|| + B.
 // One forward transform, one read of the column's weights and target and one of GH less than the two-pass form.
-template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0>
+// LISTED: -1 = the tile schedule is decided at run time (a.col_list), 0 / 1 = compiled in (the hot dense launches lose
+// 0.4 us of 51.5 with the run-time form).
+template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0, int LISTED = -1>
 __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
     using M = Math<R>;
     constexpr int T = N / 16;
@@ -1367,7 +1369,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     Cx<R> om = a.tw[((m0 * (j & 15)) & 15) * (N / 16)];
     om = om * (sgn * a.scale);
     const int r_lane = js + m0 * T - g.r0;  // SLM row of slot m is r_lane + m*T
-    const int ntiles = g.Pw / 4;
+    // tile schedule: every tile of 4 columns, or (col_list != nullptr: sparse targets whose active set the host has
+    // rounded to whole tiles) the tiles of the listed columns -- entries 4 i .. 4 i + 3 of the list are tile list[4 i] / 4
+    const bool listed = LISTED < 0 ? a.col_list != nullptr : LISTED != 0;
+    const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
+    const int ntiles = listed ? (a.n_active[b] >> 2) : g.Pw / 4;
+    auto tile_of = [&](int it) -> int { return listed ? (clist[4 * it] >> 2) : it; };
     R acc_w = 0;
 
     Cx<R> v[16];
@@ -1413,10 +1420,23 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         }
     };
 #pragma unroll 1
-    for (int ct = blockIdx.x; ct < ntiles; ct += gridDim.x) {
+    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
         HGS_T(fft.tr_n, 1);
+        const int ct = tile_of(it);
+        // this workgroup's next tile, `more` = there is one (LISTED 0 keeps the plain arithmetic of the dense schedule: the
+        // hot launches are sensitive to the form of these scalar expressions, 0.6 us of 51.5)
+        int ct_nl = -1;
+        if constexpr (LISTED != 0) {
+            const int it_n = it + (int)gridDim.x;
+            ct_nl = it_n < ntiles ? tile_of(it_n) : -1;
+        }
+        auto next_ct = [&]() -> int {
+            if constexpr (LISTED == 0) return ct + (int)gridDim.x;
+            else return ct_nl;
+        };
+        auto more = [&](int nct) -> bool { return LISTED == 0 ? nct < ntiles : nct >= 0; };
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
-        const bool staged = tpref && ct != (int)blockIdx.x;
+        const bool staged = tpref && it != (int)blockIdx.x;
         if constexpr (TPREF) {
             if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own pieces (no other wave reads them)
         }
@@ -1443,12 +1463,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
         }
         if constexpr (TPREF) {
-            if (tpref && ct + (int)gridDim.x < ntiles) {
+            if (tpref && more(next_ct())) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the image has been read into registers
-                stage_next(ct + (int)gridDim.x);
+                stage_next(next_ct());
             }
         }
-        if (ct == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
+        if (it == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
             issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
 #if HGS_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1582,9 +1602,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // weights/target of the next column (or of the first column of the next tile) land
             // under the inverse transform below and the next forward transform
             {
-                const int nct = (c < 3) ? ct : ct + (int)gridDim.x;
+                const int nct = (c < 3) ? ct : next_ct();
                 const int ncol = nct * 4 + ((c + 1) & 3);
-                if (nct < ntiles)
+                if (more(nct))
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, upd, j, wr, tr);
             }
 

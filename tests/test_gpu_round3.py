@@ -343,6 +343,47 @@ def test_single_pass_mraf_matches_the_two_pass_form(n, slm, method, extra, monke
         assert ep < 2 * yp and ew < 3 * yw, (ep, yp, ew, yw)
 
 
+# ---- column lists rounded to whole tiles on the tile-resident kernel ---------------------------------------------------
+@pytest.mark.parametrize("n, slm, method, kw", [
+    (4096, (1152, 1920), "WGS-Leonardo", {}),
+    (4096, (1152, 1920), "GS", {}),
+    (4096, (800, 1280), "WGS-Kim", dict(fix_phase_iteration=1)),
+    (4096, (1152, 1920), "WGS-Leonardo", dict(mraf_factor=0.5)),          # with the single-pass MRAF form and the masked row kernel
+    (8192, (1152, 1920), "WGS-Leonardo", dict(mraf_factor=0.5)),          # cfg 5's engine-default path
+])
+def test_tile_rounded_column_list_equals_the_dense_launch(n, slm, method, kw, monkeypatch):
+    """
+    An image (or an MRAF noise box) that covers part of the farfield: the engine's default path transforms only the
+    columns that hold a non-zero weight or target.  Where those fill their 4-column tiles at least half, the set is rounded
+    to whole tiles and the tile-resident kernel walks the list (engine.hip refresh_sparse) -- the SAME kernels as the dense
+    launch (HGS_OPT_SPARSE_COLUMNS = 0), skipping tiles whose constrained field is exactly zero: phase and weights must
+    come out bit for bit.  The box starts and ends inside a tile on purpose.  Against the per-column list kernel
+    (HGS_TILE_LIST=0, what the default path used before): equal to rounding.
+    """
+    target = np.zeros((n, n), dtype=np.float32)
+    c0, c1 = n // 2 - n // 6 + 1, n // 2 + n // 5 - 2            # columns (not multiples of 4)
+    r0, r1 = n // 2 - n // 7, n // 2 + n // 7
+    if "mraf_factor" in kw:
+        target[r0 - n // 16:r1 + n // 16, c0:c1] = np.nan
+        target[r0:r1, c0 + n // 16:c1 - n // 16] = synth.random_target(9, (r1 - r0, c1 - c0 - n // 8), 0.2, 1.0)
+    else:
+        target[r0:r1, c0:c1] = synth.random_target(9, (r1 - r0, c1 - c0), 0.2, 1.0)
+    phase0 = synth.seed_phase(11, slm)
+    out = {}
+    for name, env, opts in (("list", "1", {}), ("dense", "1", {L.OPT_SPARSE_COLUMNS: 0}), ("percol", "0", {})):
+        monkeypatch.setenv("HGS_TILE_LIST", env)
+        h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options=opts)
+        h.optimize(method, maxiter=3, verbose=False, **kw)
+        out[name] = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
+        h._release_engine()
+    np.testing.assert_array_equal(out["list"][0], out["dense"][0])
+    np.testing.assert_array_equal(out["list"][1], out["dense"][1])
+    ep, ew = phase_rel_l2(out["list"][0], out["percol"][0]), rel_l2(out["list"][1], out["percol"][1])
+    report(f"tile list vs per-column list {n} {slm} {method} {sorted(kw)}", phase=ep, weights=ew)
+    assert np.all(np.isfinite(out["list"][0]))
+    assert ep < 5e-4 and ew < 5e-4, (ep, ew)           # (three bodies of a pixel-wise rule: see the single-pass MRAF test)
+
+
 # ---- engine lifetime ---------------------------------------------------------------------------------------------
 def test_engines_give_their_memory_back():
     """
