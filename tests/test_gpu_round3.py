@@ -373,15 +373,21 @@ def test_tile_rounded_column_list_equals_the_dense_launch(n, slm, method, kw, mo
     for name, env, opts in (("list", "1", {}), ("dense", "1", {L.OPT_SPARSE_COLUMNS: 0}), ("percol", "0", {})):
         monkeypatch.setenv("HGS_TILE_LIST", env)
         h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options=opts)
-        h.optimize(method, maxiter=3, verbose=False, **kw)
-        out[name] = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
+        h.optimize(method, maxiter=2, verbose=False, **kw)
+        two = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
+        h.optimize(method, maxiter=1, verbose=False, **kw)
+        out[name] = two + (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
         h._release_engine()
-    np.testing.assert_array_equal(out["list"][0], out["dense"][0])
-    np.testing.assert_array_equal(out["list"][1], out["dense"][1])
+    for k in range(4):
+        np.testing.assert_array_equal(out["list"][k], out["dense"][k])
+    # the per-column kernel rounds differently; two bodies = one weight update (a third amplifies the difference
+    # 50 - 500 x on a dense image, see the single-pass MRAF test)
     ep, ew = phase_rel_l2(out["list"][0], out["percol"][0]), rel_l2(out["list"][1], out["percol"][1])
     report(f"tile list vs per-column list {n} {slm} {method} {sorted(kw)}", phase=ep, weights=ew)
-    assert np.all(np.isfinite(out["list"][0]))
-    assert ep < 5e-4 and ew < 5e-4, (ep, ew)           # (three bodies of a pixel-wise rule: see the single-pass MRAF test)
+    assert np.all(np.isfinite(out["list"][2]))
+    # (measured 3.4e-5 / 1.6e-5 on the dense image: the level at which the reference arithmetic's own fp32 and fp64 runs part,
+    #  1.3 - 4.5e-5 in the test above; a structural error would be O(1))
+    assert ep < 2e-4 and ew < 2e-4, (ep, ew)
 
 
 # ---- engine lifetime ---------------------------------------------------------------------------------------------
