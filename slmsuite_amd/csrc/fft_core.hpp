@@ -599,7 +599,8 @@ __device__ __forceinline__ void wave_lds_order() {
 // RAWBAR: workgroup barriers as "s_waitcnt lgkmcnt(0); s_barrier" instead of __syncthreads().  For kernels that keep
 // LDS-DMA loads (global_load_lds) in flight across the transform: with such a load outstanding hipcc drains vmcnt(0)
 // ahead of every __syncthreads(), i.e. the prefetch would be waited for at the first exchange.
-template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false> struct WgFftL {
+// ES: element stride of the LDS image (8192 points: the two images interleaved element by element, ES = 2).
+template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false, int ES = 1> struct WgFftL {
     static __device__ __forceinline__ void wg_barrier() {
         if constexpr (RAWBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
@@ -659,26 +660,26 @@ template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false> str
     // forward (DIR = -1 with the table as stored; DIR = +1 gives the conjugate transform in the same flow):
     // space layout in, frequency layout out
     template <int DIR, int NZ = 16> __device__ __forceinline__ void forward_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
-        Cx<R>* rowb = lds + ROW * (p >> 4);
+        Cx<R>* rowb = lds + ES * ROW * (p >> 4);
         HGS_T(tr_n, 10);
         if (!HGS_ABL_BFLY) Dft<16, DIR, R>::template run_lead<NZ>(v);
         HGS_T(tr_n, 11);
         if (!HGS_ABL_XCHG) {   // 16 x 16 transpose inside the row of 16 lanes
-            Cx<R>* w = rowb + 17 * (p & 15);
-            static_for<0, 16>([&](auto i_) { constexpr int i = i_; w[i] = v[i]; });
+            Cx<R>* w = rowb + ES * 17 * (p & 15);
+            static_for<0, 16>([&](auto i_) { constexpr int i = i_; w[ES * i] = v[i]; });
             wave_lds_order();
-            const Cx<R>* r = rowb + (p & 15);
-            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = r[17 * m]; });
+            const Cx<R>* r = rowb + ES * (p & 15);
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = r[ES * 17 * m]; });
         }
         HGS_T(tr_n, 12);
         butterfly_pre<DIR, 1>(v, p);
         HGS_T(tr_n, 13);
         if (!HGS_ABL_XCHG) {   // cross-wave exchange: lane (row n0, k_a) register k_b -> lane k_a + 16 k_b register n0
-            Cx<R>* w = rowb + (p & 15);
-            static_for<0, 16>([&](auto r_) { constexpr int r = r_; w[16 * r] = v[r]; });
+            Cx<R>* w = rowb + ES * (p & 15);
+            static_for<0, 16>([&](auto r_) { constexpr int r = r_; w[ES * 16 * r] = v[r]; });
             wg_barrier();
-            const Cx<R>* g = lds + p;
-            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = g[ROW * m]; });
+            const Cx<R>* g = lds + ES * p;
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = g[ES * ROW * m]; });
             wg_barrier();
         }
         HGS_T(tr_n, 14);
@@ -687,28 +688,28 @@ template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false> str
     }
     // the mirror: frequency layout in, space layout out
     template <int DIR, bool LEAD, int NOUT = 16> __device__ __forceinline__ void mirror_flow(Cx<R> (&v)[16], Cx<R>* lds, int p) {
-        Cx<R>* rowb = lds + ROW * (p >> 4);
+        Cx<R>* rowb = lds + ES * ROW * (p >> 4);
         HGS_T(tr_n, 20);
         butterfly_post<DIR, 2>(v, p);
         HGS_T(tr_n, 21);
         if (!HGS_ABL_XCHG) {
             if constexpr (LEAD) wg_barrier();
-            Cx<R>* g = lds + p;
-            static_for<0, 16>([&](auto m_) { constexpr int m = m_; g[ROW * m] = v[m]; });
+            Cx<R>* g = lds + ES * p;
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; g[ES * ROW * m] = v[m]; });
             wg_barrier();
-            const Cx<R>* r = rowb + (p & 15);
-            static_for<0, 16>([&](auto r_) { constexpr int rr = r_; v[rr] = r[16 * rr]; });
+            const Cx<R>* r = rowb + ES * (p & 15);
+            static_for<0, 16>([&](auto r_) { constexpr int rr = r_; v[rr] = r[ES * 16 * rr]; });
         }
         HGS_T(tr_n, 22);
         butterfly_post<DIR, 1>(v, p);
         HGS_T(tr_n, 23);
         if (!HGS_ABL_XCHG) {
             wave_lds_order();
-            Cx<R>* w = rowb + (p & 15);
-            static_for<0, 16>([&](auto m_) { constexpr int m = m_; w[17 * m] = v[m]; });
+            Cx<R>* w = rowb + ES * (p & 15);
+            static_for<0, 16>([&](auto m_) { constexpr int m = m_; w[ES * 17 * m] = v[m]; });
             wave_lds_order();
-            const Cx<R>* r = rowb + 17 * (p & 15);
-            static_for<0, 16>([&](auto i_) { constexpr int i = i_; v[i] = r[i]; });
+            const Cx<R>* r = rowb + ES * 17 * (p & 15);
+            static_for<0, 16>([&](auto i_) { constexpr int i = i_; v[i] = r[ES * i]; });
         }
         HGS_T(tr_n, 24);
         if (!HGS_ABL_BFLY) Dft<16, DIR, R>::template run_trail<NOUT>(v);
@@ -750,8 +751,16 @@ template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false> str
 // partner x[n + 4096] is zero, the radix-2 step is a copy and a twiddle) become 2 NZ leading slots of the 4096-point
 // transforms; likewise NOUT on the way back.
 template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k {
-    static constexpr int N = 8192, T = 512, IMG = 16 * 272 + 16, X1 = IMG + 1;
-    using Core = WgFftL<R, RESIDENT, 2, RAWBAR>;
+#ifndef HGS_8K_INTERLEAVE
+#define HGS_8K_INTERLEAVE 1
+#endif
+    // images interleaved element by element (element e of image h at 2 e + h): consecutive lanes (p, 0), (p, 1) touch
+    // consecutive elements, so a 16-lane group of a ds_write_b64 (served on 32 banks) covers 16 different bank pairs.
+    // (Images 16 elements apart instead, HGS_8K_INTERLEAVE = 0: both halves of 8 lanes on the same 8 pairs, every cross-lane
+    //  write 2-way conflicted, SQ_LDS_BANK_CONFLICT 40 % of the array cycles.)
+    static constexpr bool IL = HGS_8K_INTERLEAVE != 0;
+    static constexpr int N = 8192, T = 512, IMG = IL ? 1 : 16 * 272 + 16, X1 = IL ? 513 : IMG + 1, WREG = IL ? 1088 : 544;
+    using Core = WgFftL<R, RESIDENT, 2, RAWBAR, IL ? 2 : 1>;
     Core core;
     Cx<R> w2;            // W_8192^(space_lane(j))
     int tr_n = 0;
@@ -762,8 +771,8 @@ template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k
         w2 = table[space_lane(j)];
     }
     // element offsets of X1 for lane j: its own slots (one per register and block) / block h of the pair (p, 0), (p, 1)
-    static __device__ __forceinline__ int x1_own(int j) { return 544 * (j >> 6) + (j & 63); }
-    static __device__ __forceinline__ int x1_pair(int j) { return (j & 1) * X1 + 544 * (j >> 6) + (j & 62); }
+    static __device__ __forceinline__ int x1_own(int j) { return WREG * (j >> 6) + (j & 63); }
+    static __device__ __forceinline__ int x1_pair(int j) { return (j & 1) * X1 + WREG * (j >> 6) + (j & 62); }
 
     template <int NZ> __device__ __forceinline__ void forward(Cx<R> (&v)[16], Cx<R>* lds, int j) {
         static_assert(NZ >= 2 && NZ <= 16, "WgFftL8k: leading non-zero registers");

@@ -12,18 +12,23 @@ forward : input  lane j reg r = x[s(j) + 512 r], s(j) = js(j >> 1) + 256 (j & 1)
           output lane j reg m = X[j + 512 m]                                                ("frequency layout")
 inverse : the mirror (two mirror flows, X1 backwards, radix-2 with conjugated twiddles).
 
-X1 goes through the wave's own row regions of the two images (wave W holds p in [32 W, 32 W + 32): regions 2W, 2W+1 of
-image 0 and of image 1): block c in {0: sums, 1: differences} of the wave sits in image c, slot c + i * 64 + 2 (p % 32) + h'
-for register i of lane (p, h') -- 64 consecutive slots per write instruction, 513 <= 544 slots; the one-element shift of
-block 1 puts the readers of the two halves on odd / even banks.  Images are 4368 elements apart (16 x 272 + 16: the 32-bank offset that
-keeps the interleaved halves conflict-free).
+The two images are interleaved element by element: element e of image h sits at 2 e + h (WgFftL ES = 2), so the lanes
+(p, 0), (p, 1) touch neighbouring elements in every access of the two flows.  That matters for the cross-lane ds_write_b64:
+the hardware serves them in groups of 16 lanes on 32 banks (16 elements), and with the images a constant offset apart
+(round-3 first form: 16 x 272 + 16 elements) both halves of 8 lanes fell on the same 8 elements -- every such write 2-way
+conflicted (SQ_LDS_BANK_CONFLICT 40 % of the array cycles, cfg5pad column launch 227 -> 214 us without them).
+
+X1 goes through the wave's own row regions (wave W holds p in [32 W, 32 W + 32): regions 2W, 2W+1 of both images = elements
+[1088 W, 1088 W + 1088)): block c in {0: sums, 1: differences} at 513 c + 64 i + 2 (p % 32) + h' for register i of lane
+(p, h') -- 64 consecutive elements per write instruction; the odd offset of block 1 puts the readers of the two halves on
+odd / even elements.
 """
 import numpy as np
 
 import fft_local_model as L4
 
 N, T = 8192, 512
-IMG = 16 * 272 + 16
+WREG = 2 * 2 * 272          # elements of a wave's own regions (two rows of both images)
 
 
 def s_of(j):
@@ -33,14 +38,14 @@ def s_of(j):
 def x1_slot(p, hsrc, c, i):
     """LDS element of register i of block c written by lane (p, hsrc)."""
     wave = p >> 5
-    return c * IMG + c + 272 * 2 * wave + i * 64 + 2 * (p & 31) + hsrc
+    return WREG * wave + 513 * c + i * 64 + 2 * (p & 31) + hsrc
 
 
 def forward(x, nz=16):
     """nz: registers r >= nz of every lane are zero on input (nz <= 8 prunes the radix-2 step to copies)."""
     w8 = lambda e: np.exp(-2j * np.pi * (e % N) / N)
     reg = np.array([[x[s_of(j) + 512 * r] for r in range(16)] for j in range(T)], dtype=np.complex128)
-    lds = np.full(2 * IMG, np.nan, dtype=np.complex128)
+    lds = np.full(2 * 16 * 272, np.nan, dtype=np.complex128)
     for j in range(T):
         p, h = j >> 1, j & 1
         v = reg[j].copy()
@@ -51,7 +56,7 @@ def forward(x, nz=16):
         for c in range(2):
             for i in range(8):
                 e = x1_slot(p, h, c, i)
-                assert c * IMG + 272 * 2 * (p >> 5) <= e < c * IMG + 272 * (2 * (p >> 5) + 2)     # the wave's own regions
+                assert WREG * (p >> 5) <= e < WREG * ((p >> 5) + 1)     # the wave's own regions
                 lds[e] = v[i + 8 * c]
     half = np.zeros((2, 256, 16), dtype=np.complex128)
     for j in range(T):
@@ -76,7 +81,7 @@ def forward(x, nz=16):
 
 def inverse(X):
     w8c = lambda e: np.exp(+2j * np.pi * (e % N) / N)
-    lds = np.full(2 * IMG, np.nan, dtype=np.complex128)
+    lds = np.full(2 * 16 * 272, np.nan, dtype=np.complex128)
     half = np.zeros((2, 256, 16), dtype=np.complex128)
     for h in range(2):
         Y = np.array([X[2 * k + h] for k in range(4096)])
@@ -123,3 +128,15 @@ if __name__ == "__main__":
                 banks = [x1_slot(j >> 1, hsrc, j & 1, i) % 32 for j in range(g, g + 32)]
                 worst_r = max(worst_r, 32 - len(set(banks)))
     print("X1 bank collisions per 32-lane group: writes", worst_w, "reads", worst_r)
+    # the two interleaved 4096-point flows (element of image h at 2 e + h; e(p, i) as in fft_local_model): cross-lane writes
+    # in 16-lane groups on 16 elements, reads in 32-lane groups on 32
+    pats = {"local write": lambda p, i: 272 * (p >> 4) + 17 * (p & 15) + i, "local read": lambda p, i: 272 * (p >> 4) + 17 * i + (p & 15),
+            "global scatter": lambda p, i: 272 * (p >> 4) + 16 * i + (p & 15), "global gather": lambda p, i: 272 * i + p}
+    for name, f in pats.items():
+        for width in (16, 32):
+            worst = 0
+            for i in range(16):
+                for g in range(0, T, width):
+                    el = [(2 * f(j >> 1, i) + (j & 1)) % width for j in range(g, g + width)]
+                    worst = max(worst, width - len(set(el)))
+            print(f"{name:15s} collisions per {width}-lane group on {width} elements: {worst}")
