@@ -229,7 +229,7 @@ template <typename R> struct Engine : EngineBase {
     bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
     bool w_pending = false;  // weights stored un-normalised, wscale holds 1/||w||
     bool has_target = false, has_spots = false;
-    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256, row_xcd = 0, tile_blocks = 0, wpartial_n = 0, col_xmap = 0;
+    int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256, row_xcd = 0, tile_blocks = 0, wpartial_n = 0, col_xmap = 0, list_xmap = 0;
     // profiling
     bool prof = false;
     struct Ev { int kind; hipEvent_t a, b; };
@@ -361,6 +361,7 @@ template <typename R> struct Engine : EngineBase {
         // is a multiple of 8 * passes lets the passes of a tile run on one XCD at a time (ColArgs::col_xmap); among those
         // the one that wastes the least of its last sweep, the larger on a tie
         col_xmap = 0;
+        list_xmap = env_int("HGS_COL_XMAP", 1);
         {
             const int Tc = g.Ph / 16, cpar = Tc >= 256 ? 1 : std::min(4, 256 / Tc), passes = 4 / cpar, q = 8 * passes;
             if (passes > 1 && env_int("HGS_COL_XMAP", 1)) {
@@ -1885,7 +1886,14 @@ template <typename R> struct Engine : EngineBase {
                         a.n_active = n_active_dev;
                     }
                     if (sp && !tile_path) {
-                        const int blocks = list_blocks(n_active_max);
+                        int blocks = list_blocks(n_active_max);
+                        // fewer than four columns per workgroup pass: the groups of a 4-column run of the list on one XCD
+                        // (they share 32-byte tile rows where the active set is dense; ColArgs::list_xmap)
+                        const int gp = 8 * (4 / col_cpar());
+                        if (list_xmap && col_cpar() < 4 && blocks >= gp) {
+                            blocks -= blocks % gp;
+                            a.list_xmap = 1;
+                        }
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                         else LCHK(fused_launch(phase_mode, dim3(blocks, B), a));

@@ -830,6 +830,8 @@ template <typename R> struct ColArgs {
     // col_fused_kernel only: sparse targets.  When col_list != nullptr the kernel transforms just the
     // listed columns (those holding a non-zero weight or target): every other column of the constrained
     // farfield is exactly zero, so its inverse transform is zero and the row kernel does not read it.
+    int list_xmap;         // the same for column-list launches: list groups PASSES k .. PASSES k + PASSES - 1 (the columns
+                           // of one tile where the active set is dense) on one XCD together (gridDim.x a multiple of 8 * PASSES)
     Cx<R>* gh2;            // col_tile_kernel RULE 3 (single-pass MRAF): column-transformed noise-region part, layout of gh
     int col_xmap;          // dense launches of col_fused_kernel with fewer than four columns per pass: the passes of one
                            // 4-column tile go to workgroups of ONE XCD that run together (gridDim.x a multiple of 8 * PASSES)
@@ -1033,10 +1035,15 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const bool xmap = !listed && PASSES > 1 && a.col_xmap != 0;
     const int x_gp = (int)gridDim.x / PASSES;
     const int x_t0 = (((int)blockIdx.x >> 3) / PASSES) * 8 + ((int)blockIdx.x & 7), x_p = ((int)blockIdx.x >> 3) % PASSES;
-    const int ncols = listed ? ((int)blockIdx.x < n_grp ? (n_grp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0)
+    const bool lmap = listed && PASSES > 1 && a.list_xmap != 0;
+    const int l_lim = (n_grp - x_p + PASSES - 1) / PASSES;            // lmap: 4-column runs of the list that hold a group x_p
+    // list group of sweep q
+    auto grp_of = [&](int q) -> int { return lmap ? (q * x_gp + x_t0) * PASSES + x_p : (int)blockIdx.x + q * (int)gridDim.x; };
+    const int ncols = listed ? (lmap ? (x_t0 < l_lim ? (l_lim - x_t0 + x_gp - 1) / x_gp : 0)
+                                     : ((int)blockIdx.x < n_grp ? (n_grp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0))
                              : xmap ? (x_t0 < ntiles ? (ntiles - x_t0 + x_gp - 1) / x_gp : 0)
                              : my_tiles * PASSES;
-    auto col_valid = [&](int q) { return !listed || ((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar < n_act; };
+    auto col_valid = [&](int q) { return !listed || grp_of(q) * CPAR + cpar < n_act; };
     R acc_w = 0;
     const R nogv = cp.nog != nullptr ? cp.nog[b] : (R)0;
     double* stat_slot = scratch + 16 + (tid >> 6) * STAT_N;
@@ -1053,7 +1060,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
 
     auto col_of = [&](int q, int& ct, int& c4) {
         if (listed) {
-            const int col = clist[min(((int)blockIdx.x + q * (int)gridDim.x) * CPAR + cpar, n_act - 1)];
+            const int col = clist[min(grp_of(q) * CPAR + cpar, n_act - 1)];
             ct = col >> 2;
             c4 = col & 3;
             return;
