@@ -232,11 +232,24 @@ class GridProblem:
         kim = m == "WGS-Kim"                          # after the fixing iteration the stored phase_ff is read back
         col = 2 * gh + P * r + (P * r if (wgs or self.mraf) else 0) + (w_write if wgs else 0) + (P * r if kim else 0)
         passes = 1
-        if self.mraf and wgs:
-            # two column passes: forward + weight rule (reads GH, w, t; writes w), then forward + rebuild + inverse
-            col = (gh + 2 * P * r + w_write) + (2 * gh + 2 * P * r)
-            passes = 2
         row = 2 * gh                                  # MODE 2 (between fused iterations): H read, G written
+        mraf_note = ""
+        if self.mraf and wgs:
+            Tc = Ph // 16
+            r0 = (Ph - Sh) // 2
+            slots = (r0 + Sh - 1) // Tc - r0 // Tc + 1
+            if self.args.dtype == "f32" and Ph >= 4096 and Pw >= 4096 and slots <= 6 and os.environ.get("HGS_MRAF_SPLIT", "1") != "0":
+                # one column pass (col_tile_kernel RULE 3): reads GH, w, t; writes w and the two parts of the rebuilt field
+                # (signal part un-normalised, noise part); the row kernel (SPLIT) reads both
+                col = gh + 2 * P * r + w_write + 2 * gh
+                row = 3 * gh
+                mraf_note = ("; MRAF with a weight update in ONE column pass: the signal and the noise part of the rebuilt field "
+                             "are written separately (2 x GH) and joined by the row kernel")
+            else:
+                # two column passes: forward + weight rule (reads GH, w, t; writes w), then forward + rebuild + inverse
+                col = (gh + 2 * P * r + w_write) + (2 * gh + 2 * P * r)
+                passes = 2
+                mraf_note = "; MRAF with a weight update = two column passes"
         canon_col = (4 * P * c + (3 if wgs else 1) * P * r)
         canon_iter = ((15 if wgs else 13) * P + 2 * S) * r
         ws = gh + P * r * (2 if (wgs or self.mraf) else 1)           # GH + weights (+ target)
@@ -246,9 +259,10 @@ class GridProblem:
                               f"{'target read (P*%d) + ' % r if (wgs or self.mraf) else ''}"
                               f"{'phase_ff read (P*%d, fixed phase) + ' % r if kim else ''}"
                               f"weight writes where a weight changed ({w_write} B)"
-                              + ("; MRAF with a weight update = two column passes" if passes == 2 else ""),
+                              + mraf_note,
                     row_model=f"H read + G written, SLM rows only (2 x Sh*Pw*{c} B); the phase itself is only "
-                              "written by the last row launch of a call")
+                              "written by the last row launch of a call"
+                              + ("; single-pass MRAF: the noise part is read as well (3 x)" if row == 3 * gh else ""))
 
 
 class CompressedProblem:
