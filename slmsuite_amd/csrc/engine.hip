@@ -956,7 +956,9 @@ template <typename R> struct Engine : EngineBase {
         return a.col_list != nullptr ? launch_tile_rule_listed(N, phase, rule, grid, s, a, m0) : launch_tile_rule(N, phase, rule, grid, s, a, m0);
     }
     static int tile_rule(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
-    static int tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) { return launch_tile_split(N, phase, nr, grid, s, a, m0); }
+    static int tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+        return a.do_stats ? launch_tile_split_stats(N, phase, nr, grid, s, a, m0) : launch_tile_split(N, phase, nr, grid, s, a, m0);
+    }
     static int tile_split(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
     static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) { return launch_row_split(N, mode, grid, s, a); }
     static int row_split_launch(int, int, dim3, hipStream_t, const RowArgs<double>&) { return (int)hipErrorInvalidValue; }
@@ -1837,7 +1839,7 @@ template <typename R> struct Engine : EngineBase {
             const bool tile_path = (!sp || sparse_tiles) && tile_geometry_ok();
             // (a column list rounded to whole tiles: the same kernels walk the list)
             const int tile_grid = sp ? std::max(1, std::min(tile_blocks, n_active_max / 4)) : tile_blocks;
-            const bool split = two_pass && tile_path && g.Pw >= 4096 && opt_mraf_split && !stat_ctx;
+            const bool split = two_pass && tile_path && g.Pw >= 4096 && opt_mraf_split;
             if (split && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
             // one more forward-only pass that just accumulates it

@@ -4,10 +4,19 @@
 
 namespace hgs {
 
+#ifndef HGS_SPLIT_STATS
+#define HGS_SPLIT_STATS 0      // launch_tile_split_stats_f32.hip: 1 (the same kernels accumulating the in-pass statistics)
+#endif
+#if HGS_SPLIT_STATS
+#define LAUNCH_TILE_SPLIT launch_tile_split_stats
+#else
+#define LAUNCH_TILE_SPLIT launch_tile_split
+#endif
+
 template <int N, int PHASE, int NR>
 static int launch_tile_split_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
     constexpr size_t lds = col_tile_split_lds_bytes<float, N>();
-    auto k = col_tile_kernel<float, N, PHASE, NR, false, true, 3>;
+    auto k = col_tile_kernel<float, N, PHASE, NR, HGS_SPLIT_STATS != 0, true, 3>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
@@ -21,12 +30,13 @@ static int launch_tile_split_n(int phase, dim3 grid, hipStream_t s, const ColArg
 }
 
 // nr: register slots of the load layout the SLM rows occupy (<= 6); up to four keep the noise tile in registers
-int launch_tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+int LAUNCH_TILE_SPLIT(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
     if (N == 4096) return nr <= 4 ? launch_tile_split_n<4096, 4>(phase, grid, s, a, m0) : launch_tile_split_n<4096, 6>(phase, grid, s, a, m0);
     if (N == 8192) return nr <= 4 ? launch_tile_split_n<8192, 4>(phase, grid, s, a, m0) : launch_tile_split_n<8192, 6>(phase, grid, s, a, m0);
     return (int)hipErrorInvalidValue;
 }
 
+#if !HGS_SPLIT_STATS
 template <int N, int MODE, int NS>
 static int launch_row_split_one(dim3 grid, hipStream_t s, const RowArgs<float>& a) {
     constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<float>);
@@ -51,5 +61,7 @@ int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<fl
     if (N == 8192) return launch_row_split_n<8192>(mode, grid, s, a);
     return (int)hipErrorInvalidValue;
 }
+
+#endif
 
 }  // namespace hgs

@@ -343,6 +343,35 @@ def test_single_pass_mraf_matches_the_two_pass_form(n, slm, method, extra, monke
         assert ep < 2 * yp and ew < 3 * yw, (ep, yp, ew, yw)
 
 
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_single_pass_mraf_with_in_pass_statistics(sparse, monkeypatch):
+    """
+    hgs_iterate_stats (stat_groups = ["computational"]) on an MRAF problem: the single-pass column kernel accumulates the
+    statistics of the farfield it constrains exactly as the first of the two passes did -- same numbers in the history,
+    phases as close as without statistics.  Dense launches and the tile-rounded column list.
+    """
+    n, slm = 4096, (1152, 1920)
+    target = _mraf_target(n)
+    phase0 = synth.seed_phase(13, slm)
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("HGS_MRAF_SPLIT", split)
+        h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+        h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5, stat_groups=["computational"])
+        st = h.stats["stats"]["computational"]
+        out[split] = (h.phase.copy(), {k: np.array(v, dtype=float) for k, v in st.items()})
+        h._release_engine()
+    for k, v in out["1"][1].items():
+        w = out["0"][1][k]
+        assert v.shape == w.shape and np.all(np.isfinite(v[:2])), k
+        # bodies 1 and 2 see the same farfield in both forms; body 3 follows a rebuilt field that differs by rounding
+        np.testing.assert_allclose(v[:2], w[:2], rtol=1e-6, atol=1e-9, err_msg=k)
+        np.testing.assert_allclose(v[2:], w[2:], rtol=2e-3, atol=1e-6, err_msg=k)
+    ep = phase_rel_l2(out["1"][0], out["0"][0])
+    report(f"single-pass MRAF with statistics vs two-pass, sparse={sparse}", phase_3_bodies=ep)
+    assert ep < 5e-4, ep
+
+
 # ---- column lists rounded to whole tiles on the tile-resident kernel ---------------------------------------------------
 @pytest.mark.parametrize("n, slm, method, kw", [
     (4096, (1152, 1920), "WGS-Leonardo", {}),
