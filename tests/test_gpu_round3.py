@@ -419,6 +419,37 @@ def test_tile_rounded_column_list_equals_the_dense_launch(n, slm, method, kw, mo
     assert ep < 2e-4 and ew < 2e-4, (ep, ew)
 
 
+def test_batch_with_different_tile_lists_equals_single_holograms():
+    """
+    Three holograms in one engine (batch = 3), each with its own image box and MRAF noise frame -- so each with its own
+    tile list (ColArgs::n_active per hologram, grid sized for the longest) and its own ||w'|| in the single-pass MRAF join
+    -- against three single holograms through the same kernels.  Two bodies (one weight update): the grids differ, so the
+    partial sums of ||w'|| are taken in another order and the batch normalises its targets in one go; the results agree at
+    the level two fp32 runs of a pixel-wise rule do (3e-5 measured, cf. the tests above), not bit for bit -- a wrong list,
+    count or scale would be O(1).
+    """
+    from slmsuite_amd.batch import HologramBatch
+    n, slm = 4096, (800, 1280)
+    targets = np.zeros((3, n, n), dtype=np.float32)
+    for i, (c0, c1, r0, r1) in enumerate(((1000, 1900, 1500, 2300), (2050, 3301, 1200, 2000), (600, 2500, 1900, 2100))):
+        targets[i, r0 - 100:r1 + 100, c0:c1] = np.nan
+        targets[i, r0:r1, c0 + 150:c1 - 150] = synth.random_target(40 + i, (r1 - r0, c1 - c0 - 300), 0.2, 1.0)
+    phases = np.stack([synth.seed_phase(50 + i, slm) for i in range(3)])
+    hb = HologramBatch((n, n), slm, targets, phases, dtype=np.float32)
+    try:
+        hb.optimize("WGS-Leonardo", maxiter=2, mraf_factor=0.5)
+        got = hb.phases()
+    finally:
+        hb.close()
+    for i in range(3):
+        h = Hologram(targets[i].copy(), phase=phases[i].copy(), slm_shape=slm, dtype=np.float32)
+        h.optimize("WGS-Leonardo", maxiter=2, verbose=False, mraf_factor=0.5)
+        ep = phase_rel_l2(got[i], h.phase)
+        report(f"batch of tile lists vs single hologram {i}", phase=ep)
+        assert ep < 2e-4, (i, ep)
+        h._release_engine()
+
+
 # ---- engine lifetime ---------------------------------------------------------------------------------------------
 def test_engines_give_their_memory_back():
     """
