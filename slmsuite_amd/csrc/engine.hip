@@ -956,10 +956,10 @@ template <typename R> struct Engine : EngineBase {
         return a.col_list != nullptr ? launch_tile_rule_listed(N, phase, rule, grid, s, a, m0) : launch_tile_rule(N, phase, rule, grid, s, a, m0);
     }
     static int tile_rule(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
-    static int tile_split(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-        return a.do_stats ? launch_tile_split_stats(N, phase, nr, grid, s, a, m0) : launch_tile_split(N, phase, nr, grid, s, a, m0);
+    static int tile_split(int N, int phase, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+        return a.do_stats ? launch_tile_split_stats(N, phase, nr, rule_ok, grid, s, a, m0) : launch_tile_split(N, phase, nr, rule_ok, grid, s, a, m0);
     }
-    static int tile_split(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
+    static int tile_split(int, int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
     static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) { return launch_row_split(N, mode, grid, s, a); }
     static int row_split_launch(int, int, dim3, hipStream_t, const RowArgs<double>&) { return (int)hipErrorInvalidValue; }
 
@@ -1902,7 +1902,7 @@ template <typename R> struct Engine : EngineBase {
                     } else if (split && pass == 0) {
                         wpartial_n = tile_grid;
                         a.gh2 = gh2;
-                        LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, dim3(tile_grid, B), stream, a, m0));
+                        LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, opt_tile_rule, dim3(tile_grid, B), stream, a, m0));
                         row_split = true;
                     } else if (tile_path) {
                         wpartial_n = tile_grid;

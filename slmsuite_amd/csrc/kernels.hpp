@@ -1360,13 +1360,14 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
 
     constexpr bool TPREF = N >= 8192;
-    constexpr bool SPLIT = RULE == 3;
-    static_assert(!SPLIT || EXTRAS, "col_tile_kernel: RULE 3 is an EXTRAS form");
+    constexpr bool SPLIT = RULE == 3 || RULE == 4;     // 4: ... with the WGS-Leonardo / WGS-Kim update compiled in, MRAF on, no
+    constexpr bool FIXED = RULE == 4;                  //    Nogrette sum, not forward-only (the cfg 5 launch)
+    static_assert(!SPLIT || EXTRAS, "col_tile_kernel: RULE 3 / 4 are EXTRAS forms");
     using Sel = FftSel<R, N, true, TPREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
-    const bool do_upd = RULE == 1 ? true : (RULE == 2 ? false : cp.do_update != 0);
+    const bool do_upd = (RULE == 1 || FIXED) ? true : (RULE == 2 ? false : cp.do_update != 0);
     const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
@@ -1392,7 +1393,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     R gbx[BTILE ? NR : 1][4], gby[BTILE ? NR : 1][4];
     R wr[16], tr[16];
 
-    const bool upd = do_upd || STATS || (EXTRAS && cp.mraf != 0);   // target needed by the update, the statistics, MRAF
+    const bool upd = do_upd || STATS || (EXTRAS && (FIXED || cp.mraf != 0));   // target needed by the update, the statistics, MRAF
     const R nogv = cp.nog != nullptr ? cp.nog[b] : (R)0;
     double* stat_slot = scratch + 16 + (j >> 6) * STAT_N;
     StatAcc<R> sacc;
@@ -1532,12 +1533,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
                     v[m] = mk<R>(0, 0);
                     if constexpr (SPLIT) park[m * T + j] = mk<R>(0, 0);
-                    if (EXTRAS && cp.nog_pass) acc_w += (R)1;          // T == 0 -> fc = 1 (:1841)
+                    if (EXTRAS && !FIXED && cp.nog_pass) acc_w += (R)1;          // T == 0 -> fc = 1 (:1841)
                     return;
                 }
                 const Cx<R> F = cmul(v[m], om);
                 const R p2 = F.x * F.x + F.y * F.y;
-                if (EXTRAS && cp.nog_pass) {                          // Nogrette: sum of fc = feedback / target over all pixels
+                if (EXTRAS && !FIXED && cp.nog_pass) {                          // Nogrette: sum of fc = feedback / target over all pixels
                     acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
                     v[m] = mk<R>(0, 0);
                     return;
@@ -1546,7 +1547,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 R wv = wraw * wsc;
                 if (do_upd) {
                     const R t = tr[m];
-                    if (RULE == 1 || cp.method == M_LEONARDO || cp.method == M_KIM) {
+                    if (RULE == 1 || FIXED || cp.method == M_LEONARDO || cp.method == M_KIM) {
                         R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);     // (eager + select, see col_fused_kernel)
                         fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
                         wv *= fc;
@@ -1577,7 +1578,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
                 // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
                 v[m] = cmulc(ph, om) * wv;
-                if (EXTRAS && cp.mraf) {                              // mixed-region amplitude freedom (:1606-1653)
+                if (EXTRAS && (FIXED || cp.mraf)) {                              // mixed-region amplitude freedom (:1606-1653)
                     const R t = tr[m];
                     Cx<R> nz = mk<R>(0, 0);
                     if (is_nan(t)) {                        // noise region keeps the field (times mraf_factor)
@@ -1616,7 +1617,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
 
             HGS_T(fft.tr_n, 5);
-            if (EXTRAS && cp.weights_only) continue;
+            if (EXTRAS && !FIXED && cp.weights_only) continue;
             fft.template inv_after_fwd_trail<NR>(v, lds, j);      // slots NR.. (rows outside the SLM) are not stored
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
@@ -1657,7 +1658,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
             }
         }
-        if (EXTRAS && cp.weights_only) continue;
+        if (EXTRAS && !FIXED && cp.weights_only) continue;
         if constexpr (BTILE) {
             Cx<R>* g2 = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
 #pragma unroll

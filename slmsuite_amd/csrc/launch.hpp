@@ -24,8 +24,8 @@ int launch_tile_rule_listed(int N, int phase_mode, int rule, dim3 grid, hipStrea
 
 // single-pass MRAF with a weight update (col_tile_kernel RULE 3 writes a.gh / a.gh2, row_kernel SPLIT joins them); fp32,
 // N in {4096, 8192}
-int launch_tile_split(int N, int phase_mode, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
-int launch_tile_split_stats(int N, int phase_mode, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);   // a.do_stats
+int launch_tile_split(int N, int phase_mode, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
+int launch_tile_split_stats(int N, int phase_mode, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);   // a.do_stats
 int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a);
 
 // per-column fused kernel with the rule compiled in (fp32, no statistics, none of the MRAF / Nogrette / forward-only extras)

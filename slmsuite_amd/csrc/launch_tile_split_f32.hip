@@ -13,26 +13,39 @@ namespace hgs {
 #define LAUNCH_TILE_SPLIT launch_tile_split
 #endif
 
-template <int N, int PHASE, int NR>
+template <int N, int PHASE, int NR, int RULE>
 static int launch_tile_split_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
     constexpr size_t lds = col_tile_split_lds_bytes<float, N>();
-    auto k = col_tile_kernel<float, N, PHASE, NR, HGS_SPLIT_STATS != 0, true, 3>;
+    auto k = col_tile_kernel<float, N, PHASE, NR, HGS_SPLIT_STATS != 0, true, RULE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
     return (int)hipGetLastError();
 }
+template <int N, int NR, int RULE>
+static int launch_tile_split_r(int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    if (phase == 0) return launch_tile_split_one<N, 0, NR, RULE>(grid, s, a, m0);
+    if (phase == 1) return launch_tile_split_one<N, 1, NR, RULE>(grid, s, a, m0);
+    return launch_tile_split_one<N, 2, NR, RULE>(grid, s, a, m0);
+}
+// RULE 4 (the WGS-Leonardo / WGS-Kim update and the MRAF branches compiled in) where the launch is exactly that AND walks a
+// tile list -- measured at 8192^2 (cfg 5): list launch 153.7 -> 146.8 us, dense launch 311.0 -> 315.4 us (twice each), so
+// dense launches keep the generic form; the statistics unit has the generic form only
 template <int N, int NR>
-static int launch_tile_split_n(int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-    if (phase == 0) return launch_tile_split_one<N, 0, NR>(grid, s, a, m0);
-    if (phase == 1) return launch_tile_split_one<N, 1, NR>(grid, s, a, m0);
-    return launch_tile_split_one<N, 2, NR>(grid, s, a, m0);
+static int launch_tile_split_n(int phase, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+#if !HGS_SPLIT_STATS
+    const bool fixed = a.cp.do_update && a.cp.mraf && !a.cp.nog_pass && !a.cp.weights_only && a.cp.nog == nullptr &&
+                       (a.cp.method == M_LEONARDO || a.cp.method == M_KIM) && rule_ok && a.col_list != nullptr;
+    if (fixed) return launch_tile_split_r<N, NR, 4>(phase, grid, s, a, m0);
+#endif
+    return launch_tile_split_r<N, NR, 3>(phase, grid, s, a, m0);
 }
 
 // nr: register slots of the load layout the SLM rows occupy (<= 6); up to four keep the noise tile in registers
-int LAUNCH_TILE_SPLIT(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-    if (N == 4096) return nr <= 4 ? launch_tile_split_n<4096, 4>(phase, grid, s, a, m0) : launch_tile_split_n<4096, 6>(phase, grid, s, a, m0);
-    if (N == 8192) return nr <= 4 ? launch_tile_split_n<8192, 4>(phase, grid, s, a, m0) : launch_tile_split_n<8192, 6>(phase, grid, s, a, m0);
+// rule_ok: the rule-specialised form (RULE 4) may be used
+int LAUNCH_TILE_SPLIT(int N, int phase, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+    if (N == 4096) return nr <= 4 ? launch_tile_split_n<4096, 4>(phase, rule_ok, grid, s, a, m0) : launch_tile_split_n<4096, 6>(phase, rule_ok, grid, s, a, m0);
+    if (N == 8192) return nr <= 4 ? launch_tile_split_n<8192, 4>(phase, rule_ok, grid, s, a, m0) : launch_tile_split_n<8192, 6>(phase, rule_ok, grid, s, a, m0);
     return (int)hipErrorInvalidValue;
 }
 
