@@ -1930,9 +1930,8 @@ template <typename R> struct Engine : EngineBase {
                         HIPCHK(hipGetLastError());
                     }
                     if (two_pass && pass == 0) {
-                        if (int e = reduce(wpartial, wpartial_n, sums + 2 * B)) return e;
-                        hipLaunchKernelGGL(scale_from_sum<R>, dim3((B + 63) / 64), dim3(64), 0, stream,
-                                           (const double*)(sums + 2 * B), wscale, B);
+                        hipLaunchKernelGGL(reduce_to_scale<R>, dim3(B), dim3(256), 0, stream, (const double*)wpartial, wpartial_n,
+                                           sums + 2 * B, wscale);
                         HIPCHK(hipGetLastError());
                     }
                     return 0;

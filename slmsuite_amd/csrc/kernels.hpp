@@ -1842,6 +1842,20 @@ static __global__ void reduce_partials(const double* partial, int n, double* out
     if (threadIdx.x == 0) out[b] = s;
 }
 
+// wscale[b] = 1 / sqrt(sum_i partial[b][i]) (and the sum itself to out[b]): the weight norm between the two column passes
+// of an MRAF update, or between the single pass and the row kernel that joins its parts -- one launch instead of two
+template <typename R> __global__ void reduce_to_scale(const double* partial, int n, double* out, R* wscale) {
+    __shared__ double scratch[16];
+    const int b = blockIdx.x;
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[(size_t)b * n + i];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) {
+        out[b] = s;
+        wscale[b] = (R)(1.0 / ::sqrt(s));
+    }
+}
+
 template <typename R> __global__ void set_scalar(R* p, int n, R v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
