@@ -185,6 +185,11 @@ int hgs_sync(hgs_engine* e);
  * the spot columns dilated by the integration window, the spot feedback modes.  While it is active,
  * HGS_PHASE_FF stored by WGS-Kim is refreshed on the active columns only (the rest cannot influence the
  * loop; hgs_nearfield2farfield(store_phase_ff = 1) refreshes every pixel).  0 forces the dense kernels.
+ *   Where the tile-resident kernel applies (fp32, pad_h >= 4096) and the active columns fill their 4-column tiles at
+ *   least half (images, MRAF noise boxes), the active set is rounded up to whole tiles and that kernel walks the tile
+ *   list; results are those of the dense launch bit for bit.
+ *   MRAF with a weight update runs ONE column pass on that kernel (the signal and the noise part of the rebuilt field are
+ *   transformed separately and joined by the row kernel once ||w'|| is known), two passes elsewhere.
  * HGS_OPT_FORCE_STEPWISE (default 0): hgs_iterate / hgs_iterate_stats loop the three general operators
  *   (materialised farfield) even where a fused kernel exists -- the reference's own op sequence; used by tests.
  * HGS_OPT_TILE_KERNEL (default 1): use the tile-resident fused column kernel where it applies (fp32, pad_h >= 4096).
