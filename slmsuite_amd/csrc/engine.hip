@@ -1403,7 +1403,7 @@ template <typename R> struct Engine : EngineBase {
             if (dense) {
                 for (size_t c = 0; c < act.size(); c += 4) {
                     const unsigned char on = (act[c] | act[c + 1] | act[c + 2] | act[c + 3]) ? 1 : 0;
-                    act[c] = act[c + 1] = act[c + 2] = act[c + 3] = on;
+                    for (int k = 0; k < 4; ++k) act[c + k] |= on;          // (bits 1, 2 of scan_active_cols stay per column)
                 }
                 HIPCHK(hipMemcpyAsync(col_active, act.data(), act.size(), hipMemcpyHostToDevice, stream));
                 HIPCHK(hipStreamSynchronize(stream));      // (act goes out of scope)
@@ -1902,6 +1902,7 @@ template <typename R> struct Engine : EngineBase {
                     } else if (split && pass == 0) {
                         wpartial_n = tile_grid;
                         a.gh2 = gh2;
+                        if (sp) a.col_flags = col_active;       // (scanned with the weights / target this loop started from)
                         LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, opt_tile_rule, dim3(tile_grid, B), stream, a, m0));
                         row_split = true;
                     } else if (tile_path) {

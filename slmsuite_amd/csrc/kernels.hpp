@@ -835,6 +835,8 @@ template <typename R> struct ColArgs {
     Cx<R>* gh2;            // col_tile_kernel RULE 3 (single-pass MRAF): column-transformed noise-region part, layout of gh
     int col_xmap;          // dense launches of col_fused_kernel with fewer than four columns per pass: the passes of one
                            // 4-column tile go to workgroups of ONE XCD that run together (gridDim.x a multiple of 8 * PASSES)
+    const unsigned char* col_flags;   // [batch][Pw] scan_active_cols bits, or nullptr (col_tile_kernel RULE 4 skips the inverse
+                                      // transforms of the parts that are zero in a column)
     const int* col_list;   // [batch][Pw] compacted active columns
     const int* n_active;   // [batch]
     // fused kernels only: statistics of this iteration (hgs_iterate_stats)
@@ -1508,6 +1510,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // behind the barriers of the forward transform below.
             if constexpr (SPLIT) { if (j == 0) *nflag = 0; }
             bool noise_any = false;
+            // RULE 4 with the column flags of the scan (list launches): a column without a non-zero weight has an all-zero
+            // signal part, one without a NaN target an all-zero noise part -- known before the column is touched
+            int cflags = -1;
+            if constexpr (FIXED) { if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c]; }
+            const bool has_sig = cflags < 0 || (cflags & 2) != 0;
             fft.template fwd_lead<NR>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
 
             R* wc = a.w + cb;
@@ -1618,7 +1625,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
             HGS_T(fft.tr_n, 5);
             if (EXTRAS && !FIXED && cp.weights_only) continue;
-            fft.template inv_after_fwd_trail<NR>(v, lds, j);      // slots NR.. (rows outside the SLM) are not stored
+            if (has_sig) fft.template inv_after_fwd_trail<NR>(v, lds, j);      // slots NR.. (rows outside the SLM) are not stored
+            else static_for<0, NR>([&](auto m_) { constexpr int m = m_; v[m] = mk<R>(0, 0); });
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
                 const Cx<R> h = v[m] * (sgs * a.scale);
@@ -1637,7 +1645,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 // the noise part of this column: second inverse transform where there is one, zeros otherwise (the flag's
                 // writers are at least one barrier of the inverse above behind)
                 Cx<R>* g2 = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c;
-                const int any = __builtin_amdgcn_readfirstlane(*nflag);
+                // (column flags known: no need for the LDS flag, whose writers may not be a barrier behind when the
+                //  inverse above was skipped)
+                const int any = cflags >= 0 ? ((cflags & 4) != 0) : __builtin_amdgcn_readfirstlane(*nflag);
                 if (any) {
                     static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T + j]; });
                     fft.template inv_trail<NR>(v, lds, j);
@@ -2216,17 +2226,23 @@ template <typename R> __global__ void multiplane_combine(MpArgs<R> a) {
 // ---- sparse targets: which columns hold a non-zero (or NaN) weight or target --------------------------
 // grid = (Pw, batch), one workgroup per column (contiguous Ph values of each array)
 template <typename R> __global__ void scan_active_cols(const R* w, const R* t, int Ph, int Pw, unsigned char* active) {
+    // active[col]: bit 0 = the column holds a non-zero (or NaN) weight or target; bit 1 = a non-zero weight (a "signal"
+    // column: only there is the weighted part of the constrained field non-zero); bit 2 = a NaN target (MRAF noise pixel)
     __shared__ int any;
     const int col = blockIdx.x, b = blockIdx.y;
     if (threadIdx.x == 0) any = 0;
     __syncthreads();
     const size_t base = ((size_t)b * Pw + col) * Ph;
-    bool nz = false;
+    bool nz = false, sig = false, noise = false;
     for (int i = threadIdx.x; i < Ph; i += blockDim.x) {
         const R wv = w[base + i], tv = t[base + i];
         nz = nz || !(wv == (R)0) || !(tv == (R)0);      // NaN counts as active
+        sig = sig || !(wv == (R)0);
+        noise = noise || (tv != tv);
     }
-    if (__builtin_amdgcn_ballot_w64(nz) != 0 && (threadIdx.x & 63) == 0) any = 1;
+    const int bits = (__builtin_amdgcn_ballot_w64(nz) != 0 ? 1 : 0) | (__builtin_amdgcn_ballot_w64(sig) != 0 ? 2 : 0) |
+                     (__builtin_amdgcn_ballot_w64(noise) != 0 ? 4 : 0);
+    if (bits != 0 && (threadIdx.x & 63) == 0) atomicOr(&any, bits);
     __syncthreads();
     if (threadIdx.x == 0) active[(size_t)b * Pw + col] = (unsigned char)any;
 }
