@@ -1510,8 +1510,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // behind the barriers of the forward transform below.
             if constexpr (SPLIT) { if (j == 0) *nflag = 0; }
             bool noise_any = false;
-            // RULE 4 with the column flags of the scan (list launches): a column without a non-zero weight has an all-zero
-            // signal part, one without a NaN target an all-zero noise part -- known before the column is touched
+            // RULE 4 with the column flags of the scan (list launches): a column without a finite non-zero target has an
+            // all-zero signal part, one without a NaN target an all-zero noise part -- known before the column is touched
             int cflags = -1;
             if constexpr (FIXED) { if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c]; }
             const bool has_sig = cflags < 0 || (cflags & 2) != 0;
@@ -2226,8 +2226,9 @@ template <typename R> __global__ void multiplane_combine(MpArgs<R> a) {
 // ---- sparse targets: which columns hold a non-zero (or NaN) weight or target --------------------------
 // grid = (Pw, batch), one workgroup per column (contiguous Ph values of each array)
 template <typename R> __global__ void scan_active_cols(const R* w, const R* t, int Ph, int Pw, unsigned char* active) {
-    // active[col]: bit 0 = the column holds a non-zero (or NaN) weight or target; bit 1 = a non-zero weight (a "signal"
-    // column: only there is the weighted part of the constrained field non-zero); bit 2 = a NaN target (MRAF noise pixel)
+    // active[col]: bit 0 = the column holds a non-zero (or NaN) weight or target; bit 1 = a finite non-zero target (under
+    // MRAF only there is the weighted part of the constrained field non-zero, whatever the weights: NaN and zero targets
+    // override it, :1606-1653); bit 2 = a NaN target (MRAF noise pixel)
     __shared__ int any;
     const int col = blockIdx.x, b = blockIdx.y;
     if (threadIdx.x == 0) any = 0;
@@ -2237,7 +2238,7 @@ template <typename R> __global__ void scan_active_cols(const R* w, const R* t, i
     for (int i = threadIdx.x; i < Ph; i += blockDim.x) {
         const R wv = w[base + i], tv = t[base + i];
         nz = nz || !(wv == (R)0) || !(tv == (R)0);      // NaN counts as active
-        sig = sig || !(wv == (R)0);
+        sig = sig || (tv == tv && tv != (R)0);
         noise = noise || (tv != tv);
     }
     const int bits = (__builtin_amdgcn_ballot_w64(nz) != 0 ? 1 : 0) | (__builtin_amdgcn_ballot_w64(sig) != 0 ? 2 : 0) |
