@@ -4,6 +4,15 @@ Benchmark of the hologram optimize() hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg2|...] [--batch B]
 
+``--gpus N`` with N > 1 needs N ranks, one per GPU.  Under a launcher (the driver's ``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``) the ranks come from RANK / LOCAL_RANK / WORLD_SIZE; called plainly,
+``python bench.py --gpus N`` launches exactly that command itself and returns its exit code.  It never prints a line for
+fewer GPUs than asked for: fewer visible devices, a WORLD_SIZE that differs from N or a process group of another size end
+the run non-zero.  The default workload is then ``cfg3`` (BASELINE configs[2]: cfg 2 with 8 holograms per GPU, weak
+scaling); ``process_group`` / ``rccl_ranks`` are read back from the group, ``gathered`` says what the final all-gather of
+the phase masks moved and that every rank checked it, and ``one_hologram_per_gpu`` is the cfg 2 rate on every rank (the
+``--gpus 1`` default workload) so that an efficiency on equal per-GPU work can be formed from the N = 1 line.
+
 A *step* is one loop body of optimize_gs (nearfield -> farfield -> constraint / weight update ->
 nearfield) of the named workload, state resident in HBM when the timed region starts.  The default
 workload is BASELINE.json config 2 (the configuration the metric is quoted on): SpotHologram, 32 x 32
@@ -114,7 +123,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--reps", type=int, default=10, help="repetitions of the K-step timed region; the median is reported")
     ap.add_argument("--batch", type=int, default=None, help="independent holograms per GPU (cfg3: 8)")
-    ap.add_argument("--workload", default="cfg2", choices=ALL_WORKLOADS)
+    ap.add_argument("--workload", default=None, choices=ALL_WORKLOADS,
+                    help="default: cfg2 on one GPU, cfg3 (cfg 2 with 8 holograms per GPU, BASELINE configs[2]) on several")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo: self-test of the launcher on one device)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="let ranks share GPUs (device = LOCAL_RANK %% device_count); needs --backend gloo -- RCCL wants one "
+                         "device per rank.  Launcher self-test only: the line is marked, its value is not a scaling figure")
     ap.add_argument("--method", default=None)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--spots", type=int, default=None, help="cfg4 / cfg4grid: number of spots (default 10000; cfg4zern: 1000)")
@@ -132,6 +147,12 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], help="engine option NAME=VALUE (hgs_set_option), e.g. "
                                                                "TILE_KERNEL=0")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.share_devices and a.backend != "gloo":
+        ap.error("--share-devices needs --backend gloo (RCCL refuses two ranks on one device)")
+    if a.workload is None:
+        a.workload = "cfg2" if a.gpus == 1 else "cfg3"
     if a.steps is None:
         a.steps = 20 if a.workload == "refbench" else 200
     a.reps = max(1, a.reps)
@@ -324,13 +345,18 @@ class RefBenchProblem:
         self.desc = "Hologram, 20 random unit pixels, S = P (test_algorithms.py:121-145), whole optimize() calls"
         self.method = args.method
 
+    # optimize() leaves its trailing transform (_populate_results, _hologram.py:934-949) to whoever reads the results;
+    # the reference runs it inside the call and so does the CPU baseline, so the timed region flushes it: every timed
+    # call is maxiter loop bodies + one forward transform, on both sides
     def warm(self, n):
         self.h.optimize(self.method, maxiter=max(1, n), verbose=False, stat_groups=[])
+        self.h._flush_populate()
         self.engine.sync()
 
     def run(self, n):
         t0 = time.perf_counter()
         self.h.optimize(self.method, maxiter=n, verbose=False, stat_groups=[])
+        self.h._flush_populate()
         self.engine.sync()
         return (time.perf_counter() - t0) * 1e3
 
@@ -524,6 +550,13 @@ def pmc_traffic(args, kernel_substrings):
                  "(gfx950 half-count), WRITE_SIZE as reported; the fabric counters include Infinity-Cache hits")
 
 
+def _gather_ints(dist, torch, dev, value, world):
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [int(o.item()) for o in out]
+
+
 def apply_opts(engine, opts):
     from slmsuite_amd import _lib as L
     for o in opts:
@@ -531,21 +564,67 @@ def apply_opts(engine, opts):
         engine.set_option(getattr(L, "OPT_" + name.upper()), int(val))
 
 
+def self_launch(args):
+    """
+    ``python bench.py --gpus N`` (N > 1) outside a launcher: re-run this very command line under
+    ``python -m torch.distributed.run`` with one rank per GPU (the form the driver uses itself) and hand its exit code
+    back.  Fails loudly -- non-zero, nothing printed on stdout -- when the box has fewer than N devices.
+    """
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < 1:
+        print(f"bench.py --gpus {args.gpus}: no GPU visible (the engine has no CPU fallback)", file=sys.stderr)
+        return 2
+    if n_dev < args.gpus and not args.share_devices:
+        print(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible; refusing to report a {args.gpus}-GPU figure "
+              f"from fewer devices", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched and not args.pmc_child:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.pmc_child:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the line would report the wrong "
+                         f"number of GPUs (launch {args.gpus} ranks, or let bench.py launch them itself)")
     import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    if args.share_devices:
+        local_rank %= n_dev
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} has no device ({n_dev} visible); --gpus {args.gpus} needs one GPU per rank")
     dist = None
+    on_device = True           # tensors of the timing collectives: device memory over RCCL, host memory over gloo
     if (world > 1 or args.force_dist) and not args.pmc_child:
         import torch.distributed as dist
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)         # --force-dist outside a launcher: a one-rank group
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+            on_device = False
+        if dist.get_world_size() != args.gpus and not args.force_dist:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus} asked for")
+    coll_dev = torch.device("cuda", local_rank) if on_device else torch.device("cpu")
 
     from slmsuite_amd import _lib as L
 
@@ -560,12 +639,6 @@ def main():
     if refbench:            # the class surface as a user drives it: engine defaults
         args.sparse_columns = 1
 
-    def barrier():
-        prob.engine.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
     if spot:
         prob.engine.set_option(L.OPT_SPARSE_COLUMNS, args.sparse_columns)
     # warmup (also takes the hologram past iteration 0 so every timed step updates weights)
@@ -576,24 +649,47 @@ def main():
         prob.close()
         return
     # timed region, --reps times: EXACTLY K steps between barrier + synchronize, the slowest rank counts
-    walls, events, rank_walls = [], [], []
-    for _ in range(args.reps):
-        barrier()
-        t0 = time.perf_counter()
-        ms_ev = prob.run(args.steps)
-        barrier()
-        mine = time.perf_counter() - t0
-        tmax = torch.tensor([mine], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            every = [torch.zeros_like(tmax) for _ in range(world)]
-            dist.all_gather(every, tmax)
-            rank_walls.append([float(x.item()) for x in every])
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        walls.append(float(tmax.item()))
-        events.append(ms_ev)
-    order = sorted(range(args.reps), key=lambda i: walls[i])
-    mid = order[len(order) // 2]
+    def timed_region(pb):
+        def sync_all():
+            pb.engine.sync()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+        ws, evs, rws = [], [], []
+        for _ in range(args.reps):
+            sync_all()
+            t0 = time.perf_counter()
+            ms_ev = pb.run(args.steps)
+            sync_all()
+            mine = time.perf_counter() - t0
+            tmax = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
+            if dist is not None:
+                every = [torch.zeros_like(tmax) for _ in range(world)]
+                dist.all_gather(every, tmax)
+                rws.append([float(x.item()) for x in every])
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ws.append(float(tmax.item()))
+            evs.append(ms_ev)
+        mid_ = sorted(range(args.reps), key=lambda i: ws[i])[len(ws) // 2]
+        return ws, evs, rws, mid_
+
+    walls, events, rank_walls, mid = timed_region(prob)
     wall, ms_events = walls[mid], events[mid]
+
+    # several ranks on the default workload (cfg 3: eight holograms per GPU): the one-hologram-per-GPU rate as well, i.e.
+    # the N = 1 default workload (cfg 2) on every rank, so that a scaling figure on EQUAL per-GPU work can be formed
+    one_per_gpu = None
+    if world > 1 and args.workload == "cfg3" and args.batch != 1 and not args.no_extra_pass:
+        a1 = argparse.Namespace(**vars(args))
+        a1.workload, a1.batch = "cfg2", 1
+        p1 = GridProblem(a1, rank, local_rank)
+        apply_opts(p1.engine, args.opt)
+        p1.engine.set_option(L.OPT_SPARSE_COLUMNS, args.sparse_columns)
+        p1.warm(args.warmup)
+        w1, _, _, m1 = timed_region(p1)
+        p1.close()
+        one_per_gpu = {"workload": "cfg2 on every rank (one hologram per GPU: the --gpus 1 default)", "value": world * args.steps / w1[m1],
+                       "unit": "iterations/s", "ms_per_step": w1[m1] * 1e3 / args.steps}
 
     # roofline pass: same K steps again with per-launch HIP events on the engine stream
     prof = None
@@ -617,15 +713,26 @@ def main():
         prob.engine.set_option(L.OPT_SPARSE_COLUMNS, 0)
 
     # final gather of the phase masks over RCCL, device memory -> RCCL, timed separately
-    gather_ms = None
-    if dist is not None and not compressed:
+    gather_ms, gathered, group_info = None, None, None
+    if dist is not None and not compressed and not refbench:
         torch.cuda.synchronize()
+        dist.barrier()
         t1 = time.perf_counter()
         ph = prob.phases_device(torch, local_rank)
+        if not on_device:
+            ph = ph.cpu()
         out = [torch.empty_like(ph) for _ in range(world)]
         dist.all_gather(out, ph)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
+        # every rank must now hold every rank's masks: finite, and its own shard back unchanged
+        ok = all(bool(torch.isfinite(o).all().item()) for o in out) and bool(torch.equal(out[rank], ph))
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gathered = {"masks": world * args.batch, "bytes": world * ph.numel() * ph.element_size(), "verified_on_every_rank": bool(flag.item() == 1.0)}
+    if dist is not None:
+        group_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                      "devices": sorted(set(_gather_ints(dist, torch, coll_dev, local_rank, world)))}
 
     ref_methods = None
     if refbench and not args.no_extra_pass:
@@ -766,6 +873,15 @@ def main():
         if rank_walls:
             med = [sorted(r[i] for r in rank_walls)[len(rank_walls) // 2] for i in range(world)]
             line["per_rank_its"] = [args.batch * args.steps / t for t in med]
+        if group_info is not None:
+            line["process_group"] = group_info      # read back from the group: backend ("nccl" = RCCL), ranks, device per rank
+            line["rccl_ranks"] = group_info["ranks"] if group_info["backend"] == "nccl" else 0
+            line["gathered"] = gathered
+        if one_per_gpu is not None:
+            line["one_hologram_per_gpu"] = one_per_gpu
+        if args.share_devices:
+            line["launcher_self_test"] = (f"{world} ranks share {n_dev} device(s) over {args.backend}: exercises the launcher and the "
+                                          "collectives, NOT a scaling measurement")
         if ref_methods is not None:
             line["methods"] = ref_methods
             line["methods_note"] = ("iterations/s of whole optimize(method, maxiter=K, stat_groups=[]) calls from a reset state, median; "

@@ -64,3 +64,55 @@ def test_two_processes_drive_the_engine_and_gather():
         assert res.shape == (N_HOLO,) + SLM
         # a shard is a smaller batch of the same kernels: identical arithmetic per hologram
         np.testing.assert_array_equal(res, want)
+
+
+def _bench(argv, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_launches_its_own_ranks():
+    """
+    ``python bench.py --gpus 2`` with no launcher around it (the form the driver uses for N = 1) must come back with a
+    TWO-rank line.  The box has one GPU, so the two ranks share it over gloo (RCCL wants a device per rank); everything
+    else -- the self-launch under torch.distributed.run, rank binding, barriers, max-over-ranks timing, the gather of
+    the phase masks and its check on every rank -- is the path an 8-GPU node takes.
+    """
+    r, lines = _bench(["--gpus", "2", "--backend", "gloo", "--share-devices", "--steps", "4", "--warmup", "2", "--reps", "2",
+                       "--no-roofline-pass"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["process_group"]["ranks"] == 2 and d["process_group"]["backend"] == "gloo"
+    assert d["rccl_ranks"] == 0                                  # honest: this was not RCCL
+    assert d["config"]["holograms_per_gpu"] == 8 and "cfg3" in d["config"]["workload"]
+    assert len(d["per_rank_its"]) == 2 and all(v > 0 for v in d["per_rank_its"])
+    assert d["gathered"]["masks"] == 16 and d["gathered"]["verified_on_every_rank"] is True
+    assert d["gather_ms"] > 0 and d["value"] > 0
+    assert d["one_hologram_per_gpu"]["value"] > 0
+    assert "launcher_self_test" in d
+
+
+def test_bench_one_rank_rccl_group():
+    """The RCCL branch itself on the one device there is: a one-rank nccl group, gather included."""
+    r, lines = _bench(["--gpus", "1", "--force-dist", "--workload", "small", "--batch", "3", "--steps", "4", "--warmup", "2",
+                       "--reps", "2", "--no-roofline-pass", "--cpu-iters", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["process_group"]["backend"] == "nccl"
+    assert d["gathered"]["masks"] == 3 and d["gathered"]["verified_on_every_rank"] is True
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import torch
+    n = torch.cuda.device_count()
+    r, lines = _bench(["--gpus", str(n + 1), "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0 and lines == []
+    assert f"only {n} GPU" in r.stderr

@@ -4,6 +4,7 @@ declares, the class surface builds the same host state as the reference (checked
 golden fixtures), flag / history logic, and the loud failure without a GPU.  No compute calls.
 """
 import os
+import sys
 import re
 
 import numpy as np
@@ -442,3 +443,33 @@ def test_asan_build_of_the_shim_is_clean():
     assert "asan-ok" in p.stdout and p.returncode == 0, p.stderr[-2000:]
     assert "AddressSanitizer" not in p.stderr, p.stderr[-2000:]
 
+
+
+# ---- bench.py --gpus N: never a line for fewer GPUs than asked for ------------------------------------------------------
+def _run_bench(argv, env_extra=None):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_gpus_n_fails_loudly_without_n_devices():
+    """``bench.py --gpus 2`` on a box without two GPUs: non-zero exit, a reason on stderr, no JSON line on stdout."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here: the launcher would run")
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and ("GPU" in r.stderr)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
+def test_bench_gpus_n_rejects_a_mismatched_launch():
+    """A launcher that started another number of ranks than --gpus says must not produce a line either."""
+    r = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
