@@ -218,6 +218,18 @@ int hgs_profile_read(hgs_engine* e, double* out);
  * stream (SURVEY 8d timing protocol) */
 int hgs_iterate_timed(hgs_engine* e, hgs_step* step, int n_iter, double* ms);
 
+/* Dispatch record: which kernel template instance each launch of this engine went to since the previous call, one line
+ * per (instance, run-time flags):
+ *     "col_tile_kernel<R=float,N=4096,PHASE=0,NR=6,STATS=false,EXTRAS=false,RULE=1,LISTED=0> xmap\t50\n"
+ * (family, its template arguments by name -- the ones rocprofv3 prints positionally --, flags list / load_mask /
+ * store_mask / xmap / batch / stats / nf_out, launch count).  Families: row_kernel, col_kernel, col_fused_kernel,
+ * col_tile_kernel, bluestein_lines, c_n2f_run, c_f2n_run, c_n2f_partial, c_f2n, cgemm_streamk (the small element-wise /
+ * reduction helpers are not recorded).  The tests assert it next to the numbers: neighbouring variants often agree to
+ * the last bit, so only this shows that a policy reached the kernel it names.  `needed` (optional) receives the bytes
+ * the text takes including the terminator; with buf = NULL and nbytes = 0 the call is a size query and keeps the record,
+ * otherwise a buffer that is too small fails with HGS_ERR_ARG (record kept) and success clears the record. */
+int hgs_dispatch_read(hgs_engine* e, char* buf, size_t nbytes, size_t* needed);
+
 const char* hgs_last_error(void);
 /* library / device identification: "hgs <version> gfx950 <device name>" */
 const char* hgs_version(void);

@@ -101,6 +101,7 @@ def load():
         "hgs_profile_enable": (C.c_int, [eng, C.c_int]),
         "hgs_profile_read": (C.c_int, [eng, P(C.c_double)]),
         "hgs_iterate_timed": (C.c_int, [eng, P(hgs_step), C.c_int, P(C.c_double)]),
+        "hgs_dispatch_read": (C.c_int, [eng, C.c_char_p, C.c_size_t, P(C.c_size_t)]),
         "hgs_last_error": (C.c_char_p, []),
         "hgs_version": (C.c_char_p, []),
     }
@@ -115,7 +116,7 @@ def load():
 EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device",
            "hgs_reset_weights", "hgs_reset", "hgs_set_array_sparse", "hgs_nearfield2farfield", "hgs_farfield_constraint",
            "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_multiplane_farfield2nearfield", "hgs_set_option", "hgs_sync", "hgs_profile_enable",
-           "hgs_profile_read", "hgs_iterate_timed", "hgs_last_error", "hgs_version")
+           "hgs_profile_read", "hgs_iterate_timed", "hgs_dispatch_read", "hgs_last_error", "hgs_version")
 
 
 def check(code):

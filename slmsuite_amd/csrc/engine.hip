@@ -76,6 +76,53 @@ struct RoctxRange {
     ~RoctxRange() { if (on) g_roctx.pop(); }
 };
 
+thread_local DispatchLog* g_dispatch = nullptr;
+// one line per (kernel instance, run-time flags): "family<P0=v0,...> flag ...\tcount\n".  The argument values come from
+// __PRETTY_FUNCTION__ of dispatch_site<Fam, R, V...>: "... [Fam = hgs::KTile, R = float, V = <4096, 1, 6, false, false, 1, 0>]"
+std::string DispatchLog::text() const {
+    static const char* flag_names[] = {"list", "load_mask", "store_mask", "xmap", "batch", "stats", "nf_out"};
+    std::string out;
+    for (const Ent& e : v) {
+        std::vector<std::string> vals;
+        const std::string p = e.site->pretty;
+        size_t r0 = p.find("R = ");
+        if (r0 != std::string::npos) {
+            r0 += 4;
+            const size_t r1 = p.find_first_of(",]", r0);
+            vals.push_back(p.substr(r0, r1 - r0));
+        }
+        size_t v0 = p.find("V = <");
+        if (v0 != std::string::npos) {
+            v0 += 5;
+            const size_t v1 = p.find('>', v0);
+            std::string list = p.substr(v0, v1 - v0);
+            size_t a = 0;
+            while (a <= list.size()) {
+                size_t b = list.find(", ", a);
+                if (b == std::string::npos) b = list.size();
+                if (b > a) vals.push_back(list.substr(a, b - a));
+                a = b + 2;
+            }
+        }
+        out += e.site->family;
+        out += '<';
+        const std::string names = e.site->params;
+        size_t a = 0;
+        for (size_t i = 0; i < vals.size(); ++i) {
+            size_t b = names.find(',', a);
+            if (b == std::string::npos) b = names.size();
+            if (i) out += ',';
+            out += (a < names.size() ? names.substr(a, b - a) : std::string("?")) + "=" + vals[i];
+            a = b + 1;
+        }
+        out += '>';
+        for (unsigned bit = 0; bit < sizeof flag_names / sizeof flag_names[0]; ++bit)
+            if (e.flags & (1u << bit)) { out += ' '; out += flag_names[bit]; }
+        out += '\t' + std::to_string(e.count) + '\n';
+    }
+    return out;
+}
+
 static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -84,6 +131,7 @@ static int env_int(const char* name, int dflt) {
 
 struct EngineBase {
     int device = 0;      // HIP device ordinal of this engine; every C-ABI entry makes it current first
+    DispatchLog dispatch;    // kernel instances launched since the last hgs_dispatch_read
     virtual ~EngineBase() {}
     virtual int init(const hgs_config& c) = 0;
     virtual int set_array(int which, const void* host, size_t nbytes) = 0;
@@ -711,6 +759,7 @@ template <typename R> struct Engine : EngineBase {
         return 0;
     }
     bool use_run() const { return run_ok && opt_run; }
+    unsigned bflag() const { return B > 1 ? DF_BATCH : 0u; }
     CRunArgs run_args(const CArgs<R>& a) {
         CRunArgs ra{};
         if constexpr (sizeof(R) == 4) ra.a = a;
@@ -723,8 +772,8 @@ template <typename R> struct Engine : EngineBase {
         CRunArgs ra = run_args(a);
         a.nblocks = run_blocks;                       // what c_n2f_reduce sums over
         const dim3 grid(run_blocks, B, run_chunks);
-        if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_run<1>), grid, dim3(64), 0, stream, ra);
-        else hipLaunchKernelGGL((c_n2f_run<2>), grid, dim3(64), 0, stream, ra);
+        if (c_degree <= 1) { dispatch_note(dispatch_site<KCn2fRun, float, 1>(), bflag()); hipLaunchKernelGGL((c_n2f_run<1>), grid, dim3(64), 0, stream, ra); }
+        else { dispatch_note(dispatch_site<KCn2fRun, float, 2>(), bflag()); hipLaunchKernelGGL((c_n2f_run<2>), grid, dim3(64), 0, stream, ra); }
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -736,8 +785,8 @@ template <typename R> struct Engine : EngineBase {
         }
         CRunArgs ra = run_args(a);
         const dim3 grid(run_blocks, B, run_chunks);
-        if (c_degree <= 1) hipLaunchKernelGGL((c_f2n_run<1>), grid, dim3(64), 0, stream, ra);
-        else hipLaunchKernelGGL((c_f2n_run<2>), grid, dim3(64), 0, stream, ra);
+        if (c_degree <= 1) { dispatch_note(dispatch_site<KCf2nRun, float, 1>(), bflag()); hipLaunchKernelGGL((c_f2n_run<1>), grid, dim3(64), 0, stream, ra); }
+        else { dispatch_note(dispatch_site<KCf2nRun, float, 2>(), bflag()); hipLaunchKernelGGL((c_f2n_run<2>), grid, dim3(64), 0, stream, ra); }
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(c_f2n_run_finish, dim3((unsigned)((S + 255) / 256), B), dim3(256), 0, stream, ra.a,
                            (const Cx<float>*)run_nf, run_chunks);
@@ -839,8 +888,8 @@ template <typename R> struct Engine : EngineBase {
                      const float2* E = nullptr, int ldE = 0, float2* part = nullptr, int ldP = 0) {
         CgemmSkArgs a{A, A + planeA, Bm, Bm + planeB, C, M, N, KT, lda, ldb, tiles_m, tiles_n, planes, first_wg, strideA, strideB,
                       E, ldE, part, ldP};
-        if (E) hipLaunchKernelGGL(cgemm_streamk<1>, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL(cgemm_streamk<0>, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a);
+        if (E) { dispatch_note(dispatch_site<KCgemm, float, 1>(), bflag()); hipLaunchKernelGGL(cgemm_streamk<1>, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a); }
+        else { dispatch_note(dispatch_site<KCgemm, float, 0>(), bflag()); hipLaunchKernelGGL(cgemm_streamk<0>, dim3(G, B), dim3(256), CG_LDS_BYTES, stream, a); }
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -904,9 +953,9 @@ template <typename R> struct Engine : EngineBase {
             CArgs<R> a = cargs();
             const dim3 grid(c_nblocks, B);
             if (use_run()) { if (int e = run_n2f(a)) return e; }
-            else if (c_degree <= 1) hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a);
-            else if (c_degree == 2) hipLaunchKernelGGL((c_n2f_partial<R, 2>), grid, dim3(C_WG), 0, stream, a);
-            else hipLaunchKernelGGL((c_n2f_partial<R, 0>), grid, dim3(C_WG), 0, stream, a);
+            else if (c_degree <= 1) { dispatch_note(dispatch_site<KCn2fPix, R, 1>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a); }
+            else if (c_degree == 2) { dispatch_note(dispatch_site<KCn2fPix, R, 2>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 2>), grid, dim3(C_WG), 0, stream, a); }
+            else { dispatch_note(dispatch_site<KCn2fPix, R, 0>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 0>), grid, dim3(C_WG), 0, stream, a); }
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(c_n2f_reduce<R>, dim3(nred, B), dim3(C_RED_SPOTS * C_RED_SLICES), 0, stream, a, cnorm);
             HIPCHK(hipGetLastError());
@@ -932,9 +981,9 @@ template <typename R> struct Engine : EngineBase {
             CArgs<R> a = cargs();
             const dim3 grid(c_nblocks, B);
             if (use_run()) return run_f2n(a);
-            if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
-            else if (c_degree == 2) hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a);
-            else hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a);
+            if (c_degree <= 1) { dispatch_note(dispatch_site<KCf2nPix, R, 1>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a); }
+            else if (c_degree == 2) { dispatch_note(dispatch_site<KCf2nPix, R, 2>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a); }
+            else { dispatch_note(dispatch_site<KCf2nPix, R, 0>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a); }
             HIPCHK(hipGetLastError());
             return 0;
         });
@@ -1484,9 +1533,9 @@ template <typename R> struct Engine : EngineBase {
                 a.nf_out = nfbuf;
                 const dim3 grid(c_nblocks, B);
                 if (use_run()) return run_f2n(a);
-                if (c_degree <= 1) hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a);
-                else if (c_degree == 2) hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a);
-                else hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a);
+                if (c_degree <= 1) { dispatch_note(dispatch_site<KCf2nPix, R, 1>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a); }
+                else if (c_degree == 2) { dispatch_note(dispatch_site<KCf2nPix, R, 2>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a); }
+                else { dispatch_note(dispatch_site<KCf2nPix, R, 0>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a); }
                 HIPCHK(hipGetLastError());
                 return 0;
             });
@@ -2215,11 +2264,14 @@ template <typename R> struct Engine : EngineBase {
 struct DeviceGuard {
     int prev = -1, dev;
     bool ok = true;
-    explicit DeviceGuard(int d) : dev(d) {
+    DispatchLog* prev_log;
+    explicit DeviceGuard(int d, DispatchLog* log = nullptr) : dev(d), prev_log(g_dispatch) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        g_dispatch = log;
     }
     ~DeviceGuard() {
+        g_dispatch = prev_log;
         if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
     }
 };
@@ -2267,7 +2319,7 @@ int hgs_destroy(hgs_engine* e) {
 // keeps allocating and launching where it was
 #define ENG(e)                                                                         \
     if (!(e) || !(e)->impl) return hgs::fail(HGS_ERR_ARG, "null engine handle");       \
-    hgs::DeviceGuard guard_((e)->impl->device);                                         \
+    hgs::DeviceGuard guard_((e)->impl->device, &(e)->impl->dispatch);                   \
     if (!guard_.ok) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", (e)->impl->device);
 
 int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes) { ENG(e) return e->impl->set_array(which, host, nbytes); }
@@ -2300,12 +2352,14 @@ int hgs_multiplane_farfield2nearfield(hgs_engine* const* children, const double*
     hgs::DeviceGuard guard_(info[0].device);
     if (!guard_.ok) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", info[0].device);
     for (int k = 0; k < n; ++k) {
+        hgs::g_dispatch = &children[k]->impl->dispatch;
         if (int r = children[k]->impl->f2n_complex()) return r;
         if (int r = children[k]->impl->mp_info(&info[k])) return r;     // the nearfield buffer exists now
     }
     // every child's inverse transform must have landed before child 0's stream reads them
     for (int k = 1; k < n; ++k)
         if (hipStreamSynchronize(info[k].stream) != hipSuccess) return hgs::fail(HGS_ERR_DEVICE, "multiplane: stream sync failed");
+    hgs::g_dispatch = nullptr;
     return children[0]->impl->mp_combine(info, weights, n);
 }
 int hgs_iterate(hgs_engine* e, hgs_step* step, int n_iter, uint8_t* hist) {
@@ -2336,6 +2390,20 @@ int hgs_iterate_timed(hgs_engine* e, hgs_step* step, int n_iter, double* ms) {
     ENG(e)
     if (!step || !ms) return hgs::fail(HGS_ERR_ARG, "null argument");
     return e->impl->iterate_timed(step, n_iter, ms);
+}
+
+int hgs_dispatch_read(hgs_engine* e, char* buf, size_t nbytes, size_t* needed) {
+    if (!e || !e->impl) return hgs::fail(HGS_ERR_ARG, "null engine handle");
+    const std::string t = e->impl->dispatch.text();
+    if (needed) *needed = t.size() + 1;
+    if (!buf || nbytes < t.size() + 1) {
+        if (buf && nbytes) buf[0] = 0;
+        if (!buf && nbytes == 0 && needed) return 0;      // size query: the record is kept
+        return hgs::fail(HGS_ERR_ARG, "dispatch record needs %zu bytes", t.size() + 1);
+    }
+    std::memcpy(buf, t.c_str(), t.size() + 1);
+    e->impl->dispatch.v.clear();
+    return 0;
 }
 
 const char* hgs_last_error(void) { return hgs::g_err.c_str(); }

@@ -2,8 +2,17 @@
 // translation units (launch_row_*.hip / launch_col_*.hip) so hipcc can build them in parallel.
 #pragma once
 #include "kernels.hpp"
+#include "dispatch.hpp"
 
 namespace hgs {
+
+template <typename R> inline unsigned row_flags(dim3 grid, const RowArgs<R>& a) {
+    return (a.load_mask ? DF_LOAD_MASK : 0u) | (a.store_mask ? DF_STORE_MASK : 0u) | (grid.y > 1 ? DF_BATCH : 0u) | (a.nf_out ? DF_NF_OUT : 0u);
+}
+template <typename R> inline unsigned col_flags(dim3 grid, const ColArgs<R>& a) {
+    return (a.col_list ? DF_LIST : 0u) | ((a.col_list ? a.list_xmap : a.col_xmap) ? DF_XMAP : 0u) | (grid.y > 1 ? DF_BATCH : 0u) |
+           (a.do_stats ? DF_STATS : 0u);
+}
 
 // returns hipError_t as int
 template <typename R> int launch_row(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a);

@@ -1,5 +1,6 @@
 // Included by launch_blue_f32.hip / launch_blue_f64.hip with HGS_REAL defined.
 #include "bluestein.hpp"
+#include "dispatch.hpp"
 
 namespace hgs {
 
@@ -10,6 +11,7 @@ template <typename R, int M> static int launch_blue_one(dim3 grid, hipStream_t s
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KBlue, R, M>(), grid.y > 1 ? DF_BATCH : 0u);
     hipLaunchKernelGGL(k, grid, dim3(M / 16), lds, s, a);
     return (int)hipGetLastError();
 }

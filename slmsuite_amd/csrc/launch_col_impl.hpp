@@ -12,6 +12,7 @@ static int launch_col_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KCol, R, N, MODE>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(ColCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }

@@ -38,6 +38,7 @@ static int launch_fused_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KFused, R, N, PHASE, kStats, 0>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(ColCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }
@@ -78,6 +79,7 @@ static int launch_tile_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, in
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KTile, float, N, PHASE, 6, kStats, kExtras, 0, -1>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
     return (int)hipGetLastError();
 }

@@ -11,6 +11,7 @@ static int launch_row_pref(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
     auto k = row_kernel<R, N, 2, NS, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    dispatch_note(dispatch_site<KRow, R, N, 2, NS, true, false>(), row_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }
@@ -30,6 +31,7 @@ static int launch_row_one(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KRow, R, N, MODE, NS, false, false>(), row_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }

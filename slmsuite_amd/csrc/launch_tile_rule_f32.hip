@@ -21,6 +21,7 @@ static int launch_tile_rule_one(dim3 grid, hipStream_t s, const ColArgs<float>& 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KTile, float, N, PHASE, 6, false, false, RULE, HGS_TILE_LISTED>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
     return (int)hipGetLastError();
 }

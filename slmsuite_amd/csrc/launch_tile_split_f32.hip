@@ -19,6 +19,7 @@ static int launch_tile_split_one(dim3 grid, hipStream_t s, const ColArgs<float>&
     auto k = col_tile_kernel<float, N, PHASE, NR, HGS_SPLIT_STATS != 0, true, RULE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    dispatch_note(dispatch_site<KTile, float, N, PHASE, NR, HGS_SPLIT_STATS != 0, true, RULE, -1>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
     return (int)hipGetLastError();
 }
@@ -58,6 +59,7 @@ static int launch_row_split_one(dim3 grid, hipStream_t s, const RowArgs<float>& 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    dispatch_note(dispatch_site<KRow, float, N, MODE, NS, false, true>(), row_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }

@@ -171,6 +171,24 @@ class Engine:
         L.check(self.lib.hgs_profile_read(self._h, out))
         return {n: dict(ms=out[2 * i], launches=int(out[2 * i + 1])) for i, n in enumerate(L.K_NAMES)}
 
+    def dispatch_read(self):
+        """
+        hgs_dispatch_read: the kernel instances launched since the previous call, as a list of
+        ``{"kernel": family, "args": {template parameter: value}, "flags": set, "count": launches, "name": text}``.
+        """
+        need = C.c_size_t(0)
+        L.check(self.lib.hgs_dispatch_read(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(1, need.value))
+        L.check(self.lib.hgs_dispatch_read(self._h, buf, len(buf), None))
+        out = []
+        for line in buf.value.decode().splitlines():
+            name, count = line.rsplit("\t", 1)
+            head, _, flags = name.partition("> ")
+            family, _, arglist = head.rstrip(">").partition("<")
+            args = dict(kv.split("=", 1) for kv in arglist.split(",") if kv)
+            out.append({"kernel": family, "args": args, "flags": set(flags.split()), "count": int(count), "name": name})
+        return out
+
     def version(self):
         return self.lib.hgs_version().decode()
 

@@ -57,3 +57,43 @@ def report(name, **values):
             f.write(json.dumps({"case": name, **{k: float(v) for k, v in values.items()}}) + "\n")
     except OSError:
         pass
+
+
+# ---- dispatch record (hgs_dispatch_read): which kernel instance a policy actually reached ---------------------------------
+class Dispatch:
+    """
+    The launches of one engine since the previous read.  ``count(family, flags=..., without=..., **args)`` sums the
+    launches of the instances of ``family`` whose template arguments equal ``args`` (compared as text: N=4096,
+    RULE=1, PREF="true") and whose run-time flags include ``flags`` and none of ``without``.
+    """
+
+    def __init__(self, records):
+        self.records = records
+
+    def count(self, family, flags=(), without=(), **args):
+        n = 0
+        for r in self.records:
+            if r["kernel"] != family:
+                continue
+            if any(r["args"].get(k) != _targ(v) for k, v in args.items()):
+                continue
+            if not set(flags) <= r["flags"] or (set(without) & r["flags"]):
+                continue
+            n += r["count"]
+        return n
+
+    def families(self):
+        return {r["kernel"] for r in self.records}
+
+    def __repr__(self):
+        return "\n".join(f"{r['name']} x{r['count']}" for r in self.records) or "(no launches recorded)"
+
+
+def _targ(v):
+    return {True: "true", False: "false"}.get(v, str(v)) if isinstance(v, bool) else str(v)
+
+
+def dispatch_of(h):
+    """Dispatch record of a hologram's (or batch's, or bare) engine; reading clears it."""
+    e = getattr(h, "_engine", None) or getattr(h, "engine", None) or h
+    return Dispatch(e.dispatch_read())

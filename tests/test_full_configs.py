@@ -8,7 +8,7 @@ checked against float64 direct summation on a sample of spots / pixels).
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_l2, phase_rel_l2, report
+from conftest import dispatch_of, load_golden, rel_l2, phase_rel_l2, report
 from oracle import hgs_oracle as orc
 from slmsuite_amd import _lib as L
 from slmsuite_amd import synth
@@ -20,6 +20,32 @@ pytestmark = pytest.mark.gpu
 
 SHAPE, SLM = (4096, 4096), (1152, 1920)
 PATHS = {"default": {}, "dense": {L.OPT_SPARSE_COLUMNS: 0}, "dense-per-column": {L.OPT_SPARSE_COLUMNS: 0, L.OPT_TILE_KERNEL: 0}}
+
+
+def assert_cfg2_column_path(h, path, update=True):
+    """
+    The three policies of PATHS must reach three different kernels -- they agree to the last bit on the cfg 2 grid, so the
+    numbers alone would not notice a dispatcher that routed one policy to another's kernel.
+      default           col_fused_kernel over the active-column list (rule compiled in), masked row kernel
+      dense             col_tile_kernel, dense schedule compiled in (LISTED = 0), prefetching shifted row kernel
+      dense-per-column  col_fused_kernel, every column, no list
+    """
+    d = dispatch_of(h)
+    rule = 1 if update else 2
+    if path == "default":
+        assert d.count("col_fused_kernel", flags=["list"], N=4096, RULE=rule) > 0, d
+        assert d.count("col_tile_kernel") == 0 and d.count("col_fused_kernel", without=["list"]) == 0, d
+        assert d.count("row_kernel", flags=["load_mask", "store_mask"], MODE=2) > 0 or d.count("row_kernel", MODE=2) == 0, d
+        assert d.count("row_kernel", PREF=True) == 0, d
+    elif path == "dense":
+        assert d.count("col_tile_kernel", without=["list"], R="float", N=4096, NR=6, RULE=rule, LISTED=0, STATS=False, EXTRAS=False) > 0, d
+        assert d.count("col_fused_kernel") == 0 and d.count("col_tile_kernel", flags=["list"]) == 0, d
+        n2 = d.count("row_kernel", MODE=2)
+        assert n2 == 0 or d.count("row_kernel", MODE=2, NS=8, PREF=True, SPLIT=False, without=["load_mask", "store_mask"]) == n2, d
+    else:
+        assert d.count("col_fused_kernel", without=["list"], N=4096, RULE=rule) > 0, d
+        assert d.count("col_tile_kernel") == 0 and d.count("col_fused_kernel", flags=["list"]) == 0, d
+    return d
 
 
 def cfg2_hologram(seed, path, phase=None):
@@ -40,6 +66,8 @@ def test_cfg2_leonardo_every_column_path_matches_reference(path):
     meta, gold = load_golden("cfg2_summary")
     h = cfg2_hologram(2, path)
     h.optimize("WGS-Leonardo", maxiter=50, verbose=False)
+    d = assert_cfg2_column_path(h, path)
+    assert d.count("col_fused_kernel" if path != "dense" else "col_tile_kernel", RULE=1) == 49, d     # body 0 has no update
     ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
     amp_ff = h.amp_ff
     errs = dict(spot_amp=rel_l2(amp_ff[ky, kx], gold["spot_ampff"]),
@@ -94,7 +122,9 @@ def test_cfg2_single_bodies_at_full_size_match_reference(path):
         h.phase = gold[f"phase_{k}"].copy()
         h.weights = w
         h.iter = k
+        dispatch_of(h)                                      # (forget the stepwise launches of (a))
         h.optimize("WGS-Leonardo", maxiter=1, verbose=False)
+        assert_cfg2_column_path(h, path)
         ep = phase_rel_l2(h.phase[::3, ::3], gold[f"next_phase_{k}_sub"])
         ew = rel_l2(h.weights[ky, kx], gold[f"next_weights_{k}_spots"])
         report(f"cfg2 teacher-forced body {k} at 4096^2 [{path}]", spot_amp=ea, amp_sub=es, phase=ep, weights=ew)
@@ -107,6 +137,10 @@ def test_cfg2_kim_every_column_path_matches_reference(path):
     meta, gold = load_golden("cfg2kim_summary")
     h = cfg2_hologram(9, path)
     h.optimize("WGS-Kim", maxiter=30, verbose=False)
+    d = assert_cfg2_column_path(h, path)
+    fam = "col_tile_kernel" if path == "dense" else "col_fused_kernel"
+    # PHASE: 1 = the phase is stored (every free body of WGS-Kim with an update), 2 = the stored phase is used (fixed)
+    assert d.count(fam, PHASE=1) > 0 and d.count(fam, PHASE=2) > 0, d
     assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
     ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
     errs = dict(spot_amp=rel_l2(h.amp_ff[ky, kx], gold["spot_ampff"]),
@@ -227,6 +261,13 @@ def test_cfg4_full_size_against_direct_summation(D, sep):
                                engine_options={L.OPT_SEPARABLE: sep})
     h.reset_phase(synth.seed_phase(4, SLM))
     h.optimize("WGS-Kim", maxiter=12 if sep else 11, verbose=False)       # phase fixes at iteration 10
+    d = dispatch_of(h)
+    if sep:        # both transforms as complex GEMMs on the matrix cores (EPI 1: n2f with the y contraction in the epilogue)
+        assert d.count("cgemm_streamk", EPI=1) == 12 and d.count("cgemm_streamk", EPI=0) == 12, d
+        assert d.families() == {"cgemm_streamk"}, d
+    else:          # direct kernels: runs of 16 pixels by recurrence (degree 1: tilts; 2: with focus)
+        assert d.count("c_n2f_run", DEG=D - 1) == 11 and d.count("c_f2n_run", DEG=D - 1) == 11, d
+        assert d.families() == {"c_n2f_run", "c_f2n_run"}, d
     assert h.flags["fixed_phase"] and h.stats["flags"]["fixed_phase"][:10] == [False] * 10
     e = h._get_engine()
     S = SLM[0] * SLM[1]

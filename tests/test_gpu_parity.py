@@ -14,7 +14,7 @@ Tolerances (fp32 unless noted), all stated as relative L2 norms:
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, rel_l2, phase_rel_l2, report
+from conftest import dispatch_of, golden_names, load_golden, rel_l2, phase_rel_l2, report
 from golden_cases import hologram_inputs, spot_external_amp
 from oracle import hgs_oracle as orc
 from slmsuite_amd import _lib as L
@@ -624,7 +624,18 @@ def test_sparse_column_path_matches_dense_path(method, kw):
         h = SpotHologram(shape, xy, basis="knm", spot_amp=amp, slm_shape=slm, phase=synth.seed_phase(79, slm),
                          engine_options={L.OPT_SPARSE_COLUMNS: int(sparse)})
         h.optimize(method, maxiter=7, verbose=False, stat_groups=["computational"], **kw)
+        d = dispatch_of(h)
+        if sparse:        # per-column kernel over the list, statistics accumulated in the pass
+            assert d.count("col_fused_kernel", flags=["list", "stats"], STATS=True) == 7 and d.count("col_tile_kernel") == 0, d
+        else:             # dense tile-resident kernel, statistics unit
+            assert d.count("col_tile_kernel", flags=["stats"], without=["list"], STATS=True) == 7 and d.count("col_fused_kernel") == 0, d
         h.optimize(method, maxiter=2, verbose=False, **kw)          # state persists; plain fused call
+        d = dispatch_of(h)
+        rule = 2 if method == "GS" else 1
+        if sparse:
+            assert d.count("col_fused_kernel", flags=["list"], STATS=False, RULE=rule) == 2, d
+        else:
+            assert d.count("col_tile_kernel", without=["list"], STATS=False, RULE=rule, LISTED=0) == 2, d
         return h
 
     a, b = run(True), run(False)

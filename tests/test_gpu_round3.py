@@ -13,7 +13,7 @@ Tolerances are relative L2 norms (phase: distance of unit phasors), fp32.
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, rel_l2, phase_rel_l2, report
+from conftest import dispatch_of, golden_names, load_golden, rel_l2, phase_rel_l2, report
 from golden_cases import hologram_inputs, spot_null_ctor
 from slmsuite_amd import _lib as L
 from slmsuite_amd import synth
@@ -273,6 +273,14 @@ def test_prefetching_row_kernel_is_bit_identical(slm_shape, monkeypatch):
         h = SpotHologram(shape, host.spot_knm_rounded.astype(float), basis="knm", slm_shape=slm_shape,
                          phase=synth.seed_phase(31, slm_shape), dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: 0})
         h.optimize("WGS-Leonardo", maxiter=5, verbose=False)
+        d = dispatch_of(h)
+        shifted = (2048 + slm_shape[1] // 2 - 1) // 256 - (2048 - slm_shape[1] // 2) // 256 + 1 <= 8
+        ns = 8 if shifted else 16
+        if pref == "1":        # the four launches between bodies walk rows with the next one prefetched; first and last do not
+            assert d.count("row_kernel", MODE=2, NS=ns, PREF=True) == 4 and d.count("row_kernel", MODE=2, PREF=False) == 0, d
+        else:
+            assert d.count("row_kernel", MODE=2, NS=ns, PREF=False) == 4 and d.count("row_kernel", PREF=True) == 0, d
+        assert d.count("row_kernel", MODE=0, NS=ns) == 1 and d.count("row_kernel", MODE=1, NS=ns) == 1, d
         out[pref] = (h.phase.copy(), h.weights[host.spot_knm_rounded[1], host.spot_knm_rounded[0]].copy())
         h._release_engine()
     np.testing.assert_array_equal(out["1"][0], out["0"][0])
@@ -316,6 +324,21 @@ def test_single_pass_mraf_matches_the_two_pass_form(n, slm, method, extra, monke
         monkeypatch.setenv("HGS_MRAF_SPLIT", split)
         h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: 0})
         h.optimize(method, maxiter=2, verbose=False, mraf_factor=0.5, **extra)
+        d = dispatch_of(h)
+        Tc = n // 16
+        nr_slots = ((n - slm[0]) // 2 + slm[0] - 1) // Tc - ((n - slm[0]) // 2) // Tc + 1
+        nr = 4 if nr_slots <= 4 else 6
+        # body 0 has no weight update (one plain MRAF pass); body 1 updates: ONE pass of RULE 3 + a SPLIT row launch, or
+        # two passes of the generic kernel (forward + rule, then forward + rebuild + inverse) + a plain row launch
+        nog = 1 if method == "WGS-Nogrette" else 0          # its forward-only pass that sums feedback / target
+        if split == "1":
+            assert d.count("col_tile_kernel", N=n, NR=nr, EXTRAS=True, RULE=3) == 1, d
+            assert d.count("row_kernel", N=n, SPLIT=True) == 1, d
+            assert d.count("col_tile_kernel", EXTRAS=True, RULE=0) == 1 + nog, d
+        else:
+            assert d.count("col_tile_kernel", RULE=3) + d.count("col_tile_kernel", RULE=4) == 0 and d.count("row_kernel", SPLIT=True) == 0, d
+            assert d.count("col_tile_kernel", N=n, NR=6, EXTRAS=True, RULE=0) == 3 + nog, d
+        assert d.count("col_fused_kernel") == 0, d
         first = (h.phase.copy(), np.array(h.weights, copy=True))
         h.optimize(method, maxiter=1, verbose=False, mraf_factor=0.5, **extra)
         out[split] = first + (h.phase.copy(),)
@@ -358,6 +381,15 @@ def test_single_pass_mraf_with_in_pass_statistics(sparse, monkeypatch):
         monkeypatch.setenv("HGS_MRAF_SPLIT", split)
         h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
         h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5, stat_groups=["computational"])
+        d = dispatch_of(h)
+        lst = ["list"] if sparse else []
+        nolst = [] if sparse else ["list"]
+        if split == "1":       # the statistics unit has the generic split form (RULE 3) only
+            assert d.count("col_tile_kernel", flags=lst + ["stats"], without=nolst, STATS=True, EXTRAS=True, RULE=3) == 2, d
+            assert d.count("row_kernel", SPLIT=True) == 2, d
+        else:
+            assert d.count("col_tile_kernel", RULE=3) == 0 and d.count("row_kernel", SPLIT=True) == 0, d
+            assert d.count("col_tile_kernel", flags=lst + ["stats"], without=nolst, STATS=True, EXTRAS=True, RULE=0) == 3, d
         st = h.stats["stats"]["computational"]
         out[split] = (h.phase.copy(), {k: np.array(v, dtype=float) for k, v in st.items()})
         h._release_engine()
@@ -403,6 +435,22 @@ def test_tile_rounded_column_list_equals_the_dense_launch(n, slm, method, kw, mo
         monkeypatch.setenv("HGS_TILE_LIST", env)
         h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options=opts)
         h.optimize(method, maxiter=2, verbose=False, **kw)
+        d = dispatch_of(h)
+        if name == "list":       # the tile-resident kernels walk the rounded list; the row kernel moves only its columns
+            assert d.count("col_tile_kernel", flags=["list"], N=n) >= 2 and d.count("col_tile_kernel", without=["list"]) == 0, d
+            assert d.count("col_fused_kernel") == 0, d
+            if "mraf_factor" not in kw:     # plain passes: the rule-specialised kernels compiled for a list
+                assert d.count("col_tile_kernel", LISTED=1) == 2, d
+            elif method != "GS":            # single-pass MRAF over a list: the rule-specialised split form
+                assert d.count("col_tile_kernel", flags=["list"], RULE=4) == 1 and d.count("row_kernel", SPLIT=True, flags=["load_mask"]) == 1, d
+            assert d.count("row_kernel", MODE=2, flags=["load_mask", "store_mask"]) == 1, d
+        elif name == "dense":
+            assert d.count("col_tile_kernel", without=["list"], N=n) >= 2 and d.count("col_tile_kernel", flags=["list"]) == 0, d
+            assert d.count("col_fused_kernel") == 0 and d.count("row_kernel", flags=["load_mask"]) == 0, d
+            if "mraf_factor" not in kw:
+                assert d.count("col_tile_kernel", LISTED=0) == 2, d
+        else:
+            assert d.count("col_fused_kernel", flags=["list"], N=n) >= 2 and d.count("col_tile_kernel") == 0, d
         two = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
         h.optimize(method, maxiter=1, verbose=False, **kw)
         out[name] = two + (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
