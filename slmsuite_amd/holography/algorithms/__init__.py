@@ -9,6 +9,7 @@ weight update, inverse FFT, phase extraction, statistics reductions -- runs on t
 keeps the host-side bookkeeping (flag parsing, WGS-Kim history, stats lists).  There is no CPU
 fallback: without the built library or a gfx950 device ``optimize()`` raises.
 """
+import time
 import warnings
 
 import numpy as np
@@ -57,6 +58,14 @@ def _norm(matrix):
     return np.sqrt(np.nansum(np.square(matrix)))
 
 
+def _history_put(seq, start, values, fill=np.nan):
+    """``seq[start:start + len(values)] = values``, growing ``seq`` with ``fill`` as far as needed (at least to ``start``)."""
+    missing = start + len(values) - len(seq)
+    if missing > 0:
+        seq.extend([fill] * missing)
+    seq[start:start + len(values)] = values
+
+
 class Hologram:
     """
     Phase-retrieval hologram on a padded DFT grid (reference: ``Hologram``, _hologram.py:26-2011).
@@ -69,61 +78,45 @@ class Hologram:
     # ---- construction (_hologram.py:196-439) -------------------------------------------------------
     def __init__(self, target, amp=None, phase=None, slm_shape=None, dtype=np.float32,
                  propagation_kernel=None, **kwargs):
-        amp_shape = (np.nan, np.nan) if amp is None else np.shape(amp)
-        phase_shape = (np.nan, np.nan) if phase is None else np.shape(phase)
-        if slm_shape is None:
-            slm_shape = (np.nan, np.nan)
-        else:
-            if hasattr(slm_shape, "slm") and hasattr(slm_shape.slm, "shape"):      # FourierSLM
-                if amp is None:
-                    amp = slm_shape.slm._get_source_amplitude()
-                    amp_shape = np.shape(amp)
-                slm_shape = slm_shape.slm.shape
-            elif hasattr(slm_shape, "_get_source_amplitude"):                        # SLM
-                if amp is None:
-                    amp = slm_shape._get_source_amplitude()
-                    amp_shape = np.shape(amp)
-                slm_shape = slm_shape.shape
-            if len(slm_shape) != 2:
-                slm_shape = (np.nan, np.nan)
-
-        stack = np.vstack((amp_shape, phase_shape, slm_shape)).astype(float)
-        if np.all(np.isnan(stack)):
-            self.slm_shape = None
-        else:
-            self.slm_shape = tuple(int(x) for x in np.rint(np.nanmean(stack, axis=0)))
-            for shp, what in ((amp_shape, "amplitude (via `amp` or SLM)"),
-                              (phase_shape, "initial phase (`phase`)"),
-                              (slm_shape, "SLM (via `target` or `slm_shape`)")):
-                if not np.isnan(shp[0]) and tuple(int(s) for s in shp) != self.slm_shape:
+        # SLM geometry: whatever states it -- an SLM / FourierSLM object (which may also supply the source amplitude),
+        # an explicit pair, the amplitude array, the initial phase -- must agree
+        device = getattr(slm_shape, "slm", slm_shape)
+        if hasattr(device, "_get_source_amplitude") and hasattr(device, "shape"):
+            amp = device._get_source_amplitude() if amp is None else amp
+            slm_shape = device.shape
+        stated = (("amplitude (via `amp` or SLM)", None if amp is None else np.shape(amp)),
+                  ("initial phase (`phase`)", None if phase is None else np.shape(phase)),
+                  ("SLM (via `target` or `slm_shape`)", slm_shape))
+        stated = [(what, tuple(int(v) for v in shp)) for what, shp in stated if shp is not None and len(shp) == 2]
+        self.slm_shape = None
+        if stated:
+            self.slm_shape = tuple(int(v) for v in np.rint(np.mean([shp for _, shp in stated], axis=0)))
+            for what, shp in stated:
+                if shp != self.slm_shape:
                     raise ValueError(f"The shape of the {what} is not equal to the other provided SLM shapes")
 
-        if target is None:
+        # computational shape: the target image's, a bare (h, w) pair, or -- target=None -- the SLM's own
+        own_shape = target is not None
+        if not own_shape:
             if self.slm_shape is None:
                 raise ValueError("SLM shape must be provided through cameraslm=")
-            self.shape = self.slm_shape
-            target = []
+            self.shape, target = self.slm_shape, []
+        elif np.ndim(target) == 1 and len(target) == 2:
+            self.shape, target = (int(target[0]), int(target[1])), None
+        elif np.ndim(target) == 2:
+            self.shape = tuple(int(v) for v in np.shape(target))
         else:
-            if len(target) == 2 and np.ndim(target) == 1:
-                self.shape = (int(target[0]), int(target[1]))
-                target = None
-            elif np.ndim(target) == 2:
-                self.shape = tuple(int(s) for s in np.shape(target))
-            else:
-                raise ValueError(f"Unexpected target {target}.")
-            if any(np.log2(self.shape) != np.round(np.log2(self.shape))):
-                warnings.warn(
-                    f"Hologram target shape {self.shape} is not a power of 2; consider using "
-                    ".get_padded_shape() to pad to powers of 2 and speed up FFT computation.")
-        if self.slm_shape is None:
-            self.slm_shape = self.shape
+            raise ValueError(f"Unexpected target {target}.")
+        if own_shape and any(v & (v - 1) for v in self.shape):
+            warnings.warn(
+                f"Hologram target shape {self.shape} is not a power of 2; consider using "
+                ".get_padded_shape() to pad to powers of 2 and speed up FFT computation.")
+        self.slm_shape = self.slm_shape or self.shape
 
-        if np.dtype(dtype).itemsize == 4:
-            self.dtype, self.dtype_complex = np.float32, np.complex64
-        elif np.dtype(dtype).itemsize == 8:
-            self.dtype, self.dtype_complex = np.float64, np.complex128
-        else:
-            raise ValueError(f"Data type {dtype} not supported.")
+        try:
+            self.dtype, self.dtype_complex = {4: (np.float32, np.complex64), 8: (np.float64, np.complex128)}[np.dtype(dtype).itemsize]
+        except KeyError:
+            raise ValueError(f"Data type {dtype} not supported.") from None
 
         self._engine = None
         self._host = {}        # name -> host copy
@@ -135,24 +128,24 @@ class Hologram:
         # engine policy applied whenever this hologram creates an engine: {L.OPT_*: value} (hgs_set_option)
         self.engine_options = dict(kwargs.pop("engine_options", {}) or {})
 
-        if amp is None:
-            self.amp = 1 / np.sqrt(np.prod(self.slm_shape))              # scalar (:401-402)
-        else:
+        # source amplitude, unit L2 norm: an array, or the scalar of a uniform beam (:401-405)
+        if amp is not None:
             self.amp = np.array(amp, dtype=self.dtype)
-            self.amp *= 1 / _norm(self.amp)                                # (:404-405)
-
-        if propagation_kernel is None:
-            self.propagation_kernel = None
-        elif isinstance(propagation_kernel, toolbox.REAL_TYPES):
-            raise ValueError("propagation_kernel must be an array of slm_shape (scalars are rejected)")
+            self.amp *= 1 / _norm(self.amp)
         else:
+            self.amp = 1 / np.sqrt(np.prod(self.slm_shape))
+
+        self.propagation_kernel = None
+        if isinstance(propagation_kernel, toolbox.REAL_TYPES):
+            raise ValueError("propagation_kernel must be an array of slm_shape (scalars are rejected)")
+        if propagation_kernel is not None:
             self.propagation_kernel = np.array(propagation_kernel, dtype=self.dtype)
             if self.propagation_kernel.shape != self.slm_shape:
                 raise ValueError("Expected the propagation kernel to be the same shape as the SLM.")
 
         self.flags = kwargs
-        self._set_target(target, reset_weights=False)
         self._host["phase"] = None
+        self._set_target(target, reset_weights=False)
         self.reset_phase(phase)
         self.reset(reset_phase=False, reset_flags=False)
 
@@ -472,101 +465,68 @@ class Hologram:
                 stats["computational"].update(self._raw_stats(self.amp_ff, self.target))
 
     def _update_stats_dictionary(self, stats):
-        it = self.iter
-        M = len(self.stats["method"])
-        if it + 1 - M > 0:
-            self.stats["method"].extend(["" for _ in range(it + 1 - M)])
-            M = it + 1
-        self.stats["method"][it] = self.flags["method"]
-        for flag in set(self.flags.keys()).union(set(self.stats["flags"].keys())):
-            if flag not in self.stats["flags"]:
-                self.stats["flags"][flag] = [np.nan for _ in range(M)]
-            else:
-                diff = it + 1 - len(self.stats["flags"][flag])
-                if diff > 0:
-                    self.stats["flags"][flag].extend([np.nan for _ in range(diff)])
-            if flag in self.flags:
-                self.stats["flags"][flag][it] = self.flags[flag]
-        grouplist = set(stats.keys()).union(set(self.stats["stats"].keys()))
-        if len(grouplist) > 0:
-            statlists = [set(stats[group].keys()) for group in stats.keys()]
-            if len(self.stats["stats"].keys()) > 0:
-                key = next(iter(self.stats["stats"]))
-                statlists.append(set(self.stats["stats"][key].keys()))
-            statlist = set.union(*statlists)
-            for group in grouplist:
-                if group not in self.stats["stats"]:
-                    self.stats["stats"][group] = {}
-                for stat in statlist:
-                    if stat not in self.stats["stats"][group]:
-                        self.stats["stats"][group][stat] = [np.nan for _ in range(M)]
-                    else:
-                        diff = it + 1 - len(self.stats["stats"][group][stat])
-                        if diff > 0:
-                            self.stats["stats"][group][stat].extend([np.nan for _ in range(diff)])
-                    if group in stats.keys() and stat in stats[group].keys():
-                        self.stats["stats"][group][stat][it] = stats[group][stat]
+        """
+        History bookkeeping of one iteration (``_stats.py:118-223``): the method, every flag and every statistic of
+        ``stats`` (``{group: {name: value}}``) land in slot ``self.iter`` of their lists.  One iteration is a range of
+        length one of :meth:`_update_stats_batch`, which holds the rules (list creation, NaN padding, the reference's
+        choice of statistic names).
+        """
+        self._update_stats_batch(1, [self.flags.get("fixed_phase")], [stats], list(stats))
         if self.flags.get("raw_stats", False):
-            if "raw_farfield" not in self.stats:
-                self.stats["raw_farfield"] = []
-            diff = it + 1 - len(self.stats["raw_farfield"])
-            if diff > 0:
-                self.stats["raw_farfield"].extend([np.nan for _ in range(diff)])
-            self.stats["raw_farfield"][it] = np.array(self.farfield, copy=True)
+            frames = self.stats.setdefault("raw_farfield", [])
+            _history_put(frames, self.iter, [np.array(self.farfield, copy=True)])
 
     def _update_stats_batch(self, n, fixed_hist, per_iter, groups):
         """
-        What ``n`` consecutive calls of :meth:`_update_stats_dictionary` leave behind after a device-resident loop of ``n``
-        iterations starting at ``self.iter`` -- the flags are constant over such a loop except ``fixed_phase``
-        (``fixed_hist[k]``), the statistics of iteration k are ``per_iter[k][group]`` -- written range by range instead
-        of entry by entry (twenty iterations of the reference's bookkeeping cost as much as their kernels on a small grid).
+        The history after ``n`` iterations starting at ``self.iter``, written range by range (twenty iterations of
+        per-entry bookkeeping cost as much as their kernels on a small grid).  Over such a range the flags are constant
+        except ``fixed_phase`` (``fixed_hist[k]``); the statistics of iteration k are ``per_iter[k][group]`` for the
+        ``groups`` computed (``per_iter`` None: none).  Rules, as the reference's per-iteration writer leaves them:
+
+        * ``stats["method"]`` grows with "" up to the range, every other list with NaN;
+        * a list that does not exist yet is created as long as the method list (so it also covers a history that is
+          longer than ``self.iter + n``, e.g. after ``iter`` was lowered by hand); an existing one only grows;
+        * flags that were recorded once but are no longer in ``self.flags`` keep their list in step (NaN);
+        * every group holds the same statistic names: those computed now plus those of the FIRST group already in
+          the history (quirk of ``_stats.py:168-178``).
         """
-        it0 = self.iter
-        nan = np.nan
+        first = self.iter
+        book = self.stats
+        _history_put(book["method"], first, [self.flags["method"]] * n, fill="")
+        depth = len(book["method"])
 
-        def assign(lst, values):
-            if len(lst) < it0:
-                lst.extend([nan] * (it0 - len(lst)))
-            k = min(len(lst) - it0, len(values))
-            if k > 0:
-                lst[it0:it0 + k] = values[:k]
-            lst.extend(values[k:])
+        def column(table, key):
+            col = table.get(key)
+            if col is None:
+                col = table[key] = [np.nan] * depth
+            return col
 
-        def pad(lst):
-            if len(lst) < it0 + n:
-                lst.extend([nan] * (it0 + n - len(lst)))
-
-        method = self.stats["method"]
-        if len(method) < it0:
-            method.extend([""] * (it0 - len(method)))
-        assign(method, [self.flags["method"]] * n)
-        sflags = self.stats["flags"]
-        for flag in set(self.flags.keys()).union(sflags.keys()):
-            if flag not in sflags:
-                # (created by the first of the n calls with the length of the method list at that moment)
-                sflags[flag] = [nan] * max(it0, len(method) - n)
-            if flag in self.flags:
-                assign(sflags[flag], list(fixed_hist[:n]) if flag == "fixed_phase" else [self.flags[flag]] * n)
+        for name in set(self.flags) | set(book["flags"]):
+            col = column(book["flags"], name)
+            if name not in self.flags:
+                _history_put(col, first + n, [])
+            elif name == "fixed_phase":
+                _history_put(col, first, list(fixed_hist[:n]))
             else:
-                pad(sflags[flag])
-        sstats = self.stats["stats"]
-        new_groups = list(groups) if per_iter is not None else []
-        grouplist = set(new_groups).union(sstats.keys())
-        if len(grouplist) > 0:
-            statlists = [set(per_iter[0][g].keys()) for g in new_groups]
-            if len(sstats) > 0:
-                statlists.append(set(sstats[next(iter(sstats))].keys()))
-            statlist = set.union(*statlists)
-            for group in grouplist:
-                if group not in sstats:
-                    sstats[group] = {}
-                for stat in statlist:
-                    if stat not in sstats[group]:
-                        sstats[group][stat] = [nan] * max(it0, len(method) - n)
-                    if group in new_groups and stat in per_iter[0][group]:
-                        assign(sstats[group][stat], [per_iter[k][group][stat] for k in range(n)])
-                    else:
-                        pad(sstats[group][stat])
+                _history_put(col, first, [self.flags[name]] * n)
+
+        fresh = list(groups) if per_iter is not None else []
+        tables = book["stats"]
+        if not fresh and not tables:
+            return
+        names = set()
+        for g in fresh:
+            names |= set(per_iter[0][g])
+        if tables:
+            names |= set(next(iter(tables.values())))
+        for g in list(tables) + [g for g in fresh if g not in tables]:
+            table = tables.setdefault(g, {})
+            for name in names:
+                col = column(table, name)
+                if g in fresh and name in per_iter[0][g]:
+                    _history_put(col, first, [per_iter[k][g][name] for k in range(n)])
+                else:
+                    _history_put(col, first + n, [])
 
     def _update_stats(self, stat_groups=[]):
         stats = {}
@@ -590,27 +550,34 @@ class Hologram:
             raise ValueError(f"Unsupported optimization method '{method}'")
 
     def _update_flags(self, method, verbose, feedback, stat_groups, **kwargs):
-        methods = list(ALGORITHM_DEFAULTS.keys())
-        if method not in methods:
-            raise ValueError("Unrecognized method '{}'.\nValid methods include {}".format(method, methods))
-        self.flags["method"] = method
-        for flag, value in ALGORITHM_DEFAULTS[method].items():
-            if flag not in self.flags:
-                self.flags[flag] = value
-        if "fixed_phase" not in self.flags:
-            self.flags["fixed_phase"] = False
-        for flag in kwargs:
-            self.flags[flag] = kwargs[flag]
-        for group in stat_groups:
-            if group not in FEEDBACK_OPTIONS:
-                raise ValueError("Statistics group '{}' not recognized as a feedback option.\n"
-                                 "Valid options: {}".format(group, FEEDBACK_OPTIONS))
-        self.flags["stat_groups"] = stat_groups
-        if feedback is not None:
-            if feedback not in FEEDBACK_OPTIONS:
-                raise ValueError("Feedback '{}' not recognized as a feedback option.\n"
-                                 "Valid options: {}".format(feedback, FEEDBACK_OPTIONS))
-            self.flags["feedback"] = feedback
+        """
+        ``self.flags`` for this call (``_hologram.py:1370-1424``).  Precedence, weakest first: the method's defaults
+        (only where the hologram has no value yet -- flags persist between calls), ``fixed_phase = False`` likewise, the
+        caller's keyword flags, then ``stat_groups`` and ``feedback``, each checked against FEEDBACK_OPTIONS right
+        before it is stored (so a rejected name leaves the earlier updates in place, as in the reference).
+        """
+        defaults = ALGORITHM_DEFAULTS.get(method)
+        if defaults is None:
+            raise ValueError("Unrecognized method '{}'.\nValid methods include {}".format(method, list(ALGORITHM_DEFAULTS)))
+        fl = self.flags
+        fl["method"] = method
+        for name, value in {**defaults, "fixed_phase": False}.items():
+            fl.setdefault(name, value)
+        fl.update(kwargs)
+        checked = (("stat_groups", "Statistics group", stat_groups, stat_groups),
+                   ("feedback", "Feedback", feedback, () if feedback is None else (feedback,)))
+        for key, what, value, names in checked:
+            for name in names:
+                if name not in FEEDBACK_OPTIONS:
+                    raise ValueError("{} '{}' not recognized as a feedback option.\nValid options: {}".format(
+                        what, name, FEEDBACK_OPTIONS))
+            if value is not None:
+                fl[key] = value
+        if verbose > 1:          # (:1411-1424) the flags this method reads, before the progress bar starts
+            import pprint
+            print(f"Optimizing with '{method}' using the following method-specific flags:")
+            pprint.pprint({name: fl[name] for name in fl if name in defaults})
+            print("", end="", flush=True)
 
     # ---- the loop (_hologram.py:1427-1493) ------------------------------------------------------------------------
     def _false_run(self, skip_last=False):
@@ -697,6 +664,9 @@ class Hologram:
         fl = self.flags
         return not (callback is not None or fl.get("raw_stats", False) or self._efficiency_group() == -1)
 
+    _BAR_FIRST_CHUNK = 8        # iterations of the first engine call under a progress bar
+    _BAR_PERIOD = 0.1           # seconds of device work per later call (a bar refreshes at 10 Hz)
+
     def optimize_gs(self, iterations, callback):
         if self._populate_pending:
             # Nobody looked at the results of the previous call.  Its trailing transform matters to this loop only
@@ -714,12 +684,16 @@ class Hologram:
             # device-resident loop: flags history (and statistics) are replayed on the host afterwards
             bar = iterations if (tqdm is not None and not isinstance(iterations, range)) else None
             done = 0
-            chunk = n_total if bar is None else max(1, n_total // 20)
             groups, width, xy = self._device_stat_groups() if len(self.flags["stat_groups"]) > 0 else ([], 1, None)
             eg = self._efficiency_group()
+            # Without a progress bar the loop is ONE engine call.  With one, the calls are sized by time, not by count: each
+            # ends in a stream sync (a bar that runs ahead of the device is no bar), so a call must be long enough for the
+            # sync not to matter -- start with a few iterations, then aim at _BAR_PERIOD seconds per call
+            chunk = n_total if bar is None else min(n_total, self._BAR_FIRST_CHUNK)
             while done < n_total:
                 n = min(chunk, n_total - done)
                 st = self._make_step(efficiency_group=eg)
+                t0 = time.perf_counter()
                 if groups:
                     hist, per_iter = e.iterate_stats(st, n, groups, width, xy)
                 else:
@@ -730,6 +704,9 @@ class Hologram:
                 self.flags["fixed_phase"] = bool(st.fixed_phase)
                 done += n
                 if bar is not None:
+                    e.sync()
+                    per_iteration = max((time.perf_counter() - t0) / n, 1e-7)
+                    chunk = max(n, int(self._BAR_PERIOD / per_iteration))
                     bar.update(n)
             if bar is not None:
                 bar.close()
@@ -855,111 +832,123 @@ class SpotHologram(FeedbackHologram):
     def __init__(self, shape, spot_vectors, basis="kxy", spot_amp=None, cameraslm=None,
                  null_vectors=None, null_radius=None, null_region=None,
                  null_region_radius_frac=None, **kwargs):
+        """
+        Constructor of the reference (_spots.py:1160-1373), in five steps: amplitudes; the spots in all three bases
+        (``_resolve_bases``); the null points and region in ``"knm"`` (``_resolve_nulls``); integration widths and bounds
+        (``_integration_widths``, ``_check_bounds``); then the ``FeedbackHologram`` set-up and the target raster.
+        """
         vectors = toolbox.format_2vectors(spot_vectors)
-        N = vectors.shape[1]
-        if spot_amp is not None:
-            self.spot_amp = np.ravel(spot_amp)
-            if len(self.spot_amp) != N:
-                raise ValueError("spot_amp must have the same length as the provided spots.")
+        count = vectors.shape[1]
+        if spot_amp is None:
+            self.spot_amp = np.full(count, 1.0 / np.sqrt(count))
         else:
-            self.spot_amp = np.full(N, 1.0 / np.sqrt(N))
+            self.spot_amp = np.ravel(spot_amp)
+            if len(self.spot_amp) != count:
+                raise ValueError("spot_amp must have the same length as the provided spots.")
         self.external_spot_amp = np.copy(self.spot_amp)
 
-        if null_vectors is not None:
-            null_vectors = toolbox.format_2vectors(null_vectors)
-        self.null_knm = None
-        self.null_radius_knm = None
-        self.null_region_knm = None
-
-        if basis is None or basis == "knm":
-            self.spot_knm = vectors
-            if cameraslm is not None:
-                self.spot_kxy = toolbox.convert_vector(self.spot_knm, "knm", "kxy", cameraslm, shape)
-                if "fourier" in getattr(cameraslm, "calibrations", {}):
-                    self.spot_ij = cameraslm.kxyslm_to_ijcam(self.spot_kxy)
-                else:
-                    self.spot_ij = None
-            else:
-                self.spot_kxy = None
-                self.spot_ij = None
-            self.null_knm = null_vectors
-            self.null_radius_knm = null_radius
-            self.null_region_knm = null_region
-        elif basis == "kxy":
-            assert cameraslm is not None, "We need a cameraslm to interpret kxy."
-            self.spot_kxy = vectors
-            self.spot_ij = None
-            if "fourier" in getattr(cameraslm, "calibrations", {}):
-                self.spot_ij = cameraslm.kxyslm_to_ijcam(vectors)
-            self.spot_knm = toolbox.convert_vector(self.spot_kxy, "kxy", "knm", cameraslm, shape)
-        elif basis == "ij":
-            assert cameraslm is not None, "We need an cameraslm to interpret ij."
-            assert "fourier" in cameraslm.calibrations, "We need a fourier-calibrated cameraslm to interpret ij."
-            self.spot_ij = vectors
-            self.spot_kxy = cameraslm.ijcam_to_kxyslm(vectors)
-            self.spot_knm = toolbox.convert_vector(vectors, "ij", "knm", cameraslm, shape)
-        else:
-            raise Exception("Unrecognized basis for spots '{}'.".format(basis))
-
-        if basis in ("ij", "kxy"):
-            if null_vectors is not None:
-                self.null_knm = toolbox.convert_vector(null_vectors, basis, "knm", cameraslm, shape)
-                self.null_radius_knm = None if null_radius is None else \
-                    toolbox.convert_radius(null_radius, basis, "knm", cameraslm, shape)
-            self.null_region_knm = null_region
-
-        # integration width (_spots.py:1270-1306)
-        psf_knm, psf_ij = 0, 0
-        if cameraslm is not None and hasattr(getattr(cameraslm, "slm", cameraslm), "get_spot_radius_kxy"):
-            slm = getattr(cameraslm, "slm", cameraslm)
-            psf_kxy = np.mean(slm.get_spot_radius_kxy())
-            psf_knm = toolbox.convert_radius(psf_kxy, "kxy", "knm", slm, shape)
-            if np.isnan(psf_knm):
-                psf_knm = 0
-            if self.spot_ij is not None:
-                psf_ij = toolbox.convert_radius(psf_kxy, "kxy", "ij", cameraslm, shape)
-                if np.isnan(psf_ij):
-                    psf_ij = 0
-        min_psf = 3
-        dist_knm = np.max([toolbox.smallest_distance(self.spot_knm) / 1.5, min_psf])
-        width = np.clip(10 * psf_knm, min_psf, dist_knm)
-        self.spot_integration_width_knm = int(2 * np.floor(width / 2) + 1)
-        if self.spot_ij is not None:
-            dist_ij = np.max([toolbox.smallest_distance(self.spot_ij) / 1.5, min_psf])
-            width_ij = np.clip(10 * psf_ij, min_psf, dist_ij)
-            self.spot_integration_width_ij = int(2 * np.floor(width_ij / 2) + 1)
-        else:
-            self.spot_integration_width_ij = None
-
-        if (np.any(self.spot_knm[0] < 0) or np.any(self.spot_knm[1] < 0)
-                or np.any(self.spot_knm[0] >= shape[1]) or np.any(self.spot_knm[1] >= shape[0])):
-            raise ValueError("Spots outside SLM computational space bounds!\nSpots:\n{}\nBounds: {}".format(
-                self.spot_knm, shape))
-
-        if self.spot_ij is not None and getattr(cameraslm, "cam", None) is not None:      # _spots.py:1326-1339
-            cam_shape, wij = cameraslm.cam.shape, self.spot_integration_width_ij
-            if (np.any(self.spot_ij[0] < wij / 2) or np.any(self.spot_ij[1] < wij / 2)
-                    or np.any(self.spot_ij[0] >= cam_shape[1] - wij / 2)
-                    or np.any(self.spot_ij[1] >= cam_shape[0] - wij / 2)):
-                raise ValueError("Spots outside camera bounds!\nSpots:\n{}\nBounds: {}".format(self.spot_ij, cam_shape))
-
-        if self.null_knm is not None:
-            if self.null_radius_knm is None:
-                all_spots = np.hstack((self.null_knm, self.spot_knm))
-                self.null_radius_knm = toolbox.smallest_distance(all_spots) / 4
-            self.null_radius_knm = int(np.ceil(self.null_radius_knm))
+        self._resolve_bases(vectors, "knm" if basis is None else basis, cameraslm, shape)
+        self._resolve_nulls(null_vectors, null_radius, null_region, "knm" if basis is None else basis, cameraslm, shape)
+        self._integration_widths(cameraslm, shape)
+        self._check_bounds(cameraslm, shape)
 
         super().__init__(shape, target_ij=None, cameraslm=cameraslm, **kwargs)
 
         if null_region_radius_frac is not None:
-            if self.null_region_knm is None:
-                self.null_region_knm = np.zeros(self.shape, dtype=bool)
-            xl = np.linspace(-1, 1, self.null_region_knm.shape[0])
-            yl = np.linspace(-1, 1, self.null_region_knm.shape[1])
-            xg, yg = np.meshgrid(xl, yl)
-            self.null_region_knm[np.square(xg) + np.square(yg) > null_region_radius_frac ** 2] = True
-
+            self._null_outside_radius(null_region_radius_frac)
         self.set_target(reset_weights=True)
+
+    @staticmethod
+    def _has_fourier(cameraslm):
+        return cameraslm is not None and "fourier" in getattr(cameraslm, "calibrations", {})
+
+    def _resolve_bases(self, vectors, basis, cameraslm, shape):
+        """``spot_knm`` / ``spot_kxy`` / ``spot_ij`` from vectors given in ``basis``; what cannot be derived (no SLM
+        for angles, no Fourier calibration for camera pixels) stays None -- except that "kxy" and "ij" input REQUIRE it."""
+        have_cal = self._has_fourier(cameraslm)
+        if basis == "knm":
+            knm = vectors
+            kxy = None if cameraslm is None else toolbox.convert_vector(knm, "knm", "kxy", cameraslm, shape)
+            ij = cameraslm.kxyslm_to_ijcam(kxy) if have_cal else None
+        elif basis == "kxy":
+            assert cameraslm is not None, "We need a cameraslm to interpret kxy."
+            kxy = vectors
+            ij = cameraslm.kxyslm_to_ijcam(kxy) if have_cal else None
+            knm = toolbox.convert_vector(kxy, "kxy", "knm", cameraslm, shape)
+        elif basis == "ij":
+            assert cameraslm is not None, "We need an cameraslm to interpret ij."
+            assert have_cal, "We need a fourier-calibrated cameraslm to interpret ij."
+            ij = vectors
+            kxy = cameraslm.ijcam_to_kxyslm(ij)
+            knm = toolbox.convert_vector(ij, "ij", "knm", cameraslm, shape)
+        else:
+            raise Exception("Unrecognized basis for spots '{}'.".format(basis))
+        self.spot_knm, self.spot_kxy, self.spot_ij = knm, kxy, ij
+
+    def _resolve_nulls(self, null_vectors, null_radius, null_region, basis, cameraslm, shape):
+        """Null points and their radius in "knm" (converted when the spots came in another basis; the region is a "knm"
+        mask either way).  A missing radius is a quarter of the closest approach among nulls and spots; radii are whole
+        pixels, rounded up (_spots.py:1341-1352)."""
+        self.null_region_knm = null_region
+        self.null_knm = self.null_radius_knm = None
+        if null_vectors is None:
+            if basis == "knm":
+                self.null_radius_knm = null_radius
+        else:
+            points = toolbox.format_2vectors(null_vectors)
+            if basis == "knm":
+                self.null_knm, radius = points, null_radius
+            else:
+                self.null_knm = toolbox.convert_vector(points, basis, "knm", cameraslm, shape)
+                radius = None if null_radius is None else toolbox.convert_radius(null_radius, basis, "knm", cameraslm, shape)
+            if radius is None:
+                radius = toolbox.smallest_distance(np.hstack((self.null_knm, self.spot_knm))) / 4
+            self.null_radius_knm = int(np.ceil(radius))
+
+    _MIN_WINDOW = 3
+
+    @classmethod
+    def _odd_window(cls, psf, vectors):
+        """Odd integration width: ten point-spread radii, at least _MIN_WINDOW, at most 2/3 of the closest spot pair."""
+        ceiling = max(toolbox.smallest_distance(vectors) / 1.5, cls._MIN_WINDOW)
+        return int(2 * np.floor(np.clip(10 * psf, cls._MIN_WINDOW, ceiling) / 2) + 1)
+
+    def _integration_widths(self, cameraslm, shape):
+        """``spot_integration_width_knm`` / ``_ij`` (_spots.py:1270-1306) from the SLM's diffraction-limited spot radius,
+        where an SLM that can state one is at hand (otherwise the minimum width)."""
+        slm = getattr(cameraslm, "slm", cameraslm)
+        psf = {"knm": 0, "ij": 0}
+        if slm is not None and hasattr(slm, "get_spot_radius_kxy"):
+            radius_kxy = np.mean(slm.get_spot_radius_kxy())
+            wanted = [("knm", slm)] + ([("ij", cameraslm)] if self.spot_ij is not None else [])
+            for name, converter in wanted:
+                value = toolbox.convert_radius(radius_kxy, "kxy", name, converter, shape)
+                psf[name] = 0 if np.isnan(value) else value
+        self.spot_integration_width_knm = self._odd_window(psf["knm"], self.spot_knm)
+        self.spot_integration_width_ij = None if self.spot_ij is None else self._odd_window(psf["ij"], self.spot_ij)
+
+    def _check_bounds(self, cameraslm, shape):
+        """Spots must sit on the computational grid, and -- when a camera is known -- at least half an integration
+        window inside its sensor (_spots.py:1308-1339)."""
+        x, y = self.spot_knm[0], self.spot_knm[1]
+        if np.any((x < 0) | (y < 0) | (x >= shape[1]) | (y >= shape[0])):
+            raise ValueError("Spots outside SLM computational space bounds!\nSpots:\n{}\nBounds: {}".format(self.spot_knm, shape))
+        cam = getattr(cameraslm, "cam", None)
+        if self.spot_ij is not None and cam is not None:
+            margin = self.spot_integration_width_ij / 2
+            i, j = self.spot_ij[0], self.spot_ij[1]
+            if np.any((i < margin) | (j < margin) | (i >= cam.shape[1] - margin) | (j >= cam.shape[0] - margin)):
+                raise ValueError("Spots outside camera bounds!\nSpots:\n{}\nBounds: {}".format(self.spot_ij, cam.shape))
+
+    def _null_outside_radius(self, fraction):
+        """``null_region_radius_frac`` (_spots.py:1361-1371): everything farther than ``fraction`` of the half-extent
+        from the centre joins the null region (normalised coordinates in [-1, 1] per axis; the reference lays the two
+        axes out in the order that only square shapes support, kept)."""
+        if self.null_region_knm is None:
+            self.null_region_knm = np.zeros(self.shape, dtype=bool)
+        rows, cols = self.null_region_knm.shape
+        u, v = np.meshgrid(np.linspace(-1, 1, rows), np.linspace(-1, 1, cols))
+        self.null_region_knm[u * u + v * v > fraction ** 2] = True
 
     def __len__(self):
         return self.spot_knm.shape[1]

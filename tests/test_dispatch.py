@@ -155,7 +155,7 @@ def test_compressed_forms():
         v = np.vstack([0.03 * (synth.uniform01(51, (n,), k) - 0.5) for k in range(2)])
         return v if d == 2 else np.vstack((v, 4e-6 * (synth.uniform01(51, (n,), 2) - 0.5)))
 
-    def run(n, d=2, dtype=np.float32, **opts):
+    def run(n, d=2, dtype=np.float32, opts=None):
         h = CompressedSpotHologram(spots(n, d), basis="kxy", cameraslm=fs, dtype=dtype, engine_options=opts)
         h.optimize("WGS-Leonardo", maxiter=2, verbose=False)
         return dispatch_of(h)
@@ -166,9 +166,9 @@ def test_compressed_forms():
     assert d.families() == {"c_n2f_run", "c_f2n_run"} and d.count("c_n2f_run", DEG=1) == 2, d
     d = run(40, 3)
     assert d.count("c_n2f_run", DEG=2) == 2 and d.count("c_f2n_run", DEG=2) == 2, d
-    d = run(120, **{L.OPT_SEPARABLE_MIN_SPOTS: 200})
+    d = run(120, opts={L.OPT_SEPARABLE_MIN_SPOTS: 200})
     assert d.families() == {"c_n2f_run", "c_f2n_run"}, d
     d = run(120, dtype=np.float64)                            # fp64: per-pixel kernels
     assert d.families() == {"c_n2f_partial", "c_f2n"} and d.count("c_n2f_partial", R="double", DEG=1) == 2, d
-    d = run(40, **{L.OPT_RUN_KERNELS: 0})
+    d = run(40, opts={L.OPT_RUN_KERNELS: 0})
     assert d.families() == {"c_n2f_partial", "c_f2n"} and d.count("c_f2n", R="float", DEG=1) == 2, d

@@ -194,30 +194,37 @@ def test_stats_dictionary_bookkeeping():
 
 def test_batched_stats_bookkeeping_equals_the_per_iteration_one():
     """
-    The device-resident loop writes n iterations of flag / statistics history at once (_update_stats_batch); the result
-    must be what n calls of the reference-shaped _update_stats_dictionary produce -- fresh history, an existing one,
-    histories with holes (iterations recorded before a flag / group existed), new groups, stale groups, and an
-    ``iter`` that lags the lists.
+    The device-resident loop writes n iterations of flag / statistics history at once (_update_stats_batch) and the
+    stepwise loop one at a time (_update_stats_dictionary, a range of one).  The yardstick for both is the ORACLE's
+    per-iteration writer (oracle/hgs_oracle.py update_stats, the restatement of _stats.py:130-190 that the recorded
+    reference histories pin in test_oracle_golden.py): fresh history, an existing one, histories with holes (iterations
+    recorded before a flag / group existed), new groups, stale groups, and an ``iter`` that lags the lists -- also by
+    more than the range, where a list created now must cover the whole history.
     """
     import copy
+    from oracle import hgs_oracle as orc
     rng = np.random.default_rng(5)
 
-    def scenario(prep):
+    def scenario(prep, n=7):
         a = Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
         a._update_flags("WGS-Kim", False, None, [])
         prep(a)
-        b = copy.deepcopy(a)
-        n = 7
+        b, c = copy.deepcopy(a), copy.deepcopy(a)
+        o = orc.OracleHologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
+        o.flags, o.stats, o.iter = copy.deepcopy(a.flags), copy.deepcopy(a.stats), a.iter
         hist = [bool(x) for x in rng.integers(0, 2, n)]
         groups = ["computational"] if "computational" in a.stats["stats"] or rng.integers(0, 2) else []
         per = [{g: dict(efficiency=float(rng.random()), uniformity=float(rng.random())) for g in groups} for _ in range(n)] if groups else None
         for k in range(n):
-            a.flags["fixed_phase"] = hist[k]
+            o.flags["fixed_phase"] = a.flags["fixed_phase"] = hist[k]
+            o.compute_stats = lambda stat_groups, k=k: {} if per is None else per[k]
+            o.update_stats([])
+            o.iter += 1
             a._update_stats_dictionary({} if per is None else per[k])
             a.iter += 1
         b._update_stats_batch(n, hist, per, groups)
         b.iter += n
-        assert a.iter == b.iter
+        assert a.iter == b.iter == o.iter
 
         def same(x, y):
             if isinstance(x, dict):
@@ -228,7 +235,8 @@ def test_batched_stats_bookkeeping_equals_the_per_iteration_one():
                 assert len(x) == len(y), (len(x), len(y))
                 for u, v in zip(x, y):
                     assert (u == v) or (isinstance(u, float) and isinstance(v, float) and np.isnan(u) and np.isnan(v)), (u, v)
-        same(a.stats, b.stats)
+        same(o.stats, a.stats)
+        same(o.stats, b.stats)
 
     scenario(lambda h: None)                                            # fresh
 
@@ -250,6 +258,13 @@ def test_batched_stats_bookkeeping_equals_the_per_iteration_one():
         with_history(h)
         h.iter = 3                                                      # lists longer than iter: entries are overwritten
     scenario(lagging_iter)
+
+    def far_behind(h):
+        with_history(h)
+        with_history(h)
+        h.iter = 1
+        h.flags["brand_new_flag"] = "y"                                 # created now: must be as long as the history
+    scenario(far_behind, n=3)
 
 
 def test_false_run_is_capped_where_only_the_threshold_matters():
