@@ -98,7 +98,7 @@ enum {
     HGS_PHASE = 0,        /* [batch][slm_h][slm_w] real      Hologram.phase              */
     HGS_AMP = 1,          /* [slm_h][slm_w] real, unit L2    Hologram.amp (array form)   */
     HGS_AMP_SCALAR = 2,   /* 1 real                          Hologram.amp (scalar form)  */
-    HGS_PROP_KERNEL = 3,  /* [slm_h][slm_w] real             Hologram.propagation_kernel */
+    HGS_PROP_KERNEL = 3,  /* [slm_h][slm_w] real             Hologram.propagation_kernel; nbytes = 0: none */
     HGS_TARGET = 4,       /* [batch][pad_h][pad_w] real      Hologram.target (may hold NaN) */
     HGS_WEIGHTS = 5,      /* [batch][pad_h][pad_w] real      Hologram.weights            */
     HGS_PHASE_FF = 6,     /* [batch][pad_h][pad_w] real      Hologram.phase_ff           */
@@ -125,17 +125,25 @@ int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes);
 int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes);
 /* device -> caller-provided DEVICE buffer (e.g. a torch tensor handed to RCCL); synchronous */
 int hgs_get_array_device(hgs_engine* e, int which, void* dev, size_t nbytes);
+/* caller-provided DEVICE buffer -> engine (same layouts and sizes as hgs_set_array): what the reference does when it is
+ * handed CuPy arrays (`cp.array(x, copy=False)`, _hologram.py:70-77) -- no host bounce.  Arrays the engine parses on the
+ * host (HGS_SPOT_INDEX, HGS_XGRID/YGRID, HGS_MONOMIALS, HGS_SPOT_COEFF, HGS_AMP_SCALAR) return HGS_ERR_UNSUPPORTED. */
+int hgs_set_array_device(hgs_engine* e, int which, const void* dev, size_t nbytes);
+/* dst.phase <- src.phase on the device (same SLM shape and precision; one source hologram broadcasts over dst's batch;
+ * engines on different GPUs use a peer copy).  Hologram.get_farfield (_hologram.py:853-931, the per-frame call of
+ * SimulatedCamera) transforms the current phase on another grid without moving it through the host. */
+int hgs_copy_phase(hgs_engine* dst, hgs_engine* src);
 /* Hologram.reset_weights (:603-614): weights = target with NaN -> 0; zero_weights cleared */
 int hgs_reset_weights(hgs_engine* e);
 /* Hologram.reset (:442-478) as far as the device is concerned: hgs_reset_weights, and phase_ff / farfield /
  * amp_ff go back to "None" (a later WGS-Kim fix stores a fresh phase; reading them back fails with
  * HGS_ERR_STATE until hgs_nearfield2farfield ran).  Phase, amplitude, target, spots and options stay. */
 int hgs_reset(hgs_engine* e);
-/* Sparse upload of a farfield-sized real array (HGS_TARGET or HGS_WEIGHTS, kind 0): the array becomes `fill`
- * everywhere (0 or NaN -- the MRAF background of a SpotHologram with null points is not supported here, upload
- * it densely) except values[k] at pixel (kx = xy[k], ky = xy[n + k]), k < n, later entries winning where
- * pixels repeat (NumPy fancy assignment, _spots.py:1541).  One hologram's list broadcasts over the batch.
- * This is what SpotHologram._set_target_spots produces: n_spots values instead of pad_h * pad_w. */
+/* Sparse upload of a farfield-sized real array (HGS_TARGET or HGS_WEIGHTS, kind 0): the array becomes ZERO everywhere
+ * except values[k] at pixel (kx = xy[k], ky = xy[n + k]), k < n, later entries winning where pixels repeat (NumPy fancy
+ * assignment, _spots.py:1541).  One hologram's list broadcasts over the batch.  This is what
+ * SpotHologram._set_target_spots produces without null points: n_spots values instead of pad_h * pad_w.  A NaN
+ * background (null points) cannot be expressed here: upload such a target densely with hgs_set_array. */
 int hgs_set_array_sparse(hgs_engine* e, int which, const int32_t* xy, const void* values, int32_t n);
 
 /* Hologram._nearfield2farfield (:1038-1056) + _midloop_cleaning (:951-953): fills farfield and

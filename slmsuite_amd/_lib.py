@@ -48,14 +48,17 @@ def _torch_runtime_first():
     PyTorch-ROCm wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so) next to the system one
     libhgs.so links (libamdhip64.so.7).  Both can live in one process -- the batch driver hands torch tensors to
     hgs_get_array_device -- but only when torch's copy has opened the GPU FIRST: after the system runtime did,
-    ``torch.cuda`` reports "No HIP GPUs are available" (measured on the MI355X box, round 3).  So when torch is
-    installed its runtime is brought up before libhgs.so is loaded (HGS_SKIP_TORCH_INIT=1 skips this).
+    ``torch.cuda`` reports "No HIP GPUs are available" (measured on the MI355X box, round 3).
+
+    So a process that ALREADY imported torch gets torch's runtime brought up before libhgs.so is loaded.  A process that
+    has not is left alone: a pure NumPy caller pays neither the import (seconds) nor a HIP context in a parent that may
+    still fork workers.  Load order for mixed use: ``import torch`` before the first engine (slmsuite_amd.batch's
+    distributed path and bench.py do); ``HGS_TORCH_INIT=1`` forces the old behaviour, ``HGS_SKIP_TORCH_INIT=1`` skips it.
     """
+    import sys
     if os.environ.get("HGS_SKIP_TORCH_INIT") == "1":
         return
-    import importlib.util
-    import sys
-    if "torch" not in sys.modules and importlib.util.find_spec("torch") is None:
+    if "torch" not in sys.modules and os.environ.get("HGS_TORCH_INIT") != "1":
         return
     try:
         import torch
@@ -85,6 +88,8 @@ def load():
         "hgs_set_array": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
         "hgs_get_array": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
         "hgs_get_array_device": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
+        "hgs_set_array_device": (C.c_int, [eng, C.c_int, C.c_void_p, C.c_size_t]),
+        "hgs_copy_phase": (C.c_int, [eng, eng]),
         "hgs_reset_weights": (C.c_int, [eng]),
         "hgs_reset": (C.c_int, [eng]),
         "hgs_set_array_sparse": (C.c_int, [eng, C.c_int, P(C.c_int32), C.c_void_p, C.c_int32]),
@@ -113,7 +118,7 @@ def load():
     return lib
 
 
-EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device",
+EXPORTS = ("hgs_create", "hgs_destroy", "hgs_set_array", "hgs_get_array", "hgs_get_array_device", "hgs_set_array_device", "hgs_copy_phase",
            "hgs_reset_weights", "hgs_reset", "hgs_set_array_sparse", "hgs_nearfield2farfield", "hgs_farfield_constraint",
            "hgs_farfield2nearfield", "hgs_iterate", "hgs_iterate_stats", "hgs_stats", "hgs_multiplane_farfield2nearfield", "hgs_set_option", "hgs_sync", "hgs_profile_enable",
            "hgs_profile_read", "hgs_iterate_timed", "hgs_dispatch_read", "hgs_last_error", "hgs_version")

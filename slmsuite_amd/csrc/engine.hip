@@ -134,7 +134,11 @@ struct EngineBase {
     DispatchLog dispatch;    // kernel instances launched since the last hgs_dispatch_read
     virtual ~EngineBase() {}
     virtual int init(const hgs_config& c) = 0;
-    virtual int set_array(int which, const void* host, size_t nbytes) = 0;
+    virtual int set_array(int which, const void* src, size_t nbytes, bool src_device) = 0;
+    // device-resident phase of another engine (same SLM shape, precision and batch); PhaseRef: see phase_ref()
+    struct PhaseRef { const void* ptr; size_t S; int B; int real_bytes; int device; hipStream_t stream; };
+    virtual int phase_ref(PhaseRef* out) = 0;
+    virtual int copy_phase_from(const PhaseRef& src) = 0;
     virtual int get_array(int which, void* dst, size_t nbytes, bool dst_device) = 0;
     virtual int reset_weights() = 0;
     virtual int reset_state() = 0;
@@ -301,8 +305,8 @@ template <typename R> struct Engine : EngineBase {
 
     // host -> device on the engine stream, complete on return (ordered against in-flight kernels of this
     // engine; the caller's buffer may be reused immediately)
-    int h2d(void* dst, const void* src, size_t nbytes) {
-        HIPCHK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, stream));
+    int h2d(void* dst, const void* src, size_t nbytes, bool src_device = false) {
+        HIPCHK(hipMemcpyAsync(dst, src, nbytes, src_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -1078,7 +1082,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     // ---- natural <-> column-major moves through the staging buffer ----
-    template <typename E> int upload_T(E* dst, const void* host, size_t nbytes) {
+    template <typename E> int upload_T(E* dst, const void* host, size_t nbytes, bool src_device = false) {
         // host natural [B][Ph][Pw] -> device column-major [B][Pw][Ph]
         const size_t one = P * sizeof(E);
         if (nbytes != one * B && nbytes != one) return fail(HGS_ERR_ARG, "array size %zu does not match %zu x {1,%d}", nbytes, one, B);
@@ -1086,7 +1090,7 @@ template <typename R> struct Engine : EngineBase {
         E* st = reinterpret_cast<E*>(staging);
         for (int b = 0; b < B; ++b) {
             const char* src = (const char*)host + (nbytes == one ? 0 : (size_t)b * one);
-            HIPCHK(hipMemcpyAsync(st + (size_t)b * P, src, one, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(st + (size_t)b * P, src, one, src_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
         }
         dim3 grid((g.Pw + 31) / 32, (g.Ph + 31) / 32, B);
         hipLaunchKernelGGL((transpose_scale<E, R>), grid, dim3(32, 8), 0, stream, (const E*)st, dst, g.Ph, g.Pw,
@@ -1109,15 +1113,23 @@ template <typename R> struct Engine : EngineBase {
         return 0;
     }
 
-    int set_array(int which, const void* host, size_t nbytes) override {
-        if (!host) return fail(HGS_ERR_ARG, "null host pointer");
+    int set_array(int which, const void* host, size_t nbytes, bool src_device) override {
+        if (which == HGS_PROP_KERNEL && nbytes == 0) {       // "no kernel" (Hologram.propagation_kernel = None / 0)
+            has_kern = false;
+            farfield_valid = false;
+            return 0;
+        }
+        if (!host) return fail(HGS_ERR_ARG, "null source pointer");
+        const hipMemcpyKind kind = src_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (src_device && (which == HGS_XGRID || which == HGS_YGRID || which == HGS_MONOMIALS || which == HGS_SPOT_COEFF ||
+                           which == HGS_SPOT_INDEX || which == HGS_AMP_SCALAR))
+            return fail(HGS_ERR_UNSUPPORTED, "array selector %d is parsed on the host: upload it with hgs_set_array", which);
         switch (which) {
             case HGS_PHASE: {
                 const size_t one = S * sizeof(R);
                 if (nbytes != one * B && nbytes != one) return fail(HGS_ERR_ARG, "phase: bad size %zu", nbytes);
                 for (int b = 0; b < B; ++b)
-                    HIPCHK(hipMemcpyAsync(phase + (size_t)b * S, (const char*)host + (nbytes == one ? 0 : b * one), one,
-                                          hipMemcpyHostToDevice, stream));
+                    HIPCHK(hipMemcpyAsync(phase + (size_t)b * S, (const char*)host + (nbytes == one ? 0 : b * one), one, kind, stream));
                 HIPCHK(hipStreamSynchronize(stream));
                 farfield_valid = false;
                 return 0;
@@ -1125,11 +1137,24 @@ template <typename R> struct Engine : EngineBase {
             case HGS_AMP: {
                 if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "amp: bad size %zu", nbytes);
                 if (!amp) HIPCHK(hipMalloc(reinterpret_cast<void**>(&amp), S * sizeof(R)));
-                if (int e_ = h2d(amp, host, nbytes)) return e_;
+                if (int e_ = h2d(amp, host, nbytes, src_device)) return e_;
                 has_amp = true;
-                const R* h = (const R*)host;
                 double s = 0;
-                for (size_t i = 0; i < S; ++i) s += (double)h[i] * (double)h[i];
+                if (src_device) {         // ||amp||^2 on the device: per-block partials (double), folded here
+                    const int nb = (int)std::min<size_t>((S + 255) / 256, 1024);
+                    double* part = nullptr;
+                    HIPCHK(hipMalloc(reinterpret_cast<void**>(&part), (size_t)nb * sizeof(double)));
+                    hipLaunchKernelGGL(ew_sumsq<R>, dim3(nb, 1), dim3(256), 0, stream, (const R*)amp, S, part);
+                    std::vector<double> hp(nb);
+                    hipError_t e1 = hipMemcpyAsync(hp.data(), part, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, stream);
+                    hipError_t e2 = hipStreamSynchronize(stream);
+                    hipFree(part);
+                    if (e1 != hipSuccess || e2 != hipSuccess) return fail(HGS_ERR_DEVICE, "amplitude norm failed");
+                    for (double v : hp) s += v;
+                } else {
+                    const R* h = (const R*)host;
+                    for (size_t i = 0; i < S; ++i) s += (double)h[i] * (double)h[i];
+                }
                 amp_norm2 = s;
                 farfield_valid = false;
                 return 0;
@@ -1145,7 +1170,7 @@ template <typename R> struct Engine : EngineBase {
             case HGS_PROP_KERNEL: {
                 if (nbytes != S * sizeof(R)) return fail(HGS_ERR_ARG, "propagation kernel: bad size %zu", nbytes);
                 if (!kern) HIPCHK(hipMalloc(reinterpret_cast<void**>(&kern), S * sizeof(R)));
-                if (int e_ = h2d(kern, host, nbytes)) return e_;
+                if (int e_ = h2d(kern, host, nbytes, src_device)) return e_;
                 has_kern = true;
                 farfield_valid = false;
                 return 0;
@@ -1153,21 +1178,21 @@ template <typename R> struct Engine : EngineBase {
             case HGS_TARGET:
                 has_target = true;
                 sparse_dirty = true;
-                return upload_T<R>(t, host, nbytes);
+                return upload_T<R>(t, host, nbytes, src_device);
             case HGS_WEIGHTS: {
                 sparse_dirty = true;
-                int e = upload_T<R>(w, host, nbytes);
+                int e = upload_T<R>(w, host, nbytes, src_device);
                 if (e) return e;
                 return fill_wscale_one();
             }
             case HGS_PHASE_FF: {
                 if (int e = need_pff()) return e;
                 have_pff = true;
-                return upload_T<R>(pff, host, nbytes);
+                return upload_T<R>(pff, host, nbytes, src_device);
             }
             case HGS_ZERO_WEIGHTS: {
                 if (int e = need_zw()) return e;
-                return upload_T<C>(zw, host, nbytes);
+                return upload_T<C>(zw, host, nbytes, src_device);
             }
             case HGS_XGRID:
             case HGS_YGRID: {
@@ -1235,13 +1260,32 @@ template <typename R> struct Engine : EngineBase {
                 if (cfg.kind == 1 && which == HGS_SPOT_AMP) return fail(HGS_ERR_ARG, "compressed targets are set with HGS_TARGET");
                 if (cfg.n_spots <= 0) return fail(HGS_ERR_STATE, "engine was created with n_spots = 0");
                 if (nbytes != (size_t)cfg.n_spots * sizeof(double)) return fail(HGS_ERR_ARG, "spot amplitudes: bad size");
-                if (int e_ = h2d(which == HGS_SPOT_AMP ? spot_amp : ext_amp, host, nbytes)) return e_;
+                if (int e_ = h2d(which == HGS_SPOT_AMP ? spot_amp : ext_amp, host, nbytes, src_device)) return e_;
                 return 0;
             }
         }
         return fail(HGS_ERR_ARG, "unknown array selector %d", which);
     }
     std::vector<int32_t> spot_xy_host;
+
+    int phase_ref(PhaseRef* o) override {
+        o->ptr = phase; o->S = S; o->B = B; o->real_bytes = (int)sizeof(R); o->device = cfg.device; o->stream = stream;
+        return 0;
+    }
+    // phase <- the phase another engine holds, device to device (no host bounce); one source hologram broadcasts
+    int copy_phase_from(const PhaseRef& src) override {
+        if (src.S != S || src.real_bytes != (int)sizeof(R) || (src.B != B && src.B != 1))
+            return fail(HGS_ERR_ARG, "hgs_copy_phase: engines differ in SLM shape, precision or batch");
+        if (hipStreamSynchronize(src.stream) != hipSuccess) return fail(HGS_ERR_DEVICE, "hgs_copy_phase: source stream sync failed");
+        for (int b = 0; b < B; ++b) {
+            const char* from = (const char*)src.ptr + (src.B == 1 ? 0 : (size_t)b * S * sizeof(R));
+            if (src.device == cfg.device) HIPCHK(hipMemcpyAsync(phase + (size_t)b * S, from, S * sizeof(R), hipMemcpyDeviceToDevice, stream));
+            else HIPCHK(hipMemcpyPeerAsync(phase + (size_t)b * S, cfg.device, from, src.device, S * sizeof(R), stream));
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        farfield_valid = false;
+        return 0;
+    }
 
     int normalize_weights_now() {
         // fold the pending 1/||w|| into the stored weights (general path keeps them normalised)
@@ -1488,6 +1532,7 @@ template <typename R> struct Engine : EngineBase {
 
     int n2f(int store_pff) override {
         RoctxRange range(opt_roctx, "hgs_nearfield2farfield");
+        row_split = false;       // (a single-pass MRAF call that failed between its column and row launch must not leak)
         if (cfg.kind == 1) return n2f_compressed(store_pff);
         if (general) return n2f_general(store_pff);
         if (int e = need_ff()) return e;
@@ -1508,6 +1553,7 @@ template <typename R> struct Engine : EngineBase {
 
     int f2n() override {
         RoctxRange range(opt_roctx, "hgs_farfield2nearfield");
+        row_split = false;
         if (cfg.kind == 1) return f2n_compressed();
         if (general) return f2n_general(false);
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
@@ -1833,6 +1879,7 @@ template <typename R> struct Engine : EngineBase {
 
     int iterate(hgs_step* st, int n, uint8_t* hist) override {
         RoctxRange range(opt_roctx, "hgs_iterate");
+        row_split = false;
         if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
         if (n == 0) return 0;
         if (int e = check_step(st)) return e;
@@ -2322,7 +2369,15 @@ int hgs_destroy(hgs_engine* e) {
     hgs::DeviceGuard guard_((e)->impl->device, &(e)->impl->dispatch);                   \
     if (!guard_.ok) return hgs::fail(HGS_ERR_DEVICE, "hipSetDevice(%d) failed", (e)->impl->device);
 
-int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes) { ENG(e) return e->impl->set_array(which, host, nbytes); }
+int hgs_set_array(hgs_engine* e, int which, const void* host, size_t nbytes) { ENG(e) return e->impl->set_array(which, host, nbytes, false); }
+int hgs_set_array_device(hgs_engine* e, int which, const void* dev, size_t nbytes) { ENG(e) return e->impl->set_array(which, dev, nbytes, true); }
+int hgs_copy_phase(hgs_engine* dst, hgs_engine* src) {
+    if (!src || !src->impl) return hgs::fail(HGS_ERR_ARG, "null source engine");
+    ENG(dst)
+    hgs::EngineBase::PhaseRef ref;
+    if (int r = src->impl->phase_ref(&ref)) return r;
+    return dst->impl->copy_phase_from(ref);
+}
 int hgs_get_array(hgs_engine* e, int which, void* host, size_t nbytes) { ENG(e) return e->impl->get_array(which, host, nbytes, false); }
 int hgs_get_array_device(hgs_engine* e, int which, void* dev, size_t nbytes) { ENG(e) return e->impl->get_array(which, dev, nbytes, true); }
 int hgs_reset_weights(hgs_engine* e) { ENG(e) return e->impl->reset_weights(); }

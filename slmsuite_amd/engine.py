@@ -21,6 +21,7 @@ class Engine:
             raise ValueError(f"Data type {dtype} not supported.")
         self.ctype = np.dtype(np.complex64 if self.dtype == np.float32 else np.complex128)
         self.kind = int(kind)
+        self.device = int(device)
         self.slm_shape = (int(slm_shape[0]), int(slm_shape[1]))
         self.batch = int(batch)
         self.n_spots = int(n_spots)
@@ -74,6 +75,38 @@ class Engine:
 
     def get_into_device(self, which, dev_ptr, nbytes):
         L.check(self.lib.hgs_get_array_device(self._h, which, C.c_void_p(dev_ptr), nbytes))
+
+    def set_from_device(self, which, dev_ptr, nbytes):
+        """hgs_set_array_device: ``nbytes`` at device address ``dev_ptr`` (e.g. ``tensor.data_ptr()``), layouts as ``set``."""
+        L.check(self.lib.hgs_set_array_device(self._h, which, C.c_void_p(dev_ptr), nbytes))
+
+    def set_tensor(self, which, tensor):
+        """A contiguous torch CUDA tensor of the engine's element type, device to device."""
+        want = {4: "float32", 8: "float64"}[self.dtype.itemsize]
+        if which in (L.FARFIELD, L.ZERO_WEIGHTS):
+            want = {4: "complex64", 8: "complex128"}[self.dtype.itemsize]
+        if str(tensor.dtype).split(".")[-1] != want:
+            tensor = tensor.to(getattr(__import__("torch"), want))
+        tensor = tensor.contiguous()
+        self.set_from_device(which, tensor.data_ptr(), tensor.numel() * tensor.element_size())
+
+    def clear_propagation_kernel(self):
+        """hgs_set_array(HGS_PROP_KERNEL, nbytes = 0): no kernel."""
+        L.check(self.lib.hgs_set_array(self._h, L.PROP_KERNEL, None, 0))
+
+    def copy_phase_from(self, other):
+        """hgs_copy_phase: this engine's phase <- ``other``'s, on the device."""
+        L.check(self.lib.hgs_copy_phase(self._h, other._h))
+
+    def get_tensor(self, which):
+        """Array ``which`` as a torch tensor on the engine's GPU ([batch, ...], natural layout): no host copy."""
+        import torch
+        real = {4: torch.float32, 8: torch.float64}[self.dtype.itemsize]
+        cplx = {4: torch.complex64, 8: torch.complex128}[self.dtype.itemsize]
+        shape = (self.batch,) + (self.slm_shape if which == L.PHASE else self.shape)
+        t = torch.empty(shape, dtype=cplx if which in (L.FARFIELD, L.ZERO_WEIGHTS) else real, device=torch.device("cuda", self.device))
+        self.get_into_device(which, t.data_ptr(), t.numel() * t.element_size())
+        return t
 
     def set_sparse(self, which, xy, values):
         """hgs_set_array_sparse: ``values[k]`` at pixel (kx = xy[0, k], ky = xy[1, k]), zero elsewhere."""

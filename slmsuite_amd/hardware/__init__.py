@@ -78,24 +78,52 @@ class SimpleFourierSLM:
             raise RuntimeError("Fourier calibration must exist to be used.")
         return self.calibrations["fourier"]
 
+    _METRES = {"m": 1.0, "cm": 1e-2, "mm": 1e-3, "um": 1e-6, "nm": 1e-9}
+
+    def get_effective_focal_length(self, units="norm"):
+        """Scalar focal length of the train between SLM and camera from the calibration's magnification
+        (cameraslms.py:1436-1487): sqrt|det M| camera pixels per radian, in pixels ("ij"), wavelengths ("norm") or metres."""
+        pixels = np.sqrt(np.abs(np.linalg.det(self._fourier()["M"])))
+        if units == "ij":
+            return pixels
+        pitch_um = None if self.cam is None else getattr(self.cam, "pitch_um", None)
+        if pitch_um is None:
+            import warnings
+            warnings.warn(f"cam.pitch_um must be set to use units '{units}'")
+            return np.nan
+        if units == "norm":
+            return pixels * np.array(pitch_um) / self.slm.wav_um
+        if units in self._METRES:
+            return pixels * np.array(pitch_um) * 1e-6 / self._METRES[units]
+        raise ValueError(f"Unit '{units}' not recognized as a length.")
+
+    def _depth_gain(self):
+        """Camera-pixel depth per unit of focal power x_z (cameraslms.py:1221-1237): wav * f_eff^2 / cam pitch."""
+        f_eff = np.mean(self.get_effective_focal_length("norm"))
+        pitch_um = None if self.cam is None else getattr(self.cam, "pitch_um", None)
+        return self.slm.wav_um * f_eff * f_eff / (np.nan if pitch_um is None else np.mean(pitch_um))
+
     @staticmethod
-    def _vectors2(v):
+    def _columns(v):
+        """Vectors as columns, 2 (lateral) or 3 (lateral + depth) rows."""
         v = np.asarray(v, dtype=float)
         if v.ndim == 1:
             v = v.reshape(-1, 1)
-        if v.shape[0] != 2:
-            raise NotImplementedError("depth (3-vector) conversion needs the full FourierSLM of the reference")
+        if v.shape[0] not in (2, 3):
+            raise ValueError(f"Expected 2- or 3-vectors as columns, got an array of shape {v.shape}")
         return v
 
     def kxyslm_to_ijcam(self, kxy):
-        """cameraslms.py:1240-1294 (lateral part)."""
-        c = self._fourier()
-        return np.matmul(c["M"], self._vectors2(kxy) - c["a"]) + c["b"]
+        """cameraslms.py:1240-1294: ij = M (kxy - a) + b on the lateral rows; a depth row (focal power) scales to camera-pixel depth."""
+        c, v = self._fourier(), self._columns(kxy)
+        ij = np.matmul(c["M"], v[:2] - c["a"]) + c["b"]
+        return ij if v.shape[0] == 2 else np.vstack((ij, v[2:] * self._depth_gain()))
 
     def ijcam_to_kxyslm(self, ij):
-        """cameraslms.py:1296-1354 (lateral part)."""
-        c = self._fourier()
-        return np.matmul(np.linalg.inv(c["M"]), self._vectors2(ij) - c["b"]) + c["a"]
+        """cameraslms.py:1296-1354: the inverse map; a depth row in camera pixels becomes focal power."""
+        c, v = self._fourier(), self._columns(ij)
+        kxy = np.matmul(np.linalg.inv(c["M"]), v[:2] - c["b"]) + c["a"]
+        return kxy if v.shape[0] == 2 else np.vstack((kxy, v[2:] / self._depth_gain()))
 
     def fourier_grid_project(self, array_shape=10, array_pitch=10, array_center=None, **kwargs):
         """

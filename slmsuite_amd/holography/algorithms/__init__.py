@@ -58,6 +58,11 @@ def _norm(matrix):
     return np.sqrt(np.nansum(np.square(matrix)))
 
 
+def _is_device_tensor(value):
+    """A torch tensor that lives on a GPU (the engine takes those device to device)."""
+    return type(value).__module__.split(".")[0] == "torch" and bool(getattr(value, "is_cuda", False))
+
+
 def _history_put(seq, start, values, fill=np.nan):
     """``seq[start:start + len(values)] = values``, growing ``seq`` with ``fill`` as far as needed (at least to ``start``)."""
     missing = start + len(values) - len(seq)
@@ -159,7 +164,10 @@ class Hologram:
             self._stale.discard(name)
         elif name == "weights":
             self._materialise_weights()
-        return self._host.get(name)
+        value = self._host.get(name)
+        if _is_device_tensor(value):           # assigned as a GPU tensor and not yet handed to an engine
+            return value.detach().cpu().numpy().astype(self.dtype, copy=False)
+        return value
 
     def _set_dev(self, name, value):
         if name == "phase":
@@ -221,8 +229,14 @@ class Hologram:
                 self._upload.add("phase_ff")
             self._engine_setup(e)
         for name in list(self._upload):
-            if self._host.get(name) is not None:
-                e.set(_DEVICE_ARRAYS[name], self._host[name])
+            value = self._host.get(name)
+            if _is_device_tensor(value):
+                # already on a GPU: device to device, and from here on the engine's copy is the one that counts
+                e.set_tensor(_DEVICE_ARRAYS[name], value.reshape((1,) + tuple(value.shape[-2:])))
+                self._host[name] = None
+                self._stale.add(name)
+            elif value is not None:
+                e.set(_DEVICE_ARRAYS[name], value)
             self._upload.discard(name)
         return e
 
@@ -235,22 +249,21 @@ class Hologram:
 
     # ---- reset helpers (_hologram.py:442-614) -----------------------------------------------------------
     def reset(self, reset_phase=True, reset_flags=False):
-        if self._host.get("phase") is None or reset_phase:
+        """``Hologram.reset`` (:442-478): iteration counter, history and weights start over; the phase only on request
+        (or when there is none); the flags only on request.  The engine, if any, survives."""
+        if reset_phase or self._host.get("phase") is None:
             self.reset_phase()
         self.reset_weights()
-        self.iter = 0
-        self.stats = {"method": [], "flags": {}, "stats": {}}
+        self.iter, self.stats = 0, dict(method=[], flags={}, stats={})
         if reset_flags:
-            self.flags = {"method": ""}
-        self._host["amp_ff"] = None
-        self._host["phase_ff"] = None
-        self._host["farfield"] = np.zeros(self.shape, dtype=self.dtype_complex)
+            self.flags = dict(method="")
+        self._host.update(amp_ff=None, phase_ff=None, farfield=np.zeros(self.shape, dtype=self.dtype_complex))
         self._stale -= {"amp_ff", "phase_ff", "farfield"}
         self._upload.discard("phase_ff")
         self._populate_pending = False
         if self._engine is not None:
-            # the engine survives: weights from its target, phase_ff / farfield / amp_ff back to "None" (hgs_reset);
-            # a phase only the device holds (reset_phase False after an optimize()) simply stays there
+            # weights from its target, phase_ff / farfield / amp_ff back to "None" (hgs_reset); a phase only the device
+            # holds (reset_phase False after an optimize()) simply stays there
             self._engine.reset()
 
     def _release_engine(self):
@@ -268,8 +281,7 @@ class Hologram:
         self._engine = None
 
     def _get_random_phase(self):
-        rng = np.random.default_rng()
-        return rng.uniform(-np.pi, np.pi, self.slm_shape).astype(self.dtype)
+        return np.random.default_rng().uniform(-np.pi, np.pi, size=self.slm_shape).astype(self.dtype)
 
     def _get_target_moments_knm_norm(self):
         """Centre and standard deviation of the target in knm pixels / shape (_hologram.py:480-500)."""
@@ -298,22 +310,27 @@ class Hologram:
         return np.array(toolbox.blaze(grid, slm_shape * center_knm_norm) + toolbox.lens(grid, f), dtype=self.dtype)
 
     def reset_phase(self, custom_phase=None, random_phase=None, quadratic_phase=None):
-        if custom_phase is not None:
-            custom_phase = np.array(custom_phase, dtype=self.dtype)
+        """``Hologram.reset_phase`` (:536-601): a given phase verbatim; otherwise ``quadratic_phase`` x the lens + blaze
+        guess plus ``random_phase`` x uniform noise, each taken from the flags when not passed (defaults: off, 1)."""
+        if _is_device_tensor(custom_phase):
             if tuple(custom_phase.shape) != tuple(self.slm_shape):
-                raise ValueError(f"Reset phase of shape {custom_phase.shape} is not of slm_shape {self.slm_shape}")
-            self.phase = custom_phase.copy()
+                raise ValueError(f"Reset phase of shape {tuple(custom_phase.shape)} is not of slm_shape {self.slm_shape}")
+            self.phase = custom_phase.detach().clone()          # stays on the GPU; uploaded device to device
             return
-        if quadratic_phase is None:
-            quadratic_phase = self.flags.get("quadratic_phase", False)
-        if random_phase is None:
-            random_phase = self.flags.get("random_phase", 1)
-        ph = np.zeros(self.slm_shape, dtype=self.dtype)
-        if quadratic_phase:
-            ph += self._get_quadratic_initial_phase(quadratic_phase)
-        if random_phase:
-            ph += random_phase * self._get_random_phase()
-        self.phase = ph
+        if custom_phase is not None:
+            given = np.array(custom_phase, dtype=self.dtype)
+            if tuple(given.shape) != tuple(self.slm_shape):
+                raise ValueError(f"Reset phase of shape {given.shape} is not of slm_shape {self.slm_shape}")
+            self.phase = given.copy()
+            return
+        quadratic = self.flags.get("quadratic_phase", False) if quadratic_phase is None else quadratic_phase
+        noise = self.flags.get("random_phase", 1) if random_phase is None else random_phase
+        total = np.zeros(self.slm_shape, dtype=self.dtype)
+        if quadratic:
+            total += self._get_quadratic_initial_phase(quadratic)
+        if noise:
+            total += noise * self._get_random_phase()
+        self.phase = total
 
     def reset_weights(self):
         self._host["weights"] = None          # = target with NaN -> 0; see _materialise_weights
@@ -327,40 +344,35 @@ class Hologram:
     @staticmethod
     def get_padded_shape(slm_shape, padding_order=1, square_padding=True, precision=np.inf,
                          precision_basis="kxy"):
-        cameraslm = None
+        """
+        Computational shape for an SLM (``_hologram.py:616-725``): per axis the larger of (a) the ``padding_order``-th
+        power of two above the SLM shape (order 0: the SLM shape itself) and (b), with a finite ``precision``, the power
+        of two whose DFT grid resolves ``precision`` in ``precision_basis`` (needs the SLM's pitch, hence an SLM or
+        FourierSLM object; "ij" needs the FourierSLM's calibration); squared up on request.
+        """
+        fourier, slm = None, None
         if hasattr(slm_shape, "slm") and hasattr(slm_shape, "cam"):
-            cameraslm = slm_shape
-            slm_shape = cameraslm.slm.shape
+            fourier, slm = slm_shape, slm_shape.slm
         elif hasattr(slm_shape, "shape"):
-            class _Fake:
-                pass
-            cameraslm = _Fake()
-            cameraslm.slm = slm_shape
-            slm_shape = cameraslm.slm.shape
+            slm = slm_shape
             if precision_basis == "ij":
                 raise ValueError("Must pass a CameraSLM object under slm_shape to use the 'ij' precision_basis!")
-        if np.isfinite(precision) and cameraslm is not None:
+        base = tuple(slm.shape) if slm is not None else tuple(slm_shape)
+
+        floor = base                                   # (b): nothing asked for
+        if np.isfinite(precision):
+            if slm is None:
+                raise ValueError("Must pass a CameraSLM object under slm_shape to implement precision calculations!")
             if precision <= 0:
                 raise ValueError("Precision passed to get_padded_shape() must be positive.")
-            fs = 1 / np.amin(cameraslm.slm.pitch)
-            if precision_basis == "ij":
-                pixels = np.amax(cameraslm.kxyslm_to_ijcam([fs, fs])) / precision
-            else:
-                pixels = fs / precision
-            pixels = int(np.power(2, int(np.ceil(np.log2(pixels)))))
-            precision_shape = (pixels, pixels)
-        elif np.isfinite(precision):
-            raise ValueError("Must pass a CameraSLM object under slm_shape to implement precision calculations!")
-        else:
-            precision_shape = slm_shape
-        if padding_order > 0:
-            padding_shape = np.power(2, np.ceil(np.log2(slm_shape)) + padding_order - 1).astype(int)
-        else:
-            padding_shape = slm_shape
-        shape = tuple(int(s) for s in np.amax(np.vstack((precision_shape, padding_shape)), axis=0))
-        if square_padding:
-            shape = (max(shape), max(shape))
-        return shape
+            sampling = 1 / np.amin(slm.pitch)
+            extent = np.amax(fourier.kxyslm_to_ijcam([sampling, sampling])) if precision_basis == "ij" else sampling
+            side = 1 << int(np.ceil(np.log2(extent / precision)))
+            floor = (side, side)
+        padded = base if padding_order <= 0 else tuple(
+            int(2 ** (np.ceil(np.log2(v)) + padding_order - 1)) for v in base)
+        shape = tuple(int(max(u, v)) for u, v in zip(floor, padded))
+        return (max(shape),) * 2 if square_padding else shape
 
     # ---- target / accessors (_hologram.py:741-931) ---------------------------------------------------------
     def _set_target(self, new_target, reset_weights=False):
@@ -375,21 +387,27 @@ class Hologram:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 self.target *= 1 / _norm(self.target)
+        self._target_changed(reset_weights)
+
+    def _target_changed(self, reset_weights):
+        """A new ``self.target`` goes to the engine (if one exists); the weights follow it on request."""
         if self._engine is not None:
             self._upload_target(self._engine)
         if reset_weights:
             self.reset_weights()
 
     def set_target(self, new_target, reset_weights=False):
-        self._set_target(new_target=new_target, reset_weights=reset_weights)
+        self._set_target(new_target, reset_weights)
 
     def get_phase(self, include_propagation=False):
-        if include_propagation and self.propagation_kernel is not None:
-            return self.phase + self.propagation_kernel
-        return self.phase + np.pi
+        """The mask for the SLM (:786-806): ``phase + pi`` -- or, with ``include_propagation`` and a kernel, the phase at
+        the kernel's depth (without the pi, as in the reference)."""
+        with_kernel = include_propagation and self.propagation_kernel is not None
+        return self.phase + (self.propagation_kernel if with_kernel else np.pi)
 
     def get_amp(self):
-        return self.amp
+        amplitude = self.amp
+        return amplitude
 
     def set_weights(self, new_weights):
         if tuple(np.shape(new_weights)) != tuple(self.target.shape):
@@ -401,47 +419,67 @@ class Hologram:
 
     def get_farfield(self, shape=None, propagation_kernel=None, affine=None, get=True):
         """
-        Complex DFT farfield of the current phase at an arbitrary power-of-two ``shape``, optionally at
-        another depth (``propagation_kernel``) and resampled by ``affine`` (_hologram.py:853-931; the
-        call SimulatedCamera makes per frame).  One engine per requested shape is kept alive, so
-        repeated calls cost two kernels plus the read-back.  The affine step is the reference's own
-        host call (``scipy.ndimage.affine_transform``, order 3, constant 0) on the downloaded field.
+        Complex DFT farfield of the current phase at an arbitrary ``shape``, optionally at another depth
+        (``propagation_kernel``) and resampled by ``affine`` (_hologram.py:853-931; the call SimulatedCamera makes per
+        frame, hardware/cameras/simulated.py:370).  One engine per requested shape is kept alive; a call costs two kernels
+        plus what the caller asks to move:
+
+        * the phase goes engine -> engine on the device when this hologram's engine holds it (``hgs_copy_phase``);
+        * source amplitude and kernel are re-sent only when they are other objects than last time; no kernel = none sent;
+        * ``get=False`` returns the field as a torch tensor on the GPU (the reference: a CuPy array), ``get=True`` a NumPy
+          array.  The affine step is the reference's host call (``scipy.ndimage.affine_transform``, order 3, constant 0).
         """
         self._flush_populate()
-        if shape is None:
-            shape = self.shape
-        if len(shape) == 1:
-            shape = self.slm_shape
+        shape = self.shape if shape is None else self.slm_shape if len(shape) == 1 else shape
         shape = (int(shape[0]), int(shape[1]))
-        if propagation_kernel is None:
-            propagation_kernel = self.propagation_kernel
-        if propagation_kernel is None:
-            propagation_kernel = 0
+        for fallback in (self.propagation_kernel, 0):
+            propagation_kernel = fallback if propagation_kernel is None else propagation_kernel
         engines = self.__dict__.setdefault("_ff_engines", {})
-        e = engines.get(shape)
-        if e is None:
-            e = engines[shape] = Engine(shape, self.slm_shape, self.dtype, batch=1)
-        if np.isscalar(self.amp):
-            e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
-        else:
-            e.set(L.AMP, self.amp)
+        slot = engines.get(shape)
+        if slot is None:
+            slot = engines[shape] = {"engine": Engine(shape, self.slm_shape, self.dtype, batch=1), "amp": None, "kernel": None}
+        e = slot["engine"]
+        if slot["amp"] is None or slot["amp"] is not self.amp:
+            if np.isscalar(self.amp):
+                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
+            else:
+                e.set(L.AMP, self.amp)
+            slot["amp"] = self.amp
         if np.isscalar(propagation_kernel):
-            kern = np.full(self.slm_shape, propagation_kernel, dtype=self.dtype)
-        else:
+            if propagation_kernel == 0:
+                if slot["kernel"] is not False:
+                    e.clear_propagation_kernel()
+                    slot["kernel"] = False
+            else:
+                e.set(L.PROP_KERNEL, np.full(self.slm_shape, propagation_kernel, dtype=self.dtype))
+                slot["kernel"] = None
+        elif slot["kernel"] is not propagation_kernel:
             kern = np.ascontiguousarray(propagation_kernel, dtype=self.dtype)
             if kern.shape != tuple(self.slm_shape):
                 raise ValueError(f"propagation_kernel must have the SLM shape {tuple(self.slm_shape)}")
-        e.set(L.PROP_KERNEL, kern)
-        e.set(L.PHASE, self.phase)
-        e.nearfield2farfield(store_phase_ff=True)
-        ff = e.get(L.FARFIELD)[0]
-        if shape == tuple(self.shape) and self._host.get("amp_ff") is not None:
+            e.set(L.PROP_KERNEL, kern)
+            slot["kernel"] = propagation_kernel
+        if self._engine is not None:
+            e.copy_phase_from(self._get_engine())            # (pending host edits of the phase go up first)
+        elif _is_device_tensor(self._host.get("phase")):
+            e.set_tensor(L.PHASE, self._host["phase"])
+        else:
+            e.set(L.PHASE, self.phase)
+        refresh = shape == tuple(self.shape) and self._host.get("amp_ff") is not None
+        e.nearfield2farfield(store_phase_ff=refresh)
+        if refresh:
             self.amp_ff = e.get(L.AMP_FF)[0]
             self.phase_ff = e.get(L.PHASE_FF)[0]
+        if not get and affine is None:
+            return e.get_tensor(L.FARFIELD)[0]
+        ff = e.get(L.FARFIELD)[0]
         if affine is not None:
             from scipy.ndimage import affine_transform
             ff = affine_transform(input=ff, matrix=affine["M"], offset=affine["b"], output_shape=shape, order=3,
                                   mode="constant", cval=0)
+        if not get:
+            import torch
+            return torch.from_numpy(ff).cuda()
         return ff
 
     # ---- statistics bookkeeping (_stats.py:118-223) ---------------------------------------------------------
@@ -787,36 +825,122 @@ class Hologram:
 
 class FeedbackHologram(Hologram):
     """
-    Reference: ``FeedbackHologram`` (_feedback.py:5-411).  Only the constructor plumbing
-    (shape/amp from a cameraslm or SLM, :75-100) and the "computational" weight update are on the
-    optimize() path; camera feedback (``measure``, ``ijcam_to_knmslm``) needs hardware and raises.
+    Reference: ``FeedbackHologram`` (_feedback.py:5-411).  On the optimize() path: the constructor plumbing (shape / amp
+    from a cameraslm or SLM), camera-basis targets (``target_ij``, :meth:`update_target`, :meth:`ijcam_to_knmslm` --
+    host-side set-up through the Fourier calibration) and the "computational" weight update.  Acquiring camera frames
+    (:meth:`measure`, the "experimental" feedback modes) needs hardware and raises.
     """
 
     def __init__(self, shape, target_ij=None, cameraslm=None, null_region=None,
                  null_region_radius_frac=None, **kwargs):
+        # `cameraslm` may be a FourierSLM (kept: its calibrations are used later) or a bare SLM (only its shape and
+        # source amplitude are read, then it is dropped); without either, `amp` / `slm_shape` come from the keywords
         self.cameraslm = cameraslm
-        if self.cameraslm is not None:
-            if hasattr(self.cameraslm, "slm") and hasattr(self.cameraslm.slm, "_get_source_amplitude"):
-                amp = self.cameraslm.slm._get_source_amplitude()
-                slm_shape = self.cameraslm.slm.shape
-            elif hasattr(self.cameraslm, "_get_source_amplitude"):
-                amp = self.cameraslm._get_source_amplitude()
-                slm_shape = self.cameraslm.shape
-                self.cameraslm = None
-            else:
+        geometry = None
+        if cameraslm is not None:
+            slm = getattr(cameraslm, "slm", cameraslm)
+            if not (hasattr(slm, "_get_source_amplitude") and hasattr(slm, "shape")):
                 raise ValueError("Expected a CameraSLM or SLM to be passed to cameraslm.")
+            if slm is cameraslm:
+                self.cameraslm = None
+            amp, geometry = slm._get_source_amplitude(), slm.shape
         else:
             amp = kwargs.pop("amp", None)
-            slm_shape = None
-        if "slm_shape" not in kwargs:
-            kwargs["slm_shape"] = slm_shape
+        kwargs.setdefault("slm_shape", geometry)
         super().__init__(target=shape, amp=amp, **kwargs)
-        self.img_ij = None
-        self.img_knm = None
-        if target_ij is not None:
-            raise NotImplementedError("camera-basis targets (target_ij) need Fourier calibration hardware")
-        self.target_ij = None
+
+        self.img_ij = self.img_knm = None
+        self.target_ij = None if target_ij is None else np.asarray(target_ij).astype(self.dtype)
         self._cam_points = None
+        if self._has_fourier(self.cameraslm):
+            self._cam_points = self._camera_outline_knm()
+            if target_ij is not None:
+                self.update_target(target_ij, null_region, null_region_radius_frac, reset_weights=True)
+
+    @staticmethod
+    def _has_fourier(cameraslm):
+        return cameraslm is not None and "fourier" in getattr(cameraslm, "calibrations", {})
+
+    def _camera_outline_knm(self):
+        """The sensor's corner pixels (closed loop, five points) in "knm": where the camera looks in the computational
+        grid (_feedback.py:108-125; the reference keeps it for plotting)."""
+        h, w = self.cameraslm.cam.shape
+        loop_ij = np.array([[0, 0, w - 1, w - 1, 0], [0, h - 1, h - 1, 0, 0]], dtype=float)
+        return toolbox.convert_vector(self.cameraslm.ijcam_to_kxyslm(loop_ij), "kxy", "knm", self.cameraslm.slm, self.shape)
+
+    def _knm_to_ij_affine(self):
+        """
+        ``(A, c)`` with ``ij = A @ knm + c`` (column vectors, x first): the scaling "knm" -> "kxy" of this hologram's
+        grid followed by the Fourier calibration ``ij = M (kxy - a) + b``.
+        """
+        slm = self.cameraslm.slm
+        step = np.ravel(toolbox.convert_vector((1, 1), "knm", "kxy", slm, self.shape)
+                        - toolbox.convert_vector((0, 0), "knm", "kxy", slm, self.shape))
+        scale = np.diag(step)
+        centre = np.array([[self.shape[1] / 2], [self.shape[0] / 2]], dtype=float)
+        cal = self.cameraslm.calibrations["fourier"]
+        M = np.array(cal["M"], dtype=float)
+        shift = np.array(cal["b"], dtype=float).reshape(2, 1)
+        if "a" in cal:
+            shift = shift - M @ np.array(cal["a"], dtype=float).reshape(2, 1)
+        return M @ scale, M @ (scale @ -centre) + shift
+
+    def ijcam_to_knmslm(self, img, out=None, blur_ij=None, order=3):
+        """
+        A camera image resampled onto the computational grid (_feedback.py:141-233): amplitude |img| (after an optional
+        Gaussian blur of ``blur_ij`` camera pixels, default the ``"blur_ij"`` flag or none) interpolated at the camera
+        position of every "knm" pixel with splines of ``order``, NaN where the camera does not look, unit L2 norm over the
+        defined pixels.  Host-side set-up (scipy), like the reference without CuPy.
+        """
+        from scipy import ndimage
+        if self.cameraslm is None:
+            raise RuntimeError("Cannot use ijcam_to_knmslm without the calibrations in a cameraslm.")
+        if not self._has_fourier(self.cameraslm):
+            raise RuntimeError("ijcam_to_knmslm requires a Fourier calibration.")
+        A, c = self._knm_to_ij_affine()
+        swap = np.array([[0.0, 1.0], [1.0, 0.0]])          # array axes are (row, column) = (y, x)
+        width = self.flags.get("blur_ij", 0) if blur_ij is None else blur_ij
+        if width > 0:
+            img = ndimage.gaussian_filter(img, (width, width), output=img, truncate=2)
+        source = np.abs(np.array(img, dtype=self.dtype))
+        grid = ndimage.affine_transform(source, swap @ A @ swap, offset=np.ravel(swap @ c), output_shape=self.shape,
+                                        order=order, output=out, mode="constant", cval=np.nan)
+        np.abs(grid, out=grid)
+        power = _norm(grid)
+        if power == 0:
+            raise ValueError("No power in hologram. Maybe target_ij is out of range of knm space? Check transformations.")
+        grid *= 1 / power
+        return grid
+
+    def update_target(self, new_target_ij, null_region=None, null_region_radius_frac=None, reset_weights=False):
+        """
+        A new camera-basis target (_feedback.py:277-329): resampled to "knm" with nearest-neighbour lookup (no NaN
+        bleeding).  Pixels the camera cannot see are undefined; they become zero (dark) inside the null region and stay
+        NaN (free, MRAF noise region) elsewhere.  The null region is ``null_region`` plus everything beyond
+        ``null_region_radius_frac`` of the grid's half-extent -- but with the fraction absent or >= 1 the reference zeroes
+        EVERY undefined pixel and ignores ``null_region``; kept.
+        """
+        self.target_ij = np.asarray(new_target_ij).astype(self.dtype)
+        raster = self.ijcam_to_knmslm(new_target_ij, order=0)
+        unseen = np.isnan(raster)
+        fraction = 1 if null_region_radius_frac is None else null_region_radius_frac
+        if fraction >= 1:
+            raster[unseen] = 0
+        else:
+            if null_region is None:
+                null_region = np.zeros(self.shape, dtype=bool)
+            rows, cols = np.shape(null_region)
+            u, v = np.meshgrid(np.linspace(-1, 1, cols), np.linspace(-1, 1, rows))
+            null_region[u * u + v * v > fraction ** 2] = True          # (the caller's array is extended, as in the reference)
+            raster[unseen & np.asarray(null_region, dtype=bool)] = 0
+        if not reset_weights:
+            self._materialise_weights()
+            self._weights_reset = False
+        self.target = raster
+        if self._engine is not None:
+            self._upload_target(self._engine)
+        if reset_weights:
+            self.reset_weights()
 
     def measure(self, basis="ij"):
         raise NotImplementedError("measure() needs camera hardware and is outside this build")
@@ -854,13 +978,13 @@ class SpotHologram(FeedbackHologram):
 
         super().__init__(shape, target_ij=None, cameraslm=cameraslm, **kwargs)
 
+        if basis == "ij" and null_region is not None:
+            # a region drawn on the camera: resampled like a target (nearest neighbour); what the camera cannot see is
+            # NaN there and counts as null too (_spots.py:1352-1357)
+            self.null_region_knm = self.ijcam_to_knmslm(null_region, order=0) != 0
         if null_region_radius_frac is not None:
             self._null_outside_radius(null_region_radius_frac)
         self.set_target(reset_weights=True)
-
-    @staticmethod
-    def _has_fourier(cameraslm):
-        return cameraslm is not None and "fourier" in getattr(cameraslm, "calibrations", {})
 
     def _resolve_bases(self, vectors, basis, cameraslm, shape):
         """``spot_knm`` / ``spot_kxy`` / ``spot_ij`` from vectors given in ``basis``; what cannot be derived (no SLM
@@ -959,66 +1083,82 @@ class SpotHologram(FeedbackHologram):
     @staticmethod
     def make_rectangular_array(shape, array_shape, array_pitch, array_center=None, basis="knm",
                                orientation_check=False, **kwargs):
-        """_spots.py:1387-1488."""
-        if isinstance(array_shape, toolbox.REAL_TYPES):
-            array_shape = (int(array_shape), int(array_shape))
-        if isinstance(array_pitch, toolbox.REAL_TYPES):
-            array_pitch = (array_pitch, array_pitch)
+        """
+        A rectangular lattice of spots (_spots.py:1387-1488): ``array_shape`` = (columns, rows) spots ``array_pitch`` apart
+        around ``array_center`` (default: the zero order of ``basis``), listed row by row; ``orientation_check`` drops the
+        last two so that the pattern shows which way is up.
+        """
+        def pair(value, cast=lambda v: v):
+            return (cast(value), cast(value)) if isinstance(value, toolbox.REAL_TYPES) else value
+
+        (nx, ny), (px, py) = pair(array_shape, int), pair(array_pitch)
         if array_center is None:
-            if basis == "knm":
-                array_center = (shape[1] / 2.0, shape[0] / 2.0)
-            elif basis == "kxy":
-                array_center = (0, 0)
-            elif basis == "ij":
+            if basis == "ij":
                 cameraslm = kwargs.get("cameraslm", None)
                 assert cameraslm is not None, "We need an cameraslm to interpret ij."
                 array_center = toolbox.convert_vector((0, 0), "kxy", "ij", cameraslm)
-        x_edge = (np.arange(array_shape[0]) - (array_shape[0] - 1) / 2.0) * array_pitch[0] + array_center[0]
-        y_edge = (np.arange(array_shape[1]) - (array_shape[1] - 1) / 2.0) * array_pitch[1] + array_center[1]
-        x_grid, y_grid = np.meshgrid(x_edge, y_edge, sparse=False, indexing="xy")
-        x_list, y_list = x_grid.ravel(), y_grid.ravel()
-        if orientation_check and len(x_list) > 2:
-            x_list, y_list = x_list[:-2], y_list[:-2]
-        return SpotHologram(shape, np.vstack((x_list, y_list)), basis=basis, spot_amp=None, **kwargs)
+            else:
+                array_center = {"knm": (shape[1] / 2.0, shape[0] / 2.0), "kxy": (0, 0)}.get(basis)
+        xs = (np.arange(nx) - (nx - 1) / 2.0) * px + array_center[0]
+        ys = (np.arange(ny) - (ny - 1) / 2.0) * py + array_center[1]
+        lattice = np.vstack([axis.ravel() for axis in np.meshgrid(xs, ys)])
+        if orientation_check and lattice.shape[1] > 2:
+            lattice = lattice[:, :-2]
+        return SpotHologram(shape, lattice, basis=basis, spot_amp=None, **kwargs)
 
     def _set_target_spots(self, reset_weights=False):
-        """_spots.py:1490-1546."""
-        self.spot_knm_rounded = np.rint(self.spot_knm).astype(int)
-        self.spot_kxy_rounded = None
-        self.spot_ij_rounded = None
+        """
+        The target raster of the spot list (_spots.py:1490-1546): ``spot_amp`` at the rounded "knm" positions, zero
+        elsewhere -- or, with null points, NaN (free) elsewhere except the null region and a disk of the null radius around
+        every null point AND every spot (zero); unit norm.  Also refreshes the rounded positions in the other bases.
+        """
+        nearest = self.spot_knm_rounded = np.rint(self.spot_knm).astype(int)
+        self.spot_kxy_rounded = self.spot_ij_rounded = None
         if self.cameraslm is not None:
-            self.spot_kxy_rounded = toolbox.convert_vector(
-                self.spot_knm_rounded, "knm", "kxy", self.cameraslm.slm, self.shape)
-            if "fourier" in getattr(self.cameraslm, "calibrations", {}):
+            self.spot_kxy_rounded = toolbox.convert_vector(nearest, "knm", "kxy", self.cameraslm.slm, self.shape)
+            if self._has_fourier(self.cameraslm):
                 self.spot_ij_rounded = self.cameraslm.kxyslm_to_ijcam(self.spot_kxy_rounded)
-        target = np.zeros(self.shape, dtype=self.dtype)
-        if self.null_knm is not None:
-            target.fill(np.nan)
+        if self.null_knm is None:
+            raster = np.zeros(self.shape, dtype=self.dtype)
+        else:
+            raster = np.full(self.shape, np.nan, dtype=self.dtype)
             if self.null_region_knm is not None:
-                target[np.asarray(self.null_region_knm, dtype=bool)] = 0
-            all_spots = np.hstack((self.null_knm, self.spot_knm))
-            w = int(2 * self.null_radius_knm + 1)
-            for ii in range(all_spots.shape[1]):
-                toolbox.imprint_disk_zero(target, np.rint(all_spots[0, ii]), np.rint(all_spots[1, ii]), w)
-        target[self.spot_knm_rounded[1, :], self.spot_knm_rounded[0, :]] = self.spot_amp
-        target /= _norm(target)
+                raster[np.asarray(self.null_region_knm, dtype=bool)] = 0
+            diameter = int(2 * self.null_radius_knm + 1)
+            for x, y in np.rint(np.hstack((self.null_knm, self.spot_knm))).T:
+                toolbox.imprint_disk_zero(raster, x, y, diameter)
+        raster[nearest[1], nearest[0]] = self.spot_amp
+        raster /= _norm(raster)
         if not reset_weights:
             self._materialise_weights()
             self._weights_reset = False
-        self.target = target
+        self.target = raster
+        self._spot_raster = True           # the raster IS the spot list (cleared by any other assignment of .target)
         if self._engine is not None:
-            self._upload_target(self._engine)
             self._engine_setup(self._engine)
-        if reset_weights:
-            self.reset_weights()
+        self._target_changed(reset_weights)
 
     def set_target(self, reset_weights=False, plot=False):
-        self._set_target_spots(reset_weights=reset_weights)
+        self._set_target_spots(reset_weights)
+
+    # assigning ``target`` by hand (or through the base class's _set_target) makes it an arbitrary raster again
+    @property
+    def target(self):
+        return self.__dict__.get("_target")
+
+    @target.setter
+    def target(self, value):
+        Hologram.target.fset(self, value)
+        self._spot_raster = False
+
+    def _sparse_target(self):
+        """True when the target is exactly what _set_target_spots laid out without null points: zeros and the spot list."""
+        return self.__dict__.get("_spot_raster", False) and self.null_knm is None
 
     def _upload_target(self, e):
-        """One value per spot instead of the padded raster (hgs_set_array_sparse) -- unless null points give the
-        target a NaN background."""
-        if self.null_knm is not None:
+        """One value per spot instead of the padded raster (hgs_set_array_sparse) -- unless null points give the target
+        a NaN background, or somebody replaced the raster (then it goes up whole, like any Hologram's)."""
+        if not self._sparse_target():
             return super()._upload_target(e)
         ky, kx = self.spot_knm_rounded[1], self.spot_knm_rounded[0]
         e.set_sparse(L.TARGET, self.spot_knm_rounded, self.target[ky, kx])
@@ -1034,7 +1174,7 @@ class SpotHologram(FeedbackHologram):
     def _mraf_enabled(self):
         """NaN in the target (_mraf_helper_routines :1498) without a 67 MB reduction: the raster is zeros, the spot
         amplitudes and -- only with null points -- a NaN background."""
-        if self.null_knm is not None or not hasattr(self, "spot_knm_rounded"):
+        if not self._sparse_target():
             return super()._mraf_enabled()
         return bool(np.isnan(np.sum(self.target[self.spot_knm_rounded[1], self.spot_knm_rounded[0]])))
 
@@ -1095,64 +1235,87 @@ class CompressedSpotHologram(FeedbackHologram):
     def __init__(self, spot_vectors, basis="kxy", spot_amp=None, cameraslm=None, cuda=False, **kwargs):
         if cameraslm is None:
             raise ValueError("cameraslm must be passed.")
-        spot_vectors = toolbox.format_vectors(spot_vectors)
-        D, N = spot_vectors.shape
-        if spot_amp is not None:
-            self.spot_amp = np.array(spot_amp)
-            if self.spot_amp.size != N:
-                raise ValueError(f"spot_amp (length {self.spot_amp.size}) must have the same length as the provided spots ({N}).")
-        else:
-            self.spot_amp = np.full(N, 1.0 / np.sqrt(N))
+        vectors = toolbox.format_vectors(spot_vectors)
+        rank, count = vectors.shape
+        self.spot_amp = np.full(count, 1.0 / np.sqrt(count)) if spot_amp is None else np.array(spot_amp)
+        if self.spot_amp.size != count:
+            raise ValueError(f"spot_amp (length {self.spot_amp.size}) must have the same length as the provided spots ({count}).")
 
-        if isinstance(basis, str):
-            self.zernike_basis = toolbox.zernike_indices_parse(None, D)
-        else:
-            self.zernike_basis = np.ravel(basis)
-            basis = "zernike"
-            if len(self.zernike_basis) != D:
-                raise ValueError(f"zernike_basis (length {len(self.zernike_basis)}) must have the same "
-                                 f"dimension as the provided spots ({D}).")
-            if 0 in self.zernike_basis:
-                warnings.warn("Found ANSI index '0' (Zernike piston) in the zernike_basis; this is not necessary.")
-        if not np.any(self.zernike_basis == 2) or not np.any(self.zernike_basis == 1):
-            raise ValueError("Compressed basis must include x, y (Zernike ANSI indices 2, 1)")
-        cart = [int(np.argwhere(self.zernike_basis == 2)[0][0]), int(np.argwhere(self.zernike_basis == 1)[0][0])]
-        if np.any(self.zernike_basis == 4):
-            cart.append(int(np.argwhere(self.zernike_basis == 4)[0][0]))
-        self.zernike_basis_cartesian = np.array(cart)
-
-        if basis == "zernike":
-            self.spot_zernike = np.array(spot_vectors, dtype=float)
-            _, self.spot_kxy = toolbox.convert_vector_zernike(spot_vectors[self.zernike_basis_cartesian, :],
-                                                              "zernike", cameraslm)
-        elif basis in ("kxy", "norm"):
-            self.spot_zernike, self.spot_kxy = toolbox.convert_vector_zernike(spot_vectors, "kxy", cameraslm)
-        else:
-            raise NotImplementedError(f"basis '{basis}' needs a Fourier-calibrated camera and is outside this build")
-        self.spot_ij = None
-        self.spot_integration_width_ij = None
-
-        slm = cameraslm.slm if hasattr(cameraslm, "slm") else cameraslm
-        kmax = 1. / np.min(slm.pitch) / 2.
-        if np.any(np.abs(self.spot_kxy[:2, :]) > 1.1 * kmax):
+        units = self._parse_basis(basis, rank)
+        self._resolve_vectors(vectors, units, cameraslm)
+        slm = getattr(cameraslm, "slm", cameraslm)
+        if np.any(np.abs(self.spot_kxy[:2]) > 1.1 * (0.5 / np.min(slm.pitch))):      # 10 % beyond the Nyquist angle
             raise ValueError("Spots laterally outside the bounds of the farfield")
+        self._camera_geometry(cameraslm)
 
+        # the base classes work on a padded grid; until the N-vector target exists they see a placeholder (_set_target)
         self._compressed_ready = False
-        super().__init__(shape=None, target_ij=None, cameraslm=cameraslm, **kwargs)
-        self.shape = self.slm_shape
-        self.set_target(new_target=self.spot_amp, reset_weights=True)
+        FeedbackHologram.__init__(self, None, None, cameraslm, **kwargs)
+        self.shape = self.slm_shape                      # no DFT grid: the "shape" of this hologram is the SLM's
+        self.set_target(self.spot_amp, reset_weights=True)
         # quirk: the reference ends its constructor with reset() (_spots.py:495), which replaces any
         # phase passed by the caller with a fresh random one; reproduce, then honour reset_phase().
         self.reset()
-        self.external_spot_amp = np.ones(self.target.shape)
-        self.cuda = False
-        xg, yg = toolbox.process_grid(slm)
-        scale = slm.get_source_zernike_scaling()
-        sx, sy = (scale, scale) if np.isscalar(scale) else (scale[0], scale[1])
-        self._xg = np.asarray(xg, dtype=float) * sx
-        self._yg = np.asarray(yg, dtype=float) * sy
+        self.external_spot_amp, self.cuda = np.ones(self.target.shape), False
+        # pixel coordinates in the units the Zernike polynomials are defined on (unit disk = the source radius)
+        stretch = slm.get_source_zernike_scaling()
+        stretch = (stretch, stretch) if np.isscalar(stretch) else tuple(stretch)
+        self._xg, self._yg = (np.asarray(axis, dtype=float) * k for axis, k in zip(toolbox.process_grid(slm), stretch))
         self._spot_zernike_cached = None
         self._compressed_ready = True
+
+    def _parse_basis(self, basis, rank):
+        """
+        ``zernike_basis`` (ANSI indices of the ``rank`` coefficient rows) and where in it the Cartesian terms sit.  A string
+        names the units of the vectors and implies the default basis [2, 1, 4, 3, 5, ...]; a list of indices IS the basis
+        and the vectors are Zernike coefficients.  Returns the units.  (_spots.py:366-396)
+        """
+        if isinstance(basis, str):
+            self.zernike_basis, units = toolbox.zernike_indices_parse(None, rank), basis
+        else:
+            self.zernike_basis, units = np.ravel(basis), "zernike"
+            if len(self.zernike_basis) != rank:
+                raise ValueError(f"zernike_basis (length {len(self.zernike_basis)}) must have the same "
+                                 f"dimension as the provided spots ({rank}).")
+            if 0 in self.zernike_basis:
+                warnings.warn("Found ANSI index '0' (Zernike piston) in the zernike_basis; this is not necessary.")
+        where = {int(j): k for k, j in reversed(list(enumerate(self.zernike_basis)))}       # first occurrence wins
+        if 2 not in where or 1 not in where:
+            raise ValueError("Compressed basis must include x, y (Zernike ANSI indices 2, 1)")
+        self.zernike_basis_cartesian = np.array([where[j] for j in (2, 1, 4) if j in where])
+        return units
+
+    def _resolve_vectors(self, vectors, units, cameraslm):
+        """``spot_zernike`` (what the kernels are built from) and ``spot_kxy`` (tilts and, if present, focus)."""
+        if units == "zernike":
+            self.spot_zernike = np.array(vectors, dtype=float)
+            _, self.spot_kxy = toolbox.convert_vector_zernike(vectors[self.zernike_basis_cartesian], "zernike", cameraslm)
+            return
+        if units == "ij":          # camera pixels (and pixel depth): through the Fourier calibration
+            if not self._has_fourier(cameraslm):
+                raise RuntimeError("Fourier calibration must exist to interpret the 'ij' basis.")
+            vectors, units = cameraslm.ijcam_to_kxyslm(vectors), "kxy"
+        if units not in ("kxy", "norm"):
+            raise NotImplementedError(f"basis '{units}' is not supported; use 'kxy', 'ij' or Zernike indices")
+        self.spot_zernike, self.spot_kxy = toolbox.convert_vector_zernike(vectors, "kxy", cameraslm)
+
+    def _camera_geometry(self, cameraslm):
+        """Where the spots land on the camera, with a Fourier calibration at hand (_spots.py:433-483): ``spot_ij``, the odd
+        integration width (two point-spread radii, at least 3, at most 2/3 of the closest pair) and the sensor bounds."""
+        self.spot_ij = self.spot_integration_width_ij = None
+        cam = getattr(cameraslm, "cam", None)
+        if not self._has_fourier(cameraslm) or cam is None:
+            return
+        self.spot_ij = cameraslm.kxyslm_to_ijcam(self.spot_kxy)
+        psf = toolbox.convert_radius(np.mean(cameraslm.slm.get_spot_radius_kxy()), "kxy", "ij", cameraslm)
+        psf = 0 if np.isnan(psf) else psf
+        ceiling = max(toolbox.smallest_distance(self.spot_ij[:2]) / 1.5, 3)
+        if psf > ceiling:
+            warnings.warn("The expected camera spot point-spread-function is too large. Clipping to a smaller one.")
+        width = self.spot_integration_width_ij = int(2 * np.floor(np.clip(2 * psf, 3, ceiling) / 2) + 1)
+        i, j = self.spot_ij[0], self.spot_ij[1]
+        if np.any((i < width / 2) | (j < width / 2) | (i >= cam.shape[1] - width / 2) | (j >= cam.shape[0] - width / 2)):
+            raise ValueError("Spots outside camera bounds!\nSpots:\n{}\nBounds: {}".format(self.spot_ij, cam.shape))
 
     def __len__(self):
         return self.spot_amp.size
@@ -1352,18 +1515,17 @@ class MultiplaneHologram(Hologram):
             h.flags.update(self.flags)
 
     def reset(self, reset_phase=True, reset_flags=False):
-        if getattr(self, "_mp_ready", False):
-            if reset_phase or self._host.get("phase") is None:
-                self.reset_phase()
-            self.iter = 0
-            self.stats = {"method": [], "flags": {}, "stats": {}}
-            if reset_flags:
-                self.flags = {"method": ""}
-            for h in self.holograms:
-                h.reset(reset_phase=False, reset_flags=reset_flags)
-                h.phase = self._host["phase"]
-        else:
-            super().reset(reset_phase, reset_flags)
+        """The parent keeps the iteration counter, history and flags; every child starts over on the shared phase."""
+        if not getattr(self, "_mp_ready", False):          # (still inside Hologram.__init__)
+            return super().reset(reset_phase, reset_flags)
+        if reset_phase or self._host.get("phase") is None:
+            self.reset_phase()
+        self.iter, self.stats = 0, dict(method=[], flags={}, stats={})
+        if reset_flags:
+            self.flags = dict(method="")
+        for child in self.holograms:
+            child.reset(reset_phase=False, reset_flags=reset_flags)
+            child.phase = self._host["phase"]
 
     def reset_weights(self):
         if getattr(self, "_mp_ready", False):

@@ -218,21 +218,16 @@ def zernike_cartesian(j):
 
 def zernike_indices_parse(indices=None, D=None):
     """Default bases [2,1], [2,1,4], [2,1,4,3,5,...]  (phase._zernike_indices_parse, phase.py:923-961)."""
+    if indices is None and D is None:
+        raise ValueError("Either dimension or indices must be defined.")
     if indices is None:
-        if D is None:
-            raise ValueError("Either dimension or indices must be defined.")
-        if D == 2:
-            indices = np.array([2, 1])
-        elif D == 3:
-            indices = np.array([2, 1, 4])
-        elif D == 4:
-            indices = np.array([2, 1, 4, 3])
-        else:
-            indices = np.hstack((np.array([2, 1, 4, 3]), np.arange(5, D + 1)))
-    indices = np.ravel(indices)
-    if D is not None and len(indices) != D:
-        raise ValueError(f"Expected data (dimension {D}) to have common size with indices (length {len(indices)}).")
-    return indices
+        # tilts first (x before y), then focus, then ANSI order; a prefix of that for D = 2 .. 4
+        ladder = [2, 1, 4, 3] + list(range(5, D + 1))
+        indices = ladder[:D] if D >= 2 else ladder
+    chosen = np.ravel(np.array(indices))
+    if D is not None and len(chosen) != D:
+        raise ValueError(f"Expected data (dimension {D}) to have common size with indices (length {len(chosen)}).")
+    return chosen
 
 
 def zernike_monomial_weights(indices, weights):
@@ -288,13 +283,9 @@ def blaze(grid, vector):
     """2 pi (kx x + ky y) on normalised grids (toolbox.phase.blaze, phase.py:20-75, same branch structure)."""
     x_grid, y_grid = process_grid(grid)
     vector = np.asarray(vector, dtype=np.float64)      # float64 scalars promote the products to float64 (NEP 50)
-    if vector[0] == 0 and vector[1] == 0:
-        return np.zeros_like(x_grid)
-    if vector[1] == 0:
-        return (2 * np.pi * vector[0]) * x_grid
-    if vector[0] == 0:
-        return (2 * np.pi * vector[1]) * y_grid
-    return (2 * np.pi * vector[0]) * x_grid + (2 * np.pi * vector[1]) * y_grid
+    # a vanishing component contributes no term at all (not a term of zeros: the result keeps the other term's rounding)
+    ramps = [(2 * np.pi * k) * axis for k, axis in ((vector[0], x_grid), (vector[1], y_grid)) if k != 0]
+    return ramps[0] + ramps[1] if len(ramps) == 2 else ramps[0] if ramps else np.zeros_like(x_grid)
 
 
 def lens(grid, f):
@@ -305,19 +296,18 @@ def lens(grid, f):
         raise ValueError(f"Expected two terms in focal list. Found {f}.")
     if np.any(f == 0):
         raise ValueError(f"Cannot interpret a focal length of zero. Found {f}.")
-    if np.isfinite(f[0]) and np.isfinite(f[1]):
-        return (np.pi / f[0]) * np.square(x_grid) + (np.pi / f[1]) * np.square(y_grid)
-    if np.isfinite(f[1]):
-        return (np.pi / f[1]) * np.square(y_grid)
-    return np.zeros_like(x_grid)       # (the reference's x-only branch is unreachable, :447)
+    x_curved, y_curved = bool(np.isfinite(f[0])), bool(np.isfinite(f[1]))
+    if not y_curved:                   # (flat in y: the reference's x-only branch is unreachable, :447 -- no lens at all)
+        return np.zeros_like(x_grid)
+    bowl = (np.pi / f[1]) * np.square(y_grid)
+    return (np.pi / f[0]) * np.square(x_grid) + bowl if x_curved else bowl
 
 
 def process_grid(grid):
     """(x_grid, y_grid) from a cameraslm, an SLM or a pair of arrays (toolbox._process_grid)."""
-    if hasattr(grid, "slm") and hasattr(grid, "cam"):
-        grid = grid.slm
-    if hasattr(grid, "grid"):
-        grid = grid.grid
+    for attribute in ("slm", "grid"):          # FourierSLM -> its SLM -> the SLM's coordinate arrays
+        if attribute == "grid" or hasattr(grid, "cam"):
+            grid = getattr(grid, attribute, grid)
     return grid[0], grid[1]
 
 

@@ -111,3 +111,108 @@ def test_wavefront_calibration_reoptimisation_pattern():
         worst = max(worst, e, rel_l2(h.farfield, o.farfield))
     report("wavefront-calibration re-optimisation pattern (D=10, 4 rounds)", worst=worst)
     assert worst < 3e-5
+
+
+# ---- camera-basis targets (FeedbackHologram target_ij, _feedback.py:75-330) -----------------------------------------------
+def _same_raster(a, b):
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
+def test_camera_basis_targets_match_reference():
+    """
+    tests/golden/feedback_ij.npz (recorded from the reference): a camera image turned into the "knm" target by the
+    constructor, ``ijcam_to_knmslm`` with cubic / nearest interpolation and a blur, ``update_target`` with a null region
+    and a radius fraction (NaN = free where the camera cannot see), the sensor outline, the camera-drawn null region of an
+    ij-basis SpotHologram -- all host-side set-up, bit for bit; and the depth row of the Fourier calibration.
+    """
+    from slmsuite_amd.holography.algorithms import FeedbackHologram
+    meta, gold = load_golden("feedback_ij")
+    fs = make_fs(meta)
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    phase0 = synth.seed_phase(meta["seed"], slm)
+    h = FeedbackHologram(shape, target_ij=gold["img"].copy(), cameraslm=fs, phase=phase0.copy())
+    _same_raster(h.target, gold["target_ctor"])
+    assert not np.isnan(h.target).any() and not h._mraf_enabled()
+    np.testing.assert_allclose(h._cam_points, gold["cam_points"], rtol=1e-13)
+    _same_raster(h.ijcam_to_knmslm(gold["img"].copy()), gold["knm_cubic"])
+    _same_raster(h.ijcam_to_knmslm(gold["img"].copy(), blur_ij=2), gold["knm_blur"])
+    _same_raster(h.ijcam_to_knmslm(gold["img"].copy(), order=0), gold["knm_nearest"])
+    h.flags["blur_ij"] = 2                                                # the flag is the default of the argument
+    _same_raster(h.ijcam_to_knmslm(gold["img"].copy()), gold["knm_blur"])
+    np.testing.assert_array_equal(h.target_ij, gold["img"])
+
+    h2 = FeedbackHologram(shape, target_ij=gold["img"].copy(), cameraslm=fs, phase=phase0.copy(), null_region_radius_frac=0.6)
+    _same_raster(h2.target, gold["target_frac"])
+    assert h2._mraf_enabled()
+    region = np.zeros(shape, dtype=bool)
+    region[:, :20] = True
+    h2.update_target(gold["img"][::-1].copy(), null_region=region, null_region_radius_frac=0.8, reset_weights=True)
+    _same_raster(h2.target, gold["target_update"])
+    _same_raster(h2.weights, gold["weights_update"])
+    assert region[0, -1]                                                  # the caller's mask was extended, as in the reference
+
+    s = SpotHologram((256, 256), gold["spot_ij"], basis="ij", cameraslm=fs, phase=phase0.copy(), null_vectors=gold["null_ij"],
+                     null_radius=9.0, null_region=gold["cam_region"].copy())
+    _same_raster(s.target, gold["spot_target"])
+    np.testing.assert_array_equal(s.null_region_knm, gold["spot_null_region"])
+    np.testing.assert_allclose(s.null_knm, gold["spot_null_knm"], rtol=1e-13)
+    assert s.null_radius_knm == int(gold["spot_null_radius"])
+
+    with pytest.raises(RuntimeError):
+        FeedbackHologram(shape, cameraslm=SimpleFourierSLM(fs.slm)).ijcam_to_knmslm(gold["img"])
+    with pytest.raises(ValueError, match="No power"):
+        h.ijcam_to_knmslm(np.zeros((256, 256), np.float32))
+
+
+def test_depth_row_of_the_fourier_calibration():
+    meta, gold = load_golden("feedback_ij")
+    fs = make_fs(meta)
+    np.testing.assert_allclose(fs.kxyslm_to_ijcam(gold["kxy3"]), gold["ij_of_kxy3"], rtol=1e-13)
+    np.testing.assert_allclose(fs.ijcam_to_kxyslm(gold["ij3"]), gold["kxy_of_ij3"], rtol=1e-13)
+    np.testing.assert_allclose([fs.get_effective_focal_length("ij"), np.mean(fs.get_effective_focal_length("norm"))], gold["f_eff"], rtol=1e-13)
+    back = fs.ijcam_to_kxyslm(fs.kxyslm_to_ijcam(gold["kxy3"]))
+    np.testing.assert_allclose(back, gold["kxy3"], rtol=1e-12, atol=1e-18)
+    assert fs.kxyslm_to_ijcam([0.001, 0.002]).shape == (2, 1)
+    with pytest.raises(ValueError):
+        fs.kxyslm_to_ijcam(np.zeros((4, 2)))
+
+
+@pytest.mark.gpu
+def test_camera_basis_target_optimises_like_the_reference():
+    """Four bodies of WGS-Leonardo on the camera-basis target, plain and with the free (NaN) region + mraf_factor."""
+    from slmsuite_amd.holography.algorithms import FeedbackHologram
+    meta, gold = load_golden("feedback_ij")
+    fs = make_fs(meta)
+    shape, slm = tuple(meta["shape"]), tuple(meta["slm_shape"])
+    phase0 = synth.seed_phase(meta["seed"], slm)
+    h = FeedbackHologram(shape, target_ij=gold["img"].copy(), cameraslm=fs, phase=phase0.copy())
+    h.optimize("WGS-Leonardo", maxiter=4, verbose=False)
+    e1 = phase_rel_l2(h.phase, gold["phase_plain"])
+    h2 = FeedbackHologram(shape, target_ij=gold["img"].copy(), cameraslm=fs, phase=phase0.copy(), null_region_radius_frac=0.6)
+    region = np.zeros(shape, dtype=bool)
+    region[:, :20] = True
+    h2.update_target(gold["img"][::-1].copy(), null_region=region, null_region_radius_frac=0.8, reset_weights=True)
+    h2.optimize("WGS-Leonardo", maxiter=4, verbose=False, mraf_factor=0.5)
+    e2 = phase_rel_l2(h2.phase, gold["phase_mraf"])
+    report("camera-basis target WGS-Leonardo 4 it vs reference", phase_plain=e1, phase_mraf=e2)
+    # dense pixel-wise WGS on a small grid: the fixtures of the same size sit at 1e-5 .. 1e-4 after a few bodies
+    assert e1 < 3e-4 and e2 < 3e-4, (e1, e2)
+
+
+def test_compressed_spots_specified_on_the_camera():
+    """CompressedSpotHologram(basis="ij") with depth: camera pixels -> kxy (depth row through f_eff) -> Zernike
+    coefficients, back to ``spot_ij`` and the camera integration width, as the reference computes them."""
+    import warnings
+    meta, gold = load_golden("feedback_ij")
+    fs = make_fs(meta)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # (the point-spread radius of this tiny SLM exceeds the spot spacing)
+        c = CompressedSpotHologram(gold["ij3"], basis="ij", cameraslm=fs)
+    np.testing.assert_allclose(c.spot_zernike, gold["comp_zernike"], rtol=1e-13)
+    np.testing.assert_allclose(c.spot_kxy, gold["comp_kxy"], rtol=1e-13)
+    np.testing.assert_allclose(c.spot_ij, gold["comp_ij"], rtol=1e-13)
+    assert c.spot_integration_width_ij == int(gold["comp_width_ij"])
+    np.testing.assert_array_equal(c.zernike_basis, gold["comp_basis"])
+    with pytest.raises(RuntimeError):
+        CompressedSpotHologram(gold["ij3"], basis="ij", cameraslm=SimpleFourierSLM(fs.slm))

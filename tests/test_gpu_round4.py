@@ -1,0 +1,193 @@
+"""
+Round 4 (``-m gpu``): arrays that stay on the device at the class surface (hgs_set_array_device, hgs_copy_phase,
+get_farfield(get=False), torch CUDA tensors as phase), a hand-assigned raster on a SpotHologram, and the progress-bar
+path of optimize().
+"""
+import numpy as np
+import pytest
+import torch          # before the first engine: torch's HIP runtime opens the GPU first (slmsuite_amd._lib)
+
+from conftest import dispatch_of, rel_l2, phase_rel_l2, report
+from slmsuite_amd import _lib as L
+from slmsuite_amd import synth
+from slmsuite_amd.engine import Engine
+from slmsuite_amd.holography.algorithms import Hologram, SpotHologram
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_device_uploads_equal_host_uploads(dtype):
+    """hgs_set_array_device: every array the engine takes from device memory lands exactly as from host memory."""
+    shape, slm = (256, 512), (96, 160)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    a, b = Engine(shape, slm, dtype, batch=2), Engine(shape, slm, dtype, batch=2)
+    rng = np.random.default_rng(3)
+    arrays = {L.PHASE: rng.uniform(-3, 3, (2,) + slm), L.TARGET: rng.uniform(0, 1, (2,) + shape), L.WEIGHTS: rng.uniform(0, 1, (2,) + shape),
+              L.PHASE_FF: rng.uniform(-3, 3, (2,) + shape), L.PROP_KERNEL: rng.uniform(-1, 1, slm)}
+    amp = rng.uniform(0.5, 1, slm)
+    amp /= np.sqrt(np.sum(amp ** 2))
+    a.set(L.AMP, amp.astype(dtype))
+    b.set_tensor(L.AMP, torch.from_numpy(amp.astype(dtype)).cuda())
+    for which, arr in arrays.items():
+        arr = arr.astype(dtype)
+        a.set(which, arr)
+        b.set_tensor(which, torch.from_numpy(arr).cuda())
+        if which != L.PROP_KERNEL:
+            np.testing.assert_array_equal(a.get(which), b.get(which))
+    # a wrong dtype is converted on the device; one hologram's bytes broadcast over the batch, as with hgs_set_array
+    b.set_tensor(L.PHASE, torch.from_numpy(arrays[L.PHASE][:1].astype(np.float64 if dtype == np.float32 else np.float32)).cuda())
+    a.set(L.PHASE, arrays[L.PHASE][:1].astype(np.float64 if dtype == np.float32 else np.float32).astype(dtype))
+    np.testing.assert_array_equal(a.get(L.PHASE), b.get(L.PHASE))
+    a.nearfield2farfield(True)
+    b.nearfield2farfield(True)
+    # (||amp||^2 is folded on the device for a device upload: same farfield to rounding)
+    assert rel_l2(a.get(L.FARFIELD), b.get(L.FARFIELD)) < (1e-6 if dtype == np.float32 else 1e-14)
+    t = b.get_tensor(L.FARFIELD)
+    assert t.is_cuda and t.dtype == (torch.complex64 if dtype == np.float32 else torch.complex128) and tuple(t.shape) == (2,) + shape
+    np.testing.assert_array_equal(t.cpu().numpy(), b.get(L.FARFIELD))
+    with pytest.raises(NotImplementedError):
+        b.set_from_device(L.AMP_SCALAR, t.data_ptr(), dtype().itemsize)
+    a.close()
+    b.close()
+
+
+def test_copy_phase_between_engines_and_kernel_clear():
+    shape, slm = (256, 256), (100, 120)
+    a, b = Engine(shape, slm, np.float32), Engine((512, 512), slm, np.float32, batch=3)
+    ph = synth.seed_phase(5, slm)
+    a.set(L.PHASE, ph)
+    b.copy_phase_from(a)                                       # one source hologram broadcasts over the batch
+    np.testing.assert_array_equal(b.get(L.PHASE), np.stack([ph] * 3))
+    c = Engine(shape, (64, 64), np.float32)
+    with pytest.raises(ValueError):
+        c.copy_phase_from(a)
+    kern = (0.2 * synth.seed_phase(6, slm)).astype(np.float32)
+    a.set(L.PROP_KERNEL, kern)
+    a.nearfield2farfield()
+    with_kernel = a.get(L.FARFIELD)
+    a.clear_propagation_kernel()
+    a.nearfield2farfield()
+    plain = a.get(L.FARFIELD)
+    ref = Engine(shape, slm, np.float32)
+    ref.set(L.PHASE, ph)
+    ref.nearfield2farfield()
+    np.testing.assert_array_equal(plain, ref.get(L.FARFIELD))
+    assert rel_l2(with_kernel, plain) > 1e-2
+    for e in (a, b, c, ref):
+        e.close()
+
+
+def test_get_farfield_stays_on_the_device():
+    """get=False: a torch tensor on the GPU with the values of get=True; after an optimize() the phase goes engine -> engine
+    (no host copy of it exists then); amplitude and kernel are only re-sent when they are other objects."""
+    shape, slm = (512, 512), (144, 240)
+    amp = np.ones(slm, np.float32)
+    h = Hologram(synth.random_target(3, shape), amp=amp, phase=synth.seed_phase(2, slm), slm_shape=slm)
+    host = h.get_farfield((1024, 1024))
+    dev = h.get_farfield((1024, 1024), get=False)
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda and dev.dtype == torch.complex64 and tuple(dev.shape) == (1024, 1024)
+    np.testing.assert_array_equal(dev.cpu().numpy(), host)
+    e_ff = h._ff_engines[(1024, 1024)]["engine"]
+    sets = []
+    orig = Engine.set
+    Engine.set = lambda self, which, arr: (sets.append(which), orig(self, which, arr))[1]
+    try:
+        h.optimize("WGS-Leonardo", maxiter=3, verbose=False)
+        assert h._host.get("phase") is None or "phase" in h._stale          # only the engine holds the new phase
+        sets.clear()
+        after = h.get_farfield((1024, 1024), get=False)
+        assert L.PHASE not in sets and L.AMP not in sets and L.PROP_KERNEL not in sets, sets       # nothing went host -> device
+    finally:
+        Engine.set = orig
+    want = Engine((1024, 1024), slm, np.float32)
+    want.set(L.AMP, h.amp)
+    want.set(L.PHASE, h.phase)
+    want.nearfield2farfield()
+    np.testing.assert_array_equal(after.cpu().numpy(), want.get(L.FARFIELD)[0])
+    assert dispatch_of(e_ff).count("row_kernel", N=1024, MODE=0) >= 1
+    # another depth, then none again: the kernel is sent, then cleared
+    k = (0.1 * synth.seed_phase(4, slm)).astype(np.float32)
+    deep = h.get_farfield((1024, 1024), propagation_kernel=k)
+    flat = h.get_farfield((1024, 1024))
+    np.testing.assert_array_equal(flat, after.cpu().numpy())
+    assert rel_l2(deep, flat) > 1e-3
+    want.close()
+
+
+def test_phase_given_as_a_gpu_tensor():
+    """``phase=`` / ``reset_phase`` accept a torch CUDA tensor (the reference: a CuPy array kept without a copy); it goes to
+    the engine device to device and the run equals the one from the same values given as NumPy."""
+    shape, slm = (512, 512), (144, 240)
+    p0 = synth.seed_phase(8, slm)
+    t = synth.random_target(6, shape)
+    a = Hologram(t, phase=p0.copy(), slm_shape=slm)
+    b = Hologram(t, phase=np.zeros(slm, np.float32), slm_shape=slm)
+    b.reset_phase(torch.from_numpy(p0).cuda())
+    np.testing.assert_array_equal(b.phase, p0)                 # readable before any engine exists
+    a.optimize("WGS-Leonardo", maxiter=4, verbose=False)
+    b.optimize("WGS-Leonardo", maxiter=4, verbose=False)
+    np.testing.assert_array_equal(a.phase, b.phase)
+    b.phase = torch.from_numpy(p0).cuda()                      # with an engine alive
+    a.phase = p0.copy()
+    a.optimize("GS", maxiter=2, verbose=False)
+    b.optimize("GS", maxiter=2, verbose=False)
+    np.testing.assert_array_equal(a.phase, b.phase)
+    with pytest.raises(ValueError):
+        b.reset_phase(torch.zeros((3, 3), device="cuda"))
+
+
+def test_spot_hologram_with_a_hand_assigned_raster():
+    """A SpotHologram's target normally goes up as its spot list; a raster assigned by hand (``_set_target(image)``, or
+    ``h.target = ...``) must reach the engine whole -- and a NaN anywhere in it must switch MRAF on."""
+    shape, slm = (256, 256), (64, 96)
+    h = SpotHologram.make_rectangular_array(shape, (4, 4), (32, 32), basis="knm", slm_shape=slm, phase=synth.seed_phase(3, slm))
+    h.optimize("WGS-Leonardo", maxiter=2, verbose=False)            # engine alive, spot-list upload
+    image = synth.random_target(12, shape, 0.2, 1.0)
+    image[:40] = np.nan
+    h._set_target(image, reset_weights=True)
+    assert not h._sparse_target() and h._mraf_enabled()
+    h.reset_phase(synth.seed_phase(3, slm))
+    h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5)
+    ref = Hologram(image, phase=synth.seed_phase(3, slm), slm_shape=slm)
+    ref.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5)
+    # iteration counters differ (h had taken two bodies before): compare from equal footing
+    h2 = SpotHologram.make_rectangular_array(shape, (4, 4), (32, 32), basis="knm", slm_shape=slm, phase=synth.seed_phase(3, slm))
+    h2._set_target(image, reset_weights=True)
+    h2.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5)
+    np.testing.assert_array_equal(h2.phase, ref.phase)
+    np.testing.assert_array_equal(np.nan_to_num(h2.weights), np.nan_to_num(ref.weights))
+    h2.set_target(reset_weights=True)                               # back to the spot list
+    assert h2._sparse_target() and not h2._mraf_enabled()
+
+
+def test_progress_bar_does_not_chop_the_loop():
+    """verbose=True (the default): the device loop is cut by time, not into maxiter // 20 pieces -- 20 iterations are one or
+    two engine calls, 400 a handful -- and the run is the one verbose=False makes."""
+    shape, slm = (512, 512), (144, 240)
+    t = synth.random_target(6, shape)
+    calls = []
+    orig = Engine.iterate
+    Engine.iterate = lambda self, st, n: (calls.append(n), orig(self, st, n))[1]
+    try:
+        a = Hologram(t, phase=synth.seed_phase(8, slm), slm_shape=slm)
+        a.optimize("WGS-Kim", maxiter=20, verbose=True)
+        assert sum(calls) == 20 and len(calls) <= 2, calls
+        calls.clear()
+        a.optimize("WGS-Kim", maxiter=400, verbose=True)
+        assert sum(calls) == 400 and len(calls) <= 12, calls
+        b = Hologram(t, phase=synth.seed_phase(8, slm), slm_shape=slm)
+        b.optimize("WGS-Kim", maxiter=20, verbose=False)
+        b.optimize("WGS-Kim", maxiter=400, verbose=False)
+    finally:
+        Engine.iterate = orig
+    np.testing.assert_array_equal(a.phase, b.phase)
+    assert a.stats["flags"]["fixed_phase"] == b.stats["flags"]["fixed_phase"] and len(a.stats["method"]) == 420
+
+
+def test_verbose_two_prints_the_method_flags(capsys):
+    h = Hologram(synth.random_target(6, (128, 128)), phase=synth.seed_phase(8, (128, 128)))
+    h.optimize("WGS-Kim", maxiter=1, verbose=2, fix_phase_iteration=7)
+    out = capsys.readouterr().out
+    assert "Optimizing with 'WGS-Kim' using the following method-specific flags:" in out
+    assert "'fix_phase_iteration': 7" in out and "'feedback_exponent': 0.8" in out and "'method'" not in out

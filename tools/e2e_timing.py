@@ -15,6 +15,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
+import torch  # noqa: E402,F401  (first: torch's HIP runtime must open the GPU before libhgs.so does, see _lib.load)
 from slmsuite_amd import _lib as L  # noqa: E402
 from slmsuite_amd import synth  # noqa: E402
 from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM  # noqa: E402
@@ -158,10 +159,63 @@ def wavefront_pattern():
     return out
 
 
+def camera_frame_pattern():
+    """
+    SimulatedCamera's per-frame work (hardware/cameras/simulated.py:344-376): a fresh amplitude array and phase are handed
+    to a Hologram, ``get_farfield(get=False)`` and |ff|^2 follow.  4096^2 grid, S = 1152 x 1920.  Four ways:
+      host_out            get=True: the 134 MB field comes to the host (what every call did before round 4)
+      device_out          get=False: the field stays on the GPU as a torch tensor, |ff|^2 formed there
+      device_out_same_amp ... and the amplitude object is the one of the previous frame (not re-sent)
+      device_phase        ... and the phase is handed over as a torch CUDA tensor (no host -> device copy either)
+    plus the frame after an optimize() (phase taken from the hologram's own engine on the device).
+    """
+    import torch
+    from slmsuite_amd.holography.algorithms import Hologram
+    amp0 = np.ones(SLM, dtype=np.float32)
+    h = Hologram(SH, amp=amp0, phase=synth.seed_phase(9, SLM), slm_shape=SLM)
+    out = {}
+
+    def frames(n, fresh_amp, get, device_phase=False):
+        ts = []
+        for i in range(n):
+            ph = synth.seed_phase(100 + i, SLM)
+            ph_dev = torch.from_numpy(ph).cuda() if device_phase else None
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            if fresh_amp:
+                h.amp = np.array(amp0, copy=True) * (1 / np.sqrt(amp0.size))
+            h.reset_phase(ph_dev if device_phase else ph)
+            ff = h.get_farfield(get=get)
+            img = (ff.abs() ** 2) if not get else np.abs(ff) ** 2
+            if not get:
+                torch.cuda.synchronize()
+            ts.append(ms(t))
+            del img
+        return float(np.median(ts[1:]))
+
+    out["host_out_ms"] = frames(6, True, True)
+    out["device_out_ms"] = frames(8, True, False)
+    out["device_out_same_amp_ms"] = frames(8, False, False)
+    out["device_phase_ms"] = frames(8, False, False, device_phase=True)
+    target = np.zeros(SH, dtype=np.float32)
+    target[1800:2300, 1800:2300] = 1
+    h2 = Hologram(target, phase=synth.seed_phase(9, SLM), slm_shape=SLM)
+    ts = []
+    for _i in range(6):
+        h2.optimize("GS", maxiter=2, verbose=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ff = h2.get_farfield(get=False)
+        torch.cuda.synchronize()
+        ts.append(ms(t))
+    out["after_optimize_device_out_ms"] = float(np.median(ts[1:]))
+    return out
+
+
 if __name__ == "__main__":
     res = {"workload": "cfg2: SpotHologram 32x32 on 4096^2, S = 1152x1920, WGS-Leonardo x 50",
            "engine_default": run(False), "dense_kernels": run(True), "cold_call_breakdown": breakdown(),
-           "wavefront_calibration_pattern": wavefront_pattern()}
+           "wavefront_calibration_pattern": wavefront_pattern(), "camera_frame_pattern": camera_frame_pattern()}
     txt = json.dumps(res, indent=1)
     print(txt)
     if len(sys.argv) > 1:

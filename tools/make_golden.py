@@ -586,6 +586,67 @@ def gen_cfg2_seeds(alg):
               curve_ampff=cur, curve_ampff_perturbed=cur_p))
 
 
+def camera_image(seed, shape=(256, 256)):
+    """A camera-basis target: three Gaussian blobs and a bar, zero elsewhere (float32, deterministic)."""
+    yy, xx = np.mgrid[:shape[0], :shape[1]].astype(np.float64)
+    u = synth.uniform01(seed, (3, 3), 1)
+    img = np.zeros(shape)
+    for k in range(3):
+        cx, cy, s = 60 + 130 * u[k, 0], 60 + 130 * u[k, 1], 6 + 6 * u[k, 2]
+        img += (0.5 + k / 3) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    img[120:136, 40:200] += 0.8
+    img[img < 1e-3] = 0
+    return img.astype(np.float32)
+
+
+def gen_feedback_ij_cases(alg):
+    """Camera-basis targets (FeedbackHologram target_ij / update_target / ijcam_to_knmslm, _feedback.py:75-330), the ij
+    null region of a SpotHologram (_spots.py:1352-1357) and the depth row of the Fourier calibration (cameraslms.py:1221-1354)."""
+    fs = make_fourier_slm()
+    shape = (128, 128)
+    img = camera_image(811)
+    phase0 = synth.seed_phase(810, (48, 64))
+    h = alg.FeedbackHologram(shape, target_ij=img.copy(), cameraslm=fs, phase=phase0.copy())
+    rec = dict(img=img, target_ctor=np.array(h.target), cam_points=np.array(h._cam_points),
+               knm_cubic=np.array(h.ijcam_to_knmslm(img.copy())),
+               knm_blur=np.array(h.ijcam_to_knmslm(img.copy(), blur_ij=2)),
+               knm_nearest=np.array(h.ijcam_to_knmslm(img.copy(), order=0)))
+    h.optimize("WGS-Leonardo", maxiter=4, verbose=False)
+    rec["phase_plain"] = np.array(h.phase)
+    # a null region: NaN (noise region) stays where the camera cannot see AND the radius mask is off
+    h2 = alg.FeedbackHologram(shape, target_ij=img.copy(), cameraslm=fs, phase=phase0.copy(), null_region_radius_frac=0.6)
+    rec["target_frac"] = np.array(h2.target)
+    region = np.zeros(shape, dtype=bool)
+    region[:, :20] = True
+    h2.update_target(img[::-1].copy(), null_region=region, null_region_radius_frac=0.8, reset_weights=True)
+    rec["target_update"] = np.array(h2.target)
+    rec["weights_update"] = np.array(h2.weights)
+    h2.optimize("WGS-Leonardo", maxiter=4, verbose=False, mraf_factor=0.5)
+    rec["phase_mraf"] = np.array(h2.phase)
+    # SpotHologram in the ij basis with a camera-shaped null region
+    ij = np.array([[100., 150, 128, 171.5], [90, 128, 170, 66.25]])
+    null_ij = np.array([[110., 140.], [120., 100.]])
+    cam_region = np.zeros((256, 256), dtype=np.float32)
+    cam_region[40:220, 30:230] = 1
+    # (the reference transforms the region in place into an array of ITS shape, so this path needs shape == cam.shape)
+    s = alg.SpotHologram((256, 256), ij, basis="ij", cameraslm=fs, phase=phase0.copy(), null_vectors=null_ij, null_radius=9.0,
+                         null_region=cam_region.copy())
+    rec.update(spot_ij=ij, null_ij=null_ij, cam_region=cam_region, spot_target=np.array(s.target),
+               spot_null_knm=np.array(s.null_knm), spot_null_radius=np.array(s.null_radius_knm),
+               spot_null_region=np.array(s.null_region_knm))
+    # depth rows
+    k3 = np.array([[0.001, -0.004, 0.0], [0.002, 0.003, -0.001], [1e-6, -2e-6, 5e-7]])
+    i3 = np.array([[100., 150, 128], [90, 128, 170], [3.0, -8.0, 0.5]])
+    rec.update(kxy3=k3, ij_of_kxy3=np.array(fs.kxyslm_to_ijcam(k3)), ij3=i3, kxy_of_ij3=np.array(fs.ijcam_to_kxyslm(i3)),
+               f_eff=np.array([fs.get_effective_focal_length("ij"), np.mean(fs.get_effective_focal_length("norm"))]))
+    # CompressedSpotHologram specified on the camera, with depth (3-vectors through the calibration)
+    c = alg.CompressedSpotHologram(i3, basis="ij", cameraslm=fs)
+    rec.update(comp_zernike=np.array(c.spot_zernike), comp_kxy=np.array(c.spot_kxy), comp_ij=np.array(c.spot_ij),
+               comp_width_ij=np.array(c.spot_integration_width_ij), comp_basis=np.array(c.zernike_basis))
+    save("feedback_ij", dict(kind="feedback_ij", shape=list(shape), slm_shape=(48, 64), seed=810, M=[[6000., 0], [0, 6000.]],
+                             b=[128., 128.]), rec)
+
+
 def make_fourier_slm(res_wh=(64, 48)):
     """SimulatedSLM + SimulatedCamera + analytic Fourier calibration (SURVEY 8c recipe)."""
     from slmsuite.hardware.slms.simulated import SimulatedSLM
@@ -683,6 +744,7 @@ def main():
         "misc": lambda: gen_misc_cases(alg),
         "kimeff": lambda: gen_kimeff_cases(alg),
         "spotnull": lambda: gen_spot_null_cases(alg),
+        "feedback_ij": lambda: gen_feedback_ij_cases(alg),
     }
     if args.cfg2:
         steps["cfg2"] = lambda: gen_cfg2(alg)
