@@ -157,7 +157,7 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-    static __device__ __forceinline__ float powneg(float x, float p) { return exp2f(-p * log2f(x)); }
+    static __device__ __forceinline__ float powneg(float x, float p);      // x^-p, x >= 0 (pow_split below)
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float log2(float x) { return log2f(x); }
     static __device__ __forceinline__ float exp2(float x) { return exp2f(x); }
@@ -304,17 +304,35 @@ template <typename R> struct StatAcc {
     }
 };
 
-// (|F| c / T)^-p for the Leonardo / Kim rule of the fused kernels, from |F|^2: the ratio is formed FIRST, so
-// the logarithm is taken of a number near 1 for a converging spot (log2 of the three factors separately
-// cancels ~20 against ~20 and leaves 1e-6 relative noise per update, ten times the reference's np.power).
+// x^c for finite x > 0 with the accuracy of one rounding of each hardware transcendental (about 1.5 ulp), independent of
+// how far x is from 1.  exp2(c * log2(x)) on v_log_f32 / v_exp_f32 alone loses |log2 x| * |c| ulps: the logarithm's one
+// ulp is relative to ITS magnitude, and a speckle pixel twenty octaves under its target paid five ulps (NumPy's powf is
+// correctly rounded).  Here x = m 2^e, m in [0.5, 1): the exponent is exact, the hardware logarithm
+// is taken of the mantissa only (|log2 m| <= 1: absolute error 6e-8), and c * e is split into the nearest integer n (goes
+// into the result's exponent by v_ldexp) and a residual formed by ONE fused multiply-add:
+//     x^c = 2^n * exp2((c e - n) + c log2 m),   |argument| <= 0.5 + |c|.
+// x = 0 gives +-inf like the plain form (callers map it, :1867); NaN propagates.  9 more VALU instructions per value.
+__device__ __forceinline__ float pow_split(float x, float c) {
+    const float m = __builtin_amdgcn_frexp_mantf(x);
+    const float e = (float)__builtin_amdgcn_frexp_expf(x);
+    const float l = __builtin_amdgcn_logf(m);
+    const float n = __builtin_rintf(c * e);
+    const float f = __builtin_fmaf(c, e, -n) + c * l;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+__device__ __forceinline__ float Math<float>::powneg(float x, float p) { return pow_split(x, -p); }
+
+// (|F| c / T)^-p for the Leonardo / Kim rule of the fused kernels, from |F|^2: the ratio is formed FIRST (log2 of the
+// three factors separately cancels ~20 against ~20 and leaves 1e-6 relative noise per update).
 template <typename R> __device__ __forceinline__ R leonardo_factor(R p2, R t, R inv_fnorm, R p_exp) {
     using M = Math<R>;
-    const R q = inv_fnorm * Math<R>::rcp(t);       // 1-ulp reciprocal: the ratio is squared and logged anyway
+    const R q = inv_fnorm * Math<R>::rcp(t);       // 1-ulp reciprocal: the ratio is squared and raised to p/2 < 1/2
     const R r2 = p2 * q * q;                       // (|F| c / T)^2
     if (!(r2 < (R)INFINITY)) return (R)1;          // overflow of the ratio (:1840) and NaN targets (:1843) -> 1
-    // r2 = 0 -> inf: callers map it to 1 (:1867).  A ratio below 1.2e-38 (|F| twenty orders of magnitude under its
-    // target) is flushed to the same case by the bare log: such a pixel keeps its weight instead of gaining 2^52.
-    return M::exp2_fast((R)-0.5 * p_exp * M::log2_fast(r2));
+    // r2 = 0 -> inf: callers map it to 1 (:1867)
+    if constexpr (sizeof(R) == 4) return pow_split(r2, -0.5f * p_exp);
+    else return M::exp2_fast((R)-0.5 * p_exp * M::log2_fast(r2));
 }
 
 // ---- the WGS weight rule for one element (rows 9-10; _hologram.py:1830-1873) -------------------------

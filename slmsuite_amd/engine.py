@@ -88,6 +88,9 @@ class Engine:
         if str(tensor.dtype).split(".")[-1] != want:
             tensor = tensor.to(getattr(__import__("torch"), want))
         tensor = tensor.contiguous()
+        # the engine copies on ITS stream: whatever torch still has in flight for this tensor (its producer, the
+        # conversions above) must have landed first
+        __import__("torch").cuda.current_stream(tensor.device).synchronize()
         self.set_from_device(which, tensor.data_ptr(), tensor.numel() * tensor.element_size())
 
     def clear_propagation_kernel(self):
@@ -105,6 +108,7 @@ class Engine:
         cplx = {4: torch.complex64, 8: torch.complex128}[self.dtype.itemsize]
         shape = (self.batch,) + (self.slm_shape if which == L.PHASE else self.shape)
         t = torch.empty(shape, dtype=cplx if which in (L.FARFIELD, L.ZERO_WEIGHTS) else real, device=torch.device("cuda", self.device))
+        torch.cuda.current_stream(t.device).synchronize()     # (the block may be a recycled one torch is still reading)
         self.get_into_device(which, t.data_ptr(), t.numel() * t.element_size())
         return t
 
