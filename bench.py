@@ -123,6 +123,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--reps", type=int, default=10, help="repetitions of the K-step timed region; the median is reported")
     ap.add_argument("--batch", type=int, default=None, help="independent holograms per GPU (cfg3: 8)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="stream groups a rank's holograms are split over (one engine and HIP stream each; launches of "
+                         "different groups overlap on the device).  Default: 2 from four holograms per GPU, else 1")
     ap.add_argument("--workload", default=None, choices=ALL_WORKLOADS,
                     help="default: cfg2 on one GPU, cfg3 (cfg 2 with 8 holograms per GPU, BASELINE configs[2]) on several")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -160,6 +163,9 @@ def parse():
         a.spots = 1000 if a.workload == "cfg4zern" else 10000
     if a.batch is None:
         a.batch = 8 if a.workload == "cfg3" else 1
+    if a.streams is None:
+        a.streams = 2 if a.batch >= 4 else 1
+    a.streams = max(1, min(a.streams, a.batch))
     if a.method is None:
         a.method = ("WGS-Kim" if (a.workload in COMPRESSED_WORKLOADS or a.workload in VECTOR_WORKLOADS) else
                     "GS" if a.workload == "cfg1" else "WGS-Leonardo")
@@ -219,7 +225,8 @@ class GridProblem:
             kw = {}
             self.sparse_target = False
         phases = np.stack([synth.seed_phase(1000 * rank + 2 + i, self.slm, dtype=self.np_dtype) for i in range(args.batch)])
-        self.hb = HologramBatch(self.shape, self.slm, target, phases, dtype=self.np_dtype, device=local_rank, **kw)
+        self.hb = HologramBatch(self.shape, self.slm, target, phases, dtype=self.np_dtype, device=local_rank,
+                                streams=args.streams, **kw)
         self.engine = self.hb.engine
         self.mraf = self.hb.mraf
 
@@ -245,7 +252,7 @@ class GridProblem:
         P, S = Ph * Pw, Sh * Sw
         r = 4 if self.args.dtype == "f32" else 8
         c = 2 * r
-        B = self.args.batch
+        B = -(-self.args.batch // self.args.streams)      # holograms per launch (one stream group)
         m = self.args.method
         wgs = m != "GS"
         gh = Sh * Pw * c                              # half-transformed field: SLM rows only
@@ -681,7 +688,7 @@ def main():
     one_per_gpu = None
     if world > 1 and args.workload == "cfg3" and args.batch != 1 and not args.no_extra_pass:
         a1 = argparse.Namespace(**vars(args))
-        a1.workload, a1.batch = "cfg2", 1
+        a1.workload, a1.batch, a1.streams = "cfg2", 1, 1
         p1 = GridProblem(a1, rank, local_rank)
         apply_opts(p1.engine, args.opt)
         p1.engine.set_option(L.OPT_SPARSE_COLUMNS, args.sparse_columns)
@@ -844,12 +851,16 @@ def main():
                     "row_kernel": {"launch_us": row_dur * 1e6, "bytes_per_launch": bm["row"], "bytes_model": bm["row_model"],
                                    "achieved": bm["row"] / row_dur / 1e9, "frac": bm["row"] / row_dur / HBM_PEAK,
                                    "traffic": tr_row},
-                    "iteration": {"moved_bytes": bm["col"] + bm["row"],
-                                  "achieved": (bm["col"] + bm["row"]) * iter_s / 1e9,
-                                  "frac": (bm["col"] + bm["row"]) * iter_s / HBM_PEAK,
-                                  "canonical_bytes": bm["canon_iter"],
-                                  "canonical_equivalent_frac": bm["canon_iter"] * iter_s / HBM_PEAK},
-                    "timing": "HIP events per launch on the engine stream, second pass of K steps"}
+                    "iteration": {"moved_bytes": (bm["col"] + bm["row"]) * args.streams,
+                                  "achieved": (bm["col"] + bm["row"]) * args.streams * iter_s / 1e9,
+                                  "frac": (bm["col"] + bm["row"]) * args.streams * iter_s / HBM_PEAK,
+                                  "canonical_bytes": bm["canon_iter"] * args.streams,
+                                  "canonical_equivalent_frac": bm["canon_iter"] * args.streams * iter_s / HBM_PEAK,
+                                  "note": "all stream groups of this rank together" if args.streams > 1 else None},
+                    "timing": "HIP events per launch on the engine stream, second pass of K steps; an event pair adds about "
+                              "1 - 2 us to a launch (the rocprofv3 --kernel-trace average of the same kernel, profiles/, is "
+                              "the sharper figure)" + ("; launches of different stream groups overlap, so a launch's event "
+                              "interval also holds what ran beside it" if args.streams > 1 else "")}
         cpu = cpu_baseline(args) if world == 1 else None
         shape_txt = "" if compressed else f" padded to {prob.shape[0]}x{prob.shape[1]}"
         line = {
@@ -861,7 +872,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {prob.desc}, SLM {prob.slm[0]}x{prob.slm[1]}{shape_txt}, "
                                    f"{args.method}, {'fp32' if args.dtype == 'f32' else 'fp64'}",
-                       "holograms_per_gpu": args.batch, "parallelism": f"independent holograms x{world}"},
+                       "holograms_per_gpu": args.batch, "stream_groups_per_gpu": args.streams,
+                       "parallelism": f"independent holograms x{world}"},
             "repetitions": args.reps, "ms_per_step_min": min(walls) * 1e3 / args.steps,
             "ms_per_step_max": max(walls) * 1e3 / args.steps,
             "timing": f"median of {args.reps} repetitions of the {args.steps}-step region (barrier + synchronize on both sides, "

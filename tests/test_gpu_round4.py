@@ -199,3 +199,32 @@ def test_verbose_two_prints_the_method_flags(capsys):
     out = capsys.readouterr().out
     assert "Optimizing with 'WGS-Kim' using the following method-specific flags:" in out
     assert "'fix_phase_iteration': 7" in out and "'feedback_exponent': 0.8" in out and "'method'" not in out
+
+
+def test_stream_groups_leave_every_hologram_unchanged():
+    """HologramBatch(streams=G): the batch is split over G engines whose launches overlap on the device; every hologram's
+    masks are those of the single-engine batch, whatever the split (also an uneven one), and the device-side gather of the
+    masks puts them in batch order."""
+    from slmsuite_amd.batch import HologramBatch
+    shape, slm = (1024, 1024), (288, 480)
+    host = SpotHologram.make_rectangular_array(shape, (8, 8), (64, 64), basis="knm", slm_shape=slm, phase=synth.seed_phase(2, slm))
+    phases = np.stack([synth.seed_phase(300 + i, slm) for i in range(5)])
+    want = None
+    for groups in (1, 2, 3):
+        hb = HologramBatch(shape, slm, host.target, phases, spot_index=host.spot_knm_rounded, spot_amp=host.spot_amp, streams=groups)
+        assert len(hb.engines) == groups and [hi - lo for lo, hi in hb.bounds] == {1: [5], 2: [3, 2], 3: [2, 2, 1]}[groups]
+        hb.optimize("WGS-Kim", 12, fix_phase_iteration=5)
+        hb.optimize("WGS-Kim", 3)
+        got = hb.phases()
+        t = torch.empty((5,) + slm, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        hb.phases_into_device(t.data_ptr(), t.numel() * 4)
+        np.testing.assert_array_equal(t.cpu().numpy(), got)
+        assert hb.iter == 15 and hb.flags["fixed_phase"]
+        ms = hb.time_iterations("WGS-Kim", 4)
+        assert ms > 0 and hb.iter == 19
+        hb.close()
+        if want is None:
+            want = got
+        else:
+            np.testing.assert_array_equal(got, want)

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 TAG=${R4_TAG:-run}
 run_step() {
   case "$1" in
-    tests) shift; python -m pytest "$@" -m gpu -q 2>&1 | tail -${R4_TAIL:-80} > gpurun_out/r4_pytest_$TAG.log ;;
+    tests) shift; rm -f gpurun_out/parity_report.jsonl; python -m pytest "$@" -m gpu -q 2>&1 | tail -${R4_TAIL:-80} > gpurun_out/r4_pytest_$TAG.log; cp gpurun_out/parity_report.jsonl gpurun_out/r4_parity_$TAG.jsonl 2>/dev/null ;;
     bench) shift; name=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/r4_bench_$name.json 2> gpurun_out/r4_bench_$name.err ;;
     pow) tools/microbench/pow_rule > gpurun_out/r4_pow_rule.log 2>&1 ;;
     e2e) python tools/e2e_timing.py gpurun_out/r4_e2e.json > /dev/null 2> gpurun_out/r4_e2e.err ;;
