@@ -143,7 +143,8 @@ class HologramBatch:
         if self.flags is None:
             self.flags = batch_flags(method, **flags)
         else:
-            self.flags.update(batch_flags(method, **{**self.flags, **flags}))
+            kept = {k: v for k, v in self.flags.items() if k != "method"}      # flags persist between calls, like Hologram.flags
+            self.flags = batch_flags(method, **{**kept, **flags})
         steps = self._steps(spot_window)
         for e, st in zip(self.engines, steps):     # hgs_iterate only enqueues: the groups' launches interleave on the device
             e.iterate(st, maxiter)

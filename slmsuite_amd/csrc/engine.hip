@@ -200,6 +200,8 @@ template <typename R> struct Engine : EngineBase {
     int* col_list = nullptr;               // [B][Pw] compacted
     int* n_active_dev = nullptr;           // [B]
     unsigned short* lane_mask = nullptr;   // [B][Pw/16] row-kernel view of col_active
+    unsigned short* lane_mask_noise = nullptr;   // ... of its bit 4: columns with a NaN target (noise part of single-pass MRAF)
+    int opt_gh2_mask = 1;                  // developer A/B (HGS_GH2_MASK=0 at create): noise part stored / read for every column
     // the same for the columns the spot integration windows touch (spot feedback / spot statistics)
     unsigned char* col_active_d = nullptr;
     int* col_list_d = nullptr;
@@ -292,7 +294,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
-        void* ptrs[] = {phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
+        void* ptrs[] = {lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -372,6 +374,7 @@ template <typename R> struct Engine : EngineBase {
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
+        opt_gh2_mask = env_int("HGS_GH2_MASK", 1);
         opt_tile_list = env_int("HGS_TILE_LIST", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
         auto t_prev = std::chrono::steady_clock::now();
@@ -1421,6 +1424,9 @@ template <typename R> struct Engine : EngineBase {
                 a.prefetch = 0;
                 a.n_row_blocks = blocks = row_blocks;
                 a.gh2 = gh2;
+                // (a column-list launch already reads the listed columns only, and a noise box fills its list: there the
+                //  second mask costs its fetch -- 42.4 -> 46.1 us at cfg 5 -- and saves nothing)
+                a.gh2_mask = (opt_gh2_mask && !sparse_dirty && !a.load_mask) ? lane_mask_noise : nullptr;
                 row_split = false;
                 LCHK(row_split_launch(g.Pw, mode, dim3(blocks, B), stream, a));
                 return 0;
@@ -1507,6 +1513,10 @@ template <typename R> struct Engine : EngineBase {
         }
         hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
                            col_list, n_active_dev, lane_mask);
+        HIPCHK(hipGetLastError());
+        if (!lane_mask_noise) HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_noise), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
+        hipLaunchKernelGGL(flag_lane_mask, dim3((g.Pw / 16 + 255) / 256, B), dim3(256), 0, stream, (const unsigned char*)col_active,
+                           g.Pw, 4, lane_mask_noise);
         HIPCHK(hipGetLastError());
         std::vector<int> h(B);
         HIPCHK(hipMemcpyAsync(h.data(), n_active_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1907,6 +1917,10 @@ template <typename R> struct Engine : EngineBase {
         if (opt_sparse) {
             if (int e = refresh_sparse()) return e;
             sparse_enabled = n_active_min > 0 && n_active_max * 2 <= g.Pw;
+        } else if (st->mraf_enabled && st->method != HGS_GS && opt_mraf_split && opt_gh2_mask && tile_geometry_ok() && g.Pw >= 4096) {
+            // single-pass MRAF: which columns hold a NaN target (the noise part exists only there) -- a fact about the
+            // target, scanned once per upload; the dense launches themselves still walk every column
+            if (int e = refresh_sparse()) return e;
         }
         // "computational_spot" statistics on the sparse path: amp_ff is produced on the spot columns dilated
         // by the integration window (col_kernel FWD|STORE over that list) before the fused kernel runs
@@ -2000,6 +2014,7 @@ template <typename R> struct Engine : EngineBase {
                     } else if (split && pass == 0) {
                         wpartial_n = tile_grid;
                         a.gh2 = gh2;
+                        a.gh2_sparse = (opt_gh2_mask && !sparse_dirty && !sp) ? 1 : 0;   // (set together with RowArgs::gh2_mask below)
                         if (sp) a.col_flags = col_active;       // (scanned with the weights / target this loop started from)
                         LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, opt_tile_rule, dim3(tile_grid, B), stream, a, m0));
                         row_split = true;

@@ -442,6 +442,7 @@ template <typename R> struct RowArgs {
     Cx<R>* nf_out;       // MODE 1 only: store the complex nearfield rows [b][Sh][Sw] instead of extracting
                          // the phase (_farfield2nearfield(extract=False), MultiplaneHologram)
     const Cx<R>* gh2;    // row_kernel SPLIT: the noise-region part of an MRAF field (layout of gh); H = gh * wscale + gh2
+    const unsigned short* gh2_mask;   // ... and the columns in which it exists (a NaN target in the column); nullptr = all
 };
 
 // NS < 16 (one-row workgroups only): the SLM columns occupy at most NS of the 16 register slots of the space side.  The
@@ -696,10 +697,12 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
             if constexpr (SPLIT) {
                 const R ws = a.wscale[b];
                 const Cx<R>* gh2r = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)rr * 4;
+                // the noise part is zero -- and, with a mask, not even stored -- outside the columns that hold a NaN target
+                const unsigned nmask = a.gh2_mask != nullptr ? (lmask & fetch_mask(a.gh2_mask)) : lmask;
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
                     Cx<R> h2 = mk<R>(0, 0);
-                    if (valid && ((lmask >> m) & 1u)) h2 = (gh2r + (size_t)m * gh_step)[gh_lane];
+                    if (valid && ((nmask >> m) & 1u)) h2 = (gh2r + (size_t)m * gh_step)[gh_lane];
                     if constexpr (NS < 16) v[m] = v[m] * ws + h2;
                     else v[m] = v[m] * ws + h2 * sgn;
                 });
@@ -851,6 +854,8 @@ template <typename R> struct ColArgs {
     int list_xmap;         // the same for column-list launches: list groups PASSES k .. PASSES k + PASSES - 1 (the columns
                            // of one tile where the active set is dense) on one XCD together (gridDim.x a multiple of 8 * PASSES)
     Cx<R>* gh2;            // col_tile_kernel RULE 3 (single-pass MRAF): column-transformed noise-region part, layout of gh
+    int gh2_sparse;        // ... stored only for tiles (NR <= 4) / columns (NR > 4) that hold a noise pixel: the row kernel
+                           //     reads it through RowArgs::gh2_mask, which marks exactly the columns with a NaN target
     int col_xmap;          // dense launches of col_fused_kernel with fewer than four columns per pass: the passes of one
                            // 4-column tile go to workgroups of ONE XCD that run together (gridDim.x a multiple of 8 * PASSES)
     const unsigned char* col_flags;   // [batch][Pw] scan_active_cols bits, or nullptr (col_tile_kernel RULE 4 skips the inverse
@@ -1496,6 +1501,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 stage_next(next_ct());
             }
         }
+        int tile_noise = 0;          // SPLIT: any column of this tile with a noise pixel (wave-uniform)
         if (it == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
             issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
 #if HGS_TRACE
@@ -1666,6 +1672,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 // (column flags known: no need for the LDS flag, whose writers may not be a barrier behind when the
                 //  inverse above was skipped)
                 const int any = cflags >= 0 ? ((cflags & 4) != 0) : __builtin_amdgcn_readfirstlane(*nflag);
+                tile_noise |= any;
                 if (any) {
                     static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T + j]; });
                     fft.template inv_trail<NR>(v, lds, j);
@@ -1681,7 +1688,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                         }
                     } else {
                         const int r = r_lane + m * T;
-                        if (r >= 0 && r < g.Sh) g2[(unsigned)r * 4u] = h;
+                        if ((any || !a.gh2_sparse) && r >= 0 && r < g.Sh) g2[(unsigned)r * 4u] = h;
                     }
                 }
             }
@@ -1689,10 +1696,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         if (EXTRAS && !FIXED && cp.weights_only) continue;
         if constexpr (BTILE) {
             Cx<R>* g2 = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+            const bool keep = tile_noise != 0 || !a.gh2_sparse;      // (a tile without noise is never read back)
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
                 const int r = r_lane + m * T;
-                if (r >= 0 && r < g.Sh) {
+                if (keep && r >= 0 && r < g.Sh) {
                     float4* q = reinterpret_cast<float4*>(g2 + (unsigned)r * 4u);
                     q[0] = make_float4(gbx[m][0], gby[m][0], gbx[m][1], gby[m][1]);
                     q[1] = make_float4(gbx[m][2], gby[m][2], gbx[m][3], gby[m][3]);
@@ -2313,6 +2321,17 @@ static __global__ void compact_active_cols(const unsigned char* active, int Pw, 
 
 // WGS-Nogrette on the fused path: nog[b] = -1 / nanmean(fc) from the column kernel's partial sums; columns the
 // sparse path did not visit hold T = 0 everywhere, i.e. fc = 1 per pixel.
+// Row-kernel view of one bit of scan_active_cols: bit m of lane_mask[b][j] = column j + m * Pw / 16 has `bit` set.
+// bit 4 (a NaN target in the column) gives the columns where the noise part of a single-pass MRAF field exists at all.
+static __global__ void flag_lane_mask(const unsigned char* active, int Pw, int bit, unsigned short* lane_mask) {
+    const int b = blockIdx.y, T = Pw / 16;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    unsigned m16 = 0;
+    for (int m = 0; m < 16; ++m) m16 |= (unsigned)((active[(size_t)b * Pw + j + m * T] & bit) != 0) << m;
+    lane_mask[(size_t)b * T + j] = (unsigned short)m16;
+}
+
 template <typename R>
 __global__ void nog_finalize(const double* sum, const int* n_active, int Ph, int Pw, R* nog, int batch) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
