@@ -676,13 +676,14 @@ def main():
             ms_ev = pb.run(args.steps)
             sync_all()
             mine = time.perf_counter() - t0
-            tmax = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
-            if dist is not None:
+            if dist is not None:        # the slowest rank counts
+                tmax = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
                 every = [torch.zeros_like(tmax) for _ in range(world)]
                 dist.all_gather(every, tmax)
                 rws.append([float(x.item()) for x in every])
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            ws.append(float(tmax.item()))
+                mine = float(tmax.item())
+            ws.append(mine)
             evs.append(ms_ev)
         mid_ = sorted(range(args.reps), key=lambda i: ws[i])[len(ws) // 2]
         return ws, evs, rws, mid_

@@ -348,6 +348,14 @@ def test_cfg4_configured_run_reaches_its_end_state():
     e_paths = dict(spot_amp=rel_l2(np.abs(h.farfield), np.abs(hd.farfield)), weights=rel_l2(h.weights, hd.weights),
                    phase=phase_rel_l2(h.phase, hd.phase))
     hd._release_engine()
+    # ... and how far ONE arithmetic moves when its start phase changes by one fp32 ulp: the yardstick for the distance
+    # between the two arithmetics (each within 2e-6 .. 4e-6 of float64 direct summation per operator, see the test above)
+    hp = make(1)
+    hp.reset_phase(np.nextafter(synth.seed_phase(4, SLM), np.float32(4.0)))
+    hp.optimize("WGS-Kim", maxiter=14, verbose=False)
+    e_ulp = dict(spot_amp=rel_l2(np.abs(hp.farfield), np.abs(h.farfield)), weights=rel_l2(hp.weights, h.weights),
+                 phase=phase_rel_l2(hp.phase, h.phase))
+    hp._release_engine()
     h.optimize("WGS-Kim", maxiter=186, verbose=False)
     assert h.iter == 200 and h.flags["fixed_phase"] and sum(bool(x) for x in h.stats["flags"]["fixed_phase"]) == 190
     u200 = uniformity(h)
@@ -365,8 +373,12 @@ def test_cfg4_configured_run_reaches_its_end_state():
     scale = np.real(np.vdot(ref, got)) / np.real(np.vdot(ref, ref))
     err_end = rel_l2(got, scale * ref)
     report("cfg4 configured run (200 it): paths at 14 it, end state vs float64 direct sum, uniformity", end_farfield=err_end,
-           uniformity_12=u12, uniformity_200=u200, **{f"paths14_{k}": v for k, v in e_paths.items()})
+           uniformity_12=u12, uniformity_200=u200, **{f"paths14_{k}": v for k, v in e_paths.items()},
+           **{f"one_ulp14_{k}": v for k, v in e_ulp.items()})
     assert e_paths["spot_amp"] < 1e-2, e_paths              # same run, two arithmetics: a sanity bound, not a parity claim
+    # the two arithmetics part no faster than one of them parts from itself under a one-ulp change of the input (x 20:
+    # the perturbation is one rounding, the paths differ by a few per operator)
+    assert e_paths["spot_amp"] < 20 * max(e_ulp["spot_amp"], 1e-6), (e_paths, e_ulp)
     assert err_end < 2e-5
     assert u200 > u12, (u12, u200)
     h._release_engine()
