@@ -854,6 +854,7 @@ def main():
                                              "frac_of_peak": bm["canon_col"] / dur / HBM_PEAK,
                                              "note": "SURVEY 8(d) un-pruned count 4*P*c + 3*P*r per column launch; a throughput "
                                                      "equivalent, NOT bytes moved (rows outside the SLM are never stored)"},
+                    "valu_view": valu_view(args, prob, dur, row_dur),
                     "working_set_bytes": bm["working_set"],
                     "infinity_cache_resident": bool(bm["working_set"] <= MALL_BYTES),
                     "infinity_cache_note": "FETCH_SIZE/WRITE_SIZE count fabric requests including Infinity-Cache (256 MiB) hits; "
@@ -926,6 +927,30 @@ def main():
     prob.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def valu_view(args, prob, col_dur, row_dur):
+    """
+    The same two launches against the VECTOR pipe (they do not wait on HBM: DESIGN.md section 6).  Nominal transform work
+    5 N log2 N real operations per length-N complex transform (the textbook count; zero rows are pruned, so fewer are
+    issued): a column launch is 2 Pw transforms of length Ph per hologram, a row launch 2 Sh of length Pw.  Peaks: 157.3
+    TFLOP/s is packed fp32 FMA (4 flop per lane and issue); a butterfly network is mostly additions (2 flop per lane and
+    issue), for which the pipe's ceiling is 78.6 TFLOP/s; fp64: 78.6 / 39.3.
+    """
+    import math
+    Ph, Pw = prob.shape
+    Sh = prob.slm[0]
+    B = -(-args.batch // args.streams)
+    fma_peak = 157.3e12 if args.dtype == "f32" else 78.6e12
+    col_flop = 2 * Pw * 5.0 * Ph * math.log2(Ph) * B * prob.bytes_models()["col_passes"]
+    row_flop = 2 * Sh * 5.0 * Pw * math.log2(Pw) * B
+    out = {}
+    for name, flop, dur in (("column_launch", col_flop, col_dur), ("row_launch", row_flop, row_dur)):
+        out[name] = {"nominal_fft_flop": flop, "achieved_tflops": flop / dur / 1e12, "frac_of_fma_peak": flop / dur / fma_peak,
+                     "frac_of_add_peak": flop / dur / (fma_peak / 2)}
+    out["note"] = ("nominal 5 N log2 N per transform; two-pass launches counted with both forward transforms; the constraint "
+                   "arithmetic (up to ~45 instructions per evaluated pixel) is not included")
+    return out
 
 
 def traffic_explanation(args, prob, roof):
