@@ -233,8 +233,7 @@ class Hologram:
             if _is_device_tensor(value):
                 # already on a GPU: device to device, and from here on the engine's copy is the one that counts
                 e.set_tensor(_DEVICE_ARRAYS[name], value.reshape((1,) + tuple(value.shape[-2:])))
-                self._host[name] = None
-                self._stale.add(name)
+                self._stale.add(name)          # (a read downloads the engine's copy and replaces the tensor kept here)
             elif value is not None:
                 e.set(_DEVICE_ARRAYS[name], value)
             self._upload.discard(name)
@@ -251,7 +250,7 @@ class Hologram:
     def reset(self, reset_phase=True, reset_flags=False):
         """``Hologram.reset`` (:442-478): iteration counter, history and weights start over; the phase only on request
         (or when there is none); the flags only on request.  The engine, if any, survives."""
-        if reset_phase or self._host.get("phase") is None:
+        if reset_phase or (self._host.get("phase") is None and "phase" not in self._stale):
             self.reset_phase()
         self.reset_weights()
         self.iter, self.stats = 0, dict(method=[], flags={}, stats={})

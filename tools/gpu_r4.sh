@@ -22,7 +22,7 @@ run_step() {
     e2e) python tools/e2e_timing.py gpurun_out/r4_e2e.json > /dev/null 2> gpurun_out/r4_e2e.err ;;
     profiles) t=${2:-r04}
       prof() { n=$1; shift; bash tools/profile.sh ${t}_$n "$@" > gpurun_out/prof_$n.log 2>&1; }
-      prof cfg2; prof cfg3 --workload cfg3; prof cfg5pad --workload cfg5pad; prof cfg5mraf --workload cfg5mraf
+      prof cfg2; prof cfg3 --workload cfg3 --streams 1; prof cfg3_2streams --workload cfg3; prof cfg5pad --workload cfg5pad; prof cfg5mraf --workload cfg5mraf
       prof cfg5mraf_f64 --workload cfg5mraf --dtype f64; prof hd --workload hd; prof cfg2dense --workload cfg2dense
       prof cfg4 --workload cfg4 --steps 20; prof cfg4zern --workload cfg4zern --steps 20; prof cfg1 --workload cfg1 --steps 200 ;;
     configs) bash tools/gpu_configs.sh > gpurun_out/configs.log 2>&1
