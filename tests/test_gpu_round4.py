@@ -228,3 +228,33 @@ def test_stream_groups_leave_every_hologram_unchanged():
             want = got
         else:
             np.testing.assert_array_equal(got, want)
+
+
+def test_dispatch_read_buffer_protocol_and_device_upload_errors():
+    """The C ABI's edge behaviour behind the Python wrappers: size query keeps the record, a short buffer fails and keeps it,
+    success clears it; device uploads check sizes like host uploads."""
+    import ctypes as C
+    e = Engine((256, 256), (64, 96), np.float32)
+    e.set(L.PHASE, synth.seed_phase(1, (64, 96)))
+    e.nearfield2farfield()
+    lib = e.lib
+    need = C.c_size_t(0)
+    assert lib.hgs_dispatch_read(e._h, None, 0, C.byref(need)) == 0 and need.value > 10
+    small = C.create_string_buffer(4)
+    assert lib.hgs_dispatch_read(e._h, small, 4, None) == L.HGS_ERR_ARG and small.value == b""
+    again = C.c_size_t(0)
+    assert lib.hgs_dispatch_read(e._h, None, 0, C.byref(again)) == 0 and again.value == need.value       # still there
+    buf = C.create_string_buffer(need.value)
+    assert lib.hgs_dispatch_read(e._h, buf, len(buf), None) == 0
+    text = buf.value.decode()
+    assert "row_kernel<R=float,N=256,MODE=0" in text and "col_kernel<R=float,N=256,MODE=3>" in text and text.endswith("\n")
+    assert lib.hgs_dispatch_read(e._h, None, 0, C.byref(again)) == 0 and again.value == 1                 # cleared: just the terminator
+    assert lib.hgs_dispatch_read(None, buf, len(buf), None) == L.HGS_ERR_ARG
+    t = torch.zeros((64, 96), dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError):
+        e.set_from_device(L.PHASE, t.data_ptr(), 17)
+    with pytest.raises(ValueError):
+        e.set_from_device(L.PHASE, 0, t.numel() * 4)
+    with pytest.raises(ValueError):
+        e.set_from_device(99, t.data_ptr(), t.numel() * 4)
+    e.close()
