@@ -71,6 +71,9 @@ struct Geo {
 // hgs_set_array / hgs_get_array and the spot kernels apply it.
 // Tile-resident column kernel: pick the column of the pass out of the tile registers with a register-relative move
 // (the pass index is uniform: s_set_gpr_idx + v_mov, 24 instructions per pass) instead of 84 v_cndmask
+#ifndef HGS_ROW_ST16
+#define HGS_ROW_ST16 1      // dense fp32 row launches store G in 16-byte pieces (lane pairs swap one value per slot pair)
+#endif
 #ifndef HGS_TILE_MOVREL
 #define HGS_TILE_MOVREL 1
 #endif
@@ -789,6 +792,39 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
             if (valid) {
                 const R sc = sgn * a.scale;
                 const Cx<R> omsc = om * sc;
+                // Dense fp32 launches: the sixteen 8-byte stores of a lane are store-ISSUE bound (2.7 k of the 16.3 k cycles of
+                // a row in tools/microbench/trace_row; MI355X_MICROARCH.md: 8 x dwordx4 halves such a tail).  Lanes j, j + 1
+                // (j even) own neighbouring columns of the same tile row, so they swap one value per pair of register slots
+                // (quad_perm [1, 0, 3, 2]) and each stores 16 bytes: the even lane the pair of slot m, the odd one that of
+                // slot m + 1 -- eight store instructions instead of sixteen, the same bytes at the same addresses.
+                // (measured: a batch of eight, one-row workgroups: row launch 89.8 -> 86.9 us; the prefetching walk of a single
+                //  hologram LOSES 1.2 us to the swaps on its chain and keeps the 8-byte stores; 8192-wide rows: level)
+                if constexpr (sizeof(R) == 4 && HGS_ROW_ST16 && T % 64 == 0 && !PREF) {
+                    if (a.store_mask == nullptr) {
+                        const bool odd = (j & 1) != 0;
+                        Cx<R>* pbase = ghr + (gh_lane - (odd ? 1u : 0u)) + (odd ? (size_t)gh_step : (size_t)0);
+                        static_for<0, 8>([&](auto p_) {
+                            constexpr int m = 2 * p_;
+                            Cx<R> e0, e1;
+                            if constexpr (NS < 16) { e0 = cmul(v[m], omsc); e1 = cmul(v[m + 1], omsc); }
+                            else { e0 = v[m] * sc; e1 = v[m + 1] * sc; }
+                            const R sx = odd ? e0.x : e1.x, sy = odd ? e0.y : e1.y;       // what the neighbour stores for me
+                            const R kx = odd ? e1.x : e0.x, ky = odd ? e1.y : e0.y;       // what I store myself
+                            const R rx = __builtin_bit_cast(R, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sx), 0xB1, 0xf, 0xf, true));
+                            const R ry = __builtin_bit_cast(R, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sy), 0xB1, 0xf, 0xf, true));
+                            const float4 out = odd ? make_float4(rx, ry, kx, ky) : make_float4(kx, ky, rx, ry);
+                            *reinterpret_cast<float4*>(pbase + (size_t)m * gh_step) = out;
+                        });
+                    } else {
+                        static_for<0, 16>([&](auto m_) {
+                            constexpr int m = m_;
+                            if ((smask >> m) & 1u) {
+                                if constexpr (NS < 16) (ghr + (size_t)m * gh_step)[gh_lane] = cmul(v[m], omsc);
+                                else (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
+                            }
+                        });
+                    }
+                } else
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
                     if ((smask >> m) & 1u) {
