@@ -71,6 +71,9 @@ struct Geo {
 // hgs_set_array / hgs_get_array and the spot kernels apply it.
 // Tile-resident column kernel: pick the column of the pass out of the tile registers with a register-relative move
 // (the pass index is uniform: s_set_gpr_idx + v_mov, 24 instructions per pass) instead of 84 v_cndmask
+#ifndef HGS_ROW_LD16
+#define HGS_ROW_LD16 1      // ... and load H in 16-byte pieces
+#endif
 #ifndef HGS_ROW_ST16
 #define HGS_ROW_ST16 1      // dense fp32 row launches store G in 16-byte pieces (lane pairs swap one value per slot pair)
 #endif
@@ -689,6 +692,27 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 HGS_T(fft.tr_n, 32);
                 if (rbase + row_stride < g.Sh) prefetch_row(rbase + row_stride);
                 HGS_T(fft.tr_n, 33);
+            } else {
+            // dense fp32 launches: the H row in 16-byte pieces, the lane pair swapping one value per slot pair (see the G stores)
+            bool wide = false;
+            if constexpr (sizeof(R) == 4 && HGS_ROW_LD16 && T % 64 == 0) wide = a.load_mask == nullptr && valid;
+            if (wide) {
+                if constexpr (sizeof(R) == 4 && HGS_ROW_LD16 && T % 64 == 0) {
+                    const bool odd = (j & 1) != 0;
+                    const Cx<R>* pbase = ghr + (gh_lane - (odd ? 1u : 0u)) + (odd ? (size_t)gh_step : (size_t)0);
+                    float4 q[8];
+                    static_for<0, 8>([&](auto p_) { constexpr int m = 2 * p_; q[p_] = *reinterpret_cast<const float4*>(pbase + (size_t)m * gh_step); });
+                    static_for<0, 8>([&](auto p_) {
+                        constexpr int m = 2 * p_;
+                        const R sx = odd ? q[p_].x : q[p_].z, sy = odd ? q[p_].y : q[p_].w;      // the neighbour's value
+                        const R rx = __builtin_bit_cast(R, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sx), 0xB1, 0xf, 0xf, true));
+                        const R ry = __builtin_bit_cast(R, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sy), 0xB1, 0xf, 0xf, true));
+                        const Cx<R> h0 = odd ? mk<R>(rx, ry) : mk<R>(q[p_].x, q[p_].y);
+                        const Cx<R> h1 = odd ? mk<R>(q[p_].z, q[p_].w) : mk<R>(rx, ry);
+                        if constexpr (NS < 16) { v[m] = h0; v[m + 1] = h1; }
+                        else { v[m] = h0 * sgn; v[m + 1] = h1 * sgn; }
+                    });
+                }
             } else
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
@@ -697,6 +721,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 if constexpr (NS < 16) v[m] = h;
                 else v[m] = h * sgn;
             });
+            }
             if constexpr (SPLIT) {
                 const R ws = a.wscale[b];
                 const Cx<R>* gh2r = a.gh2 + (size_t)b * g.Sh * g.Pw + (size_t)rr * 4;
