@@ -488,3 +488,30 @@ def test_bench_gpus_n_rejects_a_mismatched_launch():
     assert r.returncode != 0
     assert "WORLD_SIZE=2" in r.stderr
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
+def test_update_flags_precedence_and_verbose_print(capsys):
+    """_update_flags (_hologram.py:1370-1424): method defaults only where no value exists yet (flags persist between calls),
+    keyword flags over both, stat_groups / feedback checked against FEEDBACK_OPTIONS right before they are stored (a rejected
+    name leaves the earlier updates in place); verbose > 1 prints the flags the method reads."""
+    h = Hologram(synth.random_target(1, (64, 64)), phase=np.zeros((64, 64), np.float32))
+    h._update_flags("WGS-Kim", False, None, [], feedback_exponent=0.5)
+    assert h.flags["method"] == "WGS-Kim" and h.flags["feedback_exponent"] == 0.5 and h.flags["fix_phase_iteration"] == 10
+    assert h.flags["fixed_phase"] is False and h.flags["stat_groups"] == [] and h.flags["feedback"] == "computational"
+    h.flags["fixed_phase"] = True
+    h._update_flags("WGS-Leonardo", False, "computational", ["computational"])
+    assert h.flags["feedback_exponent"] == 0.5 and h.flags["fixed_phase"] is True            # kept: defaults never override
+    assert h.flags["stat_groups"] == ["computational"]
+    with pytest.raises(ValueError, match="Statistics group 'nope'"):
+        h._update_flags("GS", False, None, ["nope"], some_flag=3)
+    assert h.flags["method"] == "GS" and h.flags["some_flag"] == 3 and h.flags["stat_groups"] == ["computational"]
+    with pytest.raises(ValueError, match="Feedback 'bad'"):
+        h._update_flags("GS", False, "bad", ["computational_spot"])
+    assert h.flags["stat_groups"] == ["computational_spot"] and h.flags["feedback"] == "computational"
+    with pytest.raises(ValueError, match="Unrecognized method 'XYZ'"):
+        h._update_flags("XYZ", False, None, [])
+    capsys.readouterr()
+    h._update_flags("WGS-Kim", 2, None, [], fix_phase_iteration=7)
+    out = capsys.readouterr().out
+    assert "Optimizing with 'WGS-Kim' using the following method-specific flags:" in out
+    assert "'fix_phase_iteration': 7" in out and "'method'" not in out and "'some_flag'" not in out
