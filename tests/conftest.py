@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+try:        # before any engine is loaded: torch's bundled HIP runtime has to open the GPU first (slmsuite_amd._lib.load),
+    import torch  # noqa: F401  and a test module that imports torch later would find "No HIP GPUs are available"
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
