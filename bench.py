@@ -572,10 +572,10 @@ def pmc_traffic(args, kernel_substrings):
                  "(gfx950 half-count), WRITE_SIZE as reported; the fabric counters include Infinity-Cache hits")
 
 
-def _gather_ints(dist, torch, dev, value, world):
+def _gather_ints(dist, torch, dev, value, world, group=None):
     t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
     out = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
+    dist.all_gather(out, t, group=group)
     return [int(o.item()) for o in out]
 
 
@@ -633,20 +633,25 @@ def main():
     elif local_rank >= n_dev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} has no device ({n_dev} visible); --gpus {args.gpus} needs one GPU per rank")
     dist = None
-    on_device = True           # tensors of the timing collectives: device memory over RCCL, host memory over gloo
+    ctl = None                 # control group (None = the default group, gloo)
+    data_group = None          # the group of the final gather: RCCL (created after the timed regions) or the gloo default
+    on_device = True           # the phase masks of the final gather: device memory over RCCL, host memory over gloo
     if (world > 1 or args.force_dist) and not args.pmc_child:
         import torch.distributed as dist
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)         # --force-dist outside a launcher: a one-rank group
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-            on_device = False
+        # The process group the timed regions see is gloo: the barriers of the protocol are host rendezvous (every rank has
+        # synchronised its engine streams before it arrives) and the scalars of the max-over-ranks are host numbers.  RCCL
+        # carries what north_star gives it -- the gather of the phase masks -- and its communicator is created only then:
+        # measured on the one-GPU box, an initialised RCCL communicator costs the two stream groups of a rank their overlap
+        # (cfg 3: 15.4 k -> 14.2 k it/s, the one-group rate) and an RCCL barrier 2.2 ms per region, neither of which the
+        # one-GPU line of the same bench pays.
+        dist.init_process_group("gloo")
+        on_device = args.backend == "nccl"
         if dist.get_world_size() != args.gpus and not args.force_dist:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus} asked for")
-    coll_dev = torch.device("cuda", local_rank) if on_device else torch.device("cpu")
+    coll_dev = torch.device("cpu")
 
     from slmsuite_amd import _lib as L
 
@@ -676,7 +681,7 @@ def main():
             pb.engine.sync()
             torch.cuda.synchronize()
             if dist is not None:
-                dist.barrier()
+                dist.barrier(group=ctl)
         ws, evs, rws = [], [], []
         for _ in range(args.reps):
             sync_all()
@@ -687,9 +692,9 @@ def main():
             if dist is not None:        # the slowest rank counts
                 tmax = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
                 every = [torch.zeros_like(tmax) for _ in range(world)]
-                dist.all_gather(every, tmax)
+                dist.all_gather(every, tmax, group=ctl)
                 rws.append([float(x.item()) for x in every])
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
                 mine = float(tmax.item())
             ws.append(mine)
             evs.append(ms_ev)
@@ -738,24 +743,31 @@ def main():
     # final gather of the phase masks over RCCL, device memory -> RCCL, timed separately
     gather_ms, gathered, group_info = None, None, None
     if dist is not None and not compressed and not refbench:
+        if on_device:
+            try:
+                data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:          # (older torch: no device_id argument)
+                data_group = dist.new_group(backend="nccl")
         torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier(group=ctl)
         t1 = time.perf_counter()
         ph = prob.phases_device(torch, local_rank)
         if not on_device:
             ph = ph.cpu()
         out = [torch.empty_like(ph) for _ in range(world)]
-        dist.all_gather(out, ph)
+        dist.all_gather(out, ph, group=data_group)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
         # every rank must now hold every rank's masks: finite, and its own shard back unchanged
         ok = all(bool(torch.isfinite(o).all().item()) for o in out) and bool(torch.equal(out[rank], ph))
         flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
         gathered = {"masks": world * args.batch, "bytes": world * ph.numel() * ph.element_size(), "verified_on_every_rank": bool(flag.item() == 1.0)}
     if dist is not None:
-        group_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
-                      "devices": sorted(set(_gather_ints(dist, torch, coll_dev, local_rank, world)))}
+        group_info = {"backend": dist.get_backend(data_group), "ranks": dist.get_world_size(data_group),
+                      "devices": sorted(set(_gather_ints(dist, torch, coll_dev, local_rank, world, ctl))),
+                      "barriers": "gloo (host rendezvous after hgs_sync; the RCCL communicator of the gather is created after "
+                                  "the timed regions)" if on_device else "gloo"}
 
     ref_methods = None
     if refbench and not args.no_extra_pass:
