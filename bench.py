@@ -37,9 +37,10 @@ Workloads (``--workload``):
              them (host bookkeeping and the trailing transform included); --steps = maxiter; the four methods of the
              reference's parametrisation are all timed (``methods``), ``value`` is --method (default WGS-Leonardo)
 
-Timing protocol: W warm-up steps, then ``--reps`` (default 10) repetitions of the timed region -- EXACTLY K
+Timing protocol: W warm-up steps, then ``--reps`` (default 40) repetitions of the timed region -- EXACTLY K
 steps between barrier + synchronize on both sides, the slowest rank counting -- and ``value`` is K / the MEDIAN
-repetition; the spread is reported (``ms_per_step_min`` / ``_max``), with more than one rank also the rate of every
+repetition; the spread is reported (``ms_per_step_min`` / ``_max``; the first regions after a short warm-up run on clocks
+that are still settling, which is why there are forty of them), with more than one rank also the rate of every
 rank (``per_rank_its``) so that a straggler shows.
 
 For spot workloads (and the MRAF target, whose frame outside the noise box is empty) the headline is
@@ -121,7 +122,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="K steps per timed repetition (default 200; refbench: 20)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--reps", type=int, default=10, help="repetitions of the K-step timed region; the median is reported")
+    ap.add_argument("--reps", type=int, default=40,
+                    help="repetitions of the K-step timed region; the median is reported (min / max beside it).  40 because the "
+                         "GPU's clocks take about 15 ms of work to settle after an idle spell: with ten 20-step regions (16 ms) the "
+                         "median still sat on the ramp (12.6 k it/s against 13.1 k after 200 warm-up steps, same regions)")
     ap.add_argument("--batch", type=int, default=None, help="independent holograms per GPU (cfg3: 8)")
     ap.add_argument("--streams", type=int, default=None,
                     help="stream groups a rank's holograms are split over (one engine and HIP stream each; launches of "
