@@ -19,7 +19,9 @@ workload is BASELINE.json config 2 (the configuration the metric is quoted on): 
 spots (pitch 64 px) on a 4096 x 4096 padded grid, SLM 1152 x 1920, WGS-Leonardo, fp32.  Each rank owns
 ``--batch`` independent holograms (weak scaling; ``--workload cfg3`` = cfg 2 with 8 per
 GPU); the only collective is the final all-gather of the phase masks (reported as gather_ms, outside
-the timed region, fed straight from device memory).
+the timed region, fed straight from device memory).  It runs after the line has been built from the timed
+regions and under a watchdog (``--gather-timeout``): a communicator that cannot be created, or a collective
+that never returns, costs the line its gather fields (``gathered.error`` says why), not the measurement.
 
 Workloads (``--workload``):
   cfg2       headline (above)                 cfg3      the same with --batch 8
@@ -134,6 +136,8 @@ def parse():
                     help="default: cfg2 on one GPU, cfg3 (cfg 2 with 8 holograms per GPU, BASELINE configs[2]) on several")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo: self-test of the launcher on one device)")
+    ap.add_argument("--gather-timeout", type=float, default=180.0,
+                    help="seconds the final all-gather of the phase masks may take before the line is printed without it")
     ap.add_argument("--share-devices", action="store_true",
                     help="let ranks share GPUs (device = LOCAL_RANK %% device_count); needs --backend gloo -- RCCL wants one "
                          "device per rank.  Launcher self-test only: the line is marked, its value is not a scaling figure")
@@ -744,34 +748,7 @@ def main():
             prob.engine.profile_enable(False)
         prob.engine.set_option(L.OPT_SPARSE_COLUMNS, 0)
 
-    # final gather of the phase masks over RCCL, device memory -> RCCL, timed separately
-    gather_ms, gathered, group_info = None, None, None
-    if dist is not None and not compressed and not refbench:
-        if on_device:
-            try:
-                data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            except TypeError:          # (older torch: no device_id argument)
-                data_group = dist.new_group(backend="nccl")
-        torch.cuda.synchronize()
-        dist.barrier(group=ctl)
-        t1 = time.perf_counter()
-        ph = prob.phases_device(torch, local_rank)
-        if not on_device:
-            ph = ph.cpu()
-        out = [torch.empty_like(ph) for _ in range(world)]
-        dist.all_gather(out, ph, group=data_group)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
-        # every rank must now hold every rank's masks: finite, and its own shard back unchanged
-        ok = all(bool(torch.isfinite(o).all().item()) for o in out) and bool(torch.equal(out[rank], ph))
-        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
-        gathered = {"masks": world * args.batch, "bytes": world * ph.numel() * ph.element_size(), "verified_on_every_rank": bool(flag.item() == 1.0)}
-    if dist is not None:
-        group_info = {"backend": dist.get_backend(data_group), "ranks": dist.get_world_size(data_group),
-                      "devices": sorted(set(_gather_ints(dist, torch, coll_dev, local_rank, world, ctl))),
-                      "barriers": "gloo (host rendezvous after hgs_sync; the RCCL communicator of the gather is created after "
-                                  "the timed regions)" if on_device else "gloo"}
+    gather_ms, gathered, group_info = None, None, None       # filled in by the final gather, after the line is built
 
     ref_methods = None
     if refbench and not args.no_extra_pass:
@@ -922,10 +899,6 @@ def main():
         if rank_walls:
             med = [sorted(r[i] for r in rank_walls)[len(rank_walls) // 2] for i in range(world)]
             line["per_rank_its"] = [args.batch * args.steps / t for t in med]
-        if group_info is not None:
-            line["process_group"] = group_info      # read back from the group: backend ("nccl" = RCCL), ranks, device per rank
-            line["rccl_ranks"] = group_info["ranks"] if group_info["backend"] == "nccl" else 0
-            line["gathered"] = gathered
         if one_per_gpu is not None:
             line["one_hologram_per_gpu"] = one_per_gpu
         if args.share_devices:
@@ -947,7 +920,68 @@ def main():
                 "col_kernel_us": None if sprof is None else sprof["col_fused"]["ms"] * 1e3 / max(1, sprof["col_fused"]["launches"]),
                 "row_kernel_us": None if sprof is None else sprof["row"]["ms"] * 1e3 / max(1, sprof["row"]["launches"]),
             }
-        print(json.dumps(line))
+    else:
+        line = None
+
+    # Final gather of the phase masks over RCCL, device memory -> RCCL, timed separately.  It runs AFTER the
+    # line has been built from the timed regions and under a watchdog: a communicator that cannot be created or a collective
+    # that never returns costs the line its gather fields, not the measurement.
+    if dist is not None:
+        import threading
+        finished = threading.Event()
+
+        def give_up():
+            if finished.is_set():
+                return
+            if rank == 0:
+                line["gathered"] = {"error": f"the all-gather of the phase masks did not return within {args.gather_timeout:g} s; "
+                                             "the timed regions do not depend on it"}
+                line["rccl_ranks"] = 0
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.gather_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if not compressed and not refbench:
+                if on_device:
+                    try:
+                        data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                    except TypeError:          # (older torch: no device_id argument)
+                        data_group = dist.new_group(backend="nccl")
+                torch.cuda.synchronize()
+                dist.barrier(group=ctl)
+                t1 = time.perf_counter()
+                ph = prob.phases_device(torch, local_rank)
+                if not on_device:
+                    ph = ph.cpu()
+                out = [torch.empty_like(ph) for _ in range(world)]
+                dist.all_gather(out, ph, group=data_group)
+                torch.cuda.synchronize()
+                gather_ms = (time.perf_counter() - t1) * 1e3
+                # every rank must now hold every rank's masks: finite, and its own shard back unchanged
+                ok = all(bool(torch.isfinite(o).all().item()) for o in out) and bool(torch.equal(out[rank], ph))
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+                gathered = {"masks": world * args.batch, "bytes": world * ph.numel() * ph.element_size(),
+                            "verified_on_every_rank": bool(flag.item() == 1.0)}
+            group_info = {"backend": dist.get_backend(data_group), "ranks": dist.get_world_size(data_group),
+                          "devices": sorted(set(_gather_ints(dist, torch, coll_dev, local_rank, world, ctl))),
+                          "barriers": "gloo (host rendezvous after hgs_sync; the RCCL communicator of the gather is created after "
+                                      "the timed regions)" if on_device else "gloo"}
+        except Exception as exc:           # noqa: BLE001 -- whatever the communicator raises: reported, not fatal
+            gathered = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        finished.set()
+        watchdog.cancel()
+        if rank == 0:
+            line["gather_ms"] = gather_ms
+            if group_info is not None:
+                line["process_group"] = group_info      # read back from the group: backend ("nccl" = RCCL), ranks, device per rank
+                line["rccl_ranks"] = group_info["ranks"] if group_info["backend"] == "nccl" else 0
+            line["gathered"] = gathered
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     prob.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -116,3 +116,16 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     r, lines = _bench(["--gpus", str(n + 1), "--steps", "2", "--warmup", "1"])
     assert r.returncode != 0 and lines == []
     assert f"only {n} GPU" in r.stderr
+
+
+def test_bench_line_survives_a_gather_that_does_not_return():
+    """The final all-gather runs after the line is built and under a watchdog: with no time at all for it (the two ranks
+    are still creating the group when the timer fires) the line comes out anyway -- value from the timed regions, the gather
+    fields replaced by the reason -- and the launch ends with exit code 0."""
+    r, lines = _bench(["--gpus", "2", "--backend", "gloo", "--share-devices", "--steps", "4", "--warmup", "2", "--reps", "2",
+                       "--no-roofline-pass", "--no-extra-pass", "--gather-timeout", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["per_rank_its"]) == 2
+    assert "did not return" in d["gathered"]["error"] and d["rccl_ranks"] == 0 and d["gather_ms"] is None
