@@ -1,0 +1,178 @@
+"""
+Randomised differential test (MI355X): every seed draws a class, a geometry, a kind of target, a method, its options,
+the optional inputs (array amplitude, depth kernel, statistics groups, feedback mode) and the engine's column policy, and
+runs the same few loop bodies on the engine and on the CPU oracle.  The deterministic sweep (test_gpu_sweep.py) walks a
+grid; this one lands between its points -- the kernel variant a case dispatches to follows from the shapes (register
+slots the SLM occupies, tile / per-column / Bluestein paths, column lists), so random geometries visit variants no
+hand-written case names.  float64 pins the logic at 1e-9; float32 is measured against the float64 run of the same inputs,
+next to the float32 oracle's own distance from it.
+A failing seed is reproduced with ``pytest tests/test_fuzz_parity.py -k "[<seed>]"``.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2, phase_rel_l2, report
+from oracle import hgs_oracle as orc
+from slmsuite_amd import _lib as L
+from slmsuite_amd import synth
+from slmsuite_amd.holography.algorithms import Hologram, SpotHologram
+
+pytestmark = pytest.mark.gpu
+
+POW2 = [64, 128, 256, 512, 1024, 2048]
+METHODS = [("GS", {}), ("WGS-Leonardo", {}), ("WGS-Kim", {"fix_phase_iteration": 1}), ("WGS-Kim", {"fix_phase_iteration": 2}),
+           ("WGS-Nogrette", {}), ("WGS-Wu", {}), ("WGS-tanh", {})]
+
+
+def _axis(rng, big):
+    """A padded length: mostly powers of two, sometimes a general one (Bluestein path)."""
+    if rng.random() < 0.25:
+        return int(rng.integers(40, 400))
+    return int(rng.choice(POW2[: 6 if big else 5]))
+
+
+def draw(seed, dtype):
+    rng = np.random.default_rng(seed)
+    H, W = _axis(rng, True), _axis(rng, True)
+    while H * W > (1 << 21):                       # keeps the oracle at a fraction of a second per body
+        H, W = _axis(rng, False), _axis(rng, False)
+    sh = int(rng.integers(max(4, H // 8), H + 1))
+    sw = int(rng.integers(max(4, W // 8), W + 1))
+    if rng.random() < 0.2:
+        sh, sw = H, W                              # SLM as large as the grid: no padding at all
+    case = {"shape": (H, W), "slm": (sh, sw), "kind": str(rng.choice(["image", "image", "mraf", "blocks", "spots", "spots"]))}
+    m, kw = METHODS[int(rng.integers(len(METHODS)))]
+    case["method"], case["kw"] = m, dict(kw)
+    if m != "GS" and rng.random() < 0.4:
+        case["kw"]["feedback_exponent"] = float(rng.uniform(0.4, 1.0))
+    case["amp"] = bool(rng.random() < 0.4)
+    case["kernel"] = bool(rng.random() < 0.3)
+    case["sparse"] = int(rng.integers(2))
+    case["stats"] = bool(rng.random() < 0.5)
+    case["seed"] = seed
+    if case["kind"] == "mraf":
+        case["kw"]["mraf_factor"] = float(rng.choice([0.3, 0.5, 1.0]))
+        if rng.random() < 0.4:
+            case["kw"]["zero_factor"] = 1.0
+    if case["kind"] == "spots":
+        n = int(rng.integers(3, 40))
+        # distinct pixels, two apart at least (one pixel per spot; the integration window of the spot statistics stays 1 .. 3)
+        ky = rng.choice(np.arange(2, H - 2, 3), size=min(n, (H - 4) // 3), replace=False)
+        kx = rng.choice(np.arange(2, W - 2, 3), size=len(ky), replace=len(ky) > (W - 4) // 3)
+        pts = np.unique(np.stack([kx, ky]), axis=1)
+        case["spots"] = pts.astype(float)
+        case["feedback"] = str(rng.choice(["computational", "computational_spot", "external_spot"]))
+    return case
+
+
+def build(case, dtype, engine=True):
+    H, W = case["shape"]
+    slm = case["slm"]
+    seed = case["seed"]
+    # every input is drawn in float32 and cast: a float64 run of a case then starts from exactly the float32 run's numbers
+    common = dict(slm_shape=slm, dtype=dtype)
+    if case["amp"]:
+        common["amp"] = synth.gaussian_amp(slm, dtype=np.float32).astype(dtype)
+    if case["kernel"]:
+        common["propagation_kernel"] = (0.3 * synth.seed_phase(seed + 5, slm)).astype(np.float32).astype(dtype)
+    phase = synth.seed_phase(seed + 1, slm, dtype=np.float32).astype(dtype)
+    opts = {L.OPT_SPARSE_COLUMNS: case["sparse"]}
+    if case["kind"] == "spots":
+        o = orc.OracleSpotHologram((H, W), case["spots"], phase=phase.copy(), **common)
+        ext = o.spot_amp * (1 + 0.1 * np.cos(np.arange(len(o.spot_amp))))
+        o.external_spot_amp = ext.copy()
+        if not engine:
+            return None, o
+        h = SpotHologram((H, W), case["spots"], basis="knm", phase=phase.copy(), engine_options=opts, **common)
+        h.external_spot_amp = ext.copy()
+        return h, o
+    target = synth.random_target(seed + 2, (H, W), 0.2, 1.0, dtype=np.float32).astype(dtype)
+    if case["kind"] == "mraf":
+        target[: max(1, H // 5), :] = np.nan
+        target[:, : max(1, W // 6)] = 0
+    elif case["kind"] == "blocks":                 # a mostly empty image: the engine's column lists on a plain Hologram
+        keep = np.zeros((H, W), bool)
+        rng = np.random.default_rng(seed + 3)
+        for _ in range(3):
+            r, c = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+            keep[r:r + int(rng.integers(1, 9)), c:c + int(rng.integers(1, 9))] = True
+        target = np.where(keep, target, 0).astype(dtype)
+    o = orc.OracleHologram(target.copy(), phase=phase.copy(), **common)
+    h = Hologram(target.copy(), phase=phase.copy(), engine_options=opts, **common) if engine else None
+    return h, o
+
+
+def run(case, dtype, maxiter, engine=True):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        h, o = build(case, dtype, engine)
+        kw = dict(case["kw"])
+        groups = []
+        if case["stats"]:
+            groups = ["computational_spot"] if case["kind"] == "spots" else ["computational"]
+        if case["kind"] == "spots":
+            kw["feedback"] = case["feedback"]
+        if engine:
+            h.optimize(case["method"], maxiter=maxiter, verbose=False, stat_groups=groups, **kw)
+        o.optimize(case["method"], maxiter=maxiter, stat_groups=groups, **kw)
+    return h, o, groups
+
+
+def errors(case, h, o):
+    """Relative L2 distances between two runs of a case (engine or oracle objects).  The phase is compared where the source
+    lights the SLM (the phase of an un-illuminated pixel is not recoverable); spot arrays at their spots."""
+    lit = np.ones(case["slm"], bool)
+    if case["amp"]:
+        amp = np.asarray(o.amp)
+        lit = amp > 1e-2 * amp.max()
+    ph = phase_rel_l2(np.asarray(h.phase)[lit], np.asarray(o.phase)[lit])
+    if case["kind"] == "spots":
+        kx, ky = np.rint(case["spots"]).astype(int)
+        return dict(phase=ph, amp_ff=rel_l2(h.amp_ff[ky, kx], o.amp_ff[ky, kx]), weights=rel_l2(h.weights[ky, kx], o.weights[ky, kx]))
+    return dict(phase=ph, amp_ff=rel_l2(h.amp_ff, o.amp_ff), weights=rel_l2(np.nan_to_num(h.weights), np.nan_to_num(o.weights)))
+
+
+def describe(case):
+    return (f"{case['kind']} {case['shape']} slm {case['slm']} {case['method']} {case['kw']} amp={case['amp']} "
+            f"kernel={case['kernel']} sparse={case['sparse']} stats={case['stats']} {case.get('feedback', '')}")
+
+
+@pytest.mark.parametrize("seed", range(5000, 5048))
+def test_random_case_fp64(seed):
+    case = draw(seed, np.float64)
+    h, o, groups = run(case, np.float64, 3)
+    errs = errors(case, h, o)
+    report(f"fuzz fp64 [{seed}] {describe(case)}", **errs)
+    assert max(errs.values()) < 1e-9, (describe(case), errs)
+    assert h.stats["flags"].get("fixed_phase") == o.stats["flags"].get("fixed_phase"), describe(case)
+    for g in groups:
+        for key in ("efficiency", "uniformity"):
+            np.testing.assert_allclose(h.stats["stats"][g][key], o.stats["stats"][g][key], rtol=1e-8, atol=1e-12, err_msg=describe(case))
+    h._release_engine()
+
+
+FP32_FLOOR = {"phase": 3e-5, "amp_ff": 1e-5, "weights": 1e-5}      # the per-body tolerances of the step tests
+
+
+@pytest.mark.parametrize("seed", range(6000, 6032))
+def test_random_case_fp32(seed):
+    """
+    Two bodies (one weight update) in float32.  A dense pixel-wise rule amplifies rounding (a speckle zero under
+    a non-zero target turns one ulp of |F| into a large step of its weight), so the distance between two float32
+    implementations has no flat bound; the yardstick is the float64 run of the same float32 inputs: the engine may be as
+    far from it as the step tolerances allow, or five times as far as the float32 ORACLE is -- whichever is larger.  (Over
+    these seeds the ratio engine / oracle is 0.4 .. 1.5 on every quantity with one exception, 3.5 on the weights of seed
+    6024: one pixel -- a speckle zero of body 0 whose weight grew 67-fold -- carries 94 % of that distance in the engine's
+    run and 63 % in the oracle's, ``tools/fuzz_case.py 6024``; hence five and not three.)
+    """
+    case = draw(seed, np.float32)
+    h, o32, _ = run(case, np.float32, 2)
+    _, o64, _ = run(case, np.float64, 2, engine=False)
+    direct, eng, ref = errors(case, h, o32), errors(case, h, o64), errors(case, o32, o64)
+    report(f"fuzz fp32 [{seed}] {describe(case)}", **{f"{k}_vs_f64": v for k, v in eng.items()},
+           **{f"{k}_oracle32_vs_f64": v for k, v in ref.items()}, **{f"{k}_vs_oracle32": v for k, v in direct.items()})
+    for k, floor in FP32_FLOOR.items():
+        assert eng[k] < max(floor, 5 * ref[k]), (describe(case), k, eng, ref)
+    h._release_engine()
