@@ -33,11 +33,17 @@ def _axis(rng, big):
     return int(rng.choice(POW2[: 6 if big else 5]))
 
 
-def draw(seed, dtype):
+LARGE = [(4096, 4096), (4096, 8192), (8192, 4096), (2048, 4096), (4096, 2048), (8192, 2048), (2048, 8192), (4096, 1024)]
+
+
+def draw(seed, dtype, large=False):
     rng = np.random.default_rng(seed)
-    H, W = _axis(rng, True), _axis(rng, True)
-    while H * W > (1 << 21):                       # keeps the oracle at a fraction of a second per body
-        H, W = _axis(rng, False), _axis(rng, False)
+    if large:                                      # the tile-resident kernels' sizes (4096 / 8192 rows) and their neighbours
+        H, W = LARGE[int(rng.integers(len(LARGE)))]
+    else:
+        H, W = _axis(rng, True), _axis(rng, True)
+        while H * W > (1 << 21):                   # keeps the oracle at a fraction of a second per body
+            H, W = _axis(rng, False), _axis(rng, False)
     sh = int(rng.integers(max(4, H // 8), H + 1))
     sw = int(rng.integers(max(4, W // 8), W + 1))
     if rng.random() < 0.2:
@@ -172,6 +178,21 @@ def test_random_case_fp32(seed):
     _, o64, _ = run(case, np.float64, 2, engine=False)
     direct, eng, ref = errors(case, h, o32), errors(case, h, o64), errors(case, o32, o64)
     report(f"fuzz fp32 [{seed}] {describe(case)}", **{f"{k}_vs_f64": v for k, v in eng.items()},
+           **{f"{k}_oracle32_vs_f64": v for k, v in ref.items()}, **{f"{k}_vs_oracle32": v for k, v in direct.items()})
+    for k, floor in FP32_FLOOR.items():
+        assert eng[k] < max(floor, 5 * ref[k]), (describe(case), k, eng, ref)
+    h._release_engine()
+
+
+@pytest.mark.parametrize("seed", range(7000, 7012))
+def test_random_large_case_fp32(seed):
+    """The same at 4096 / 8192 points per axis, where the tile-resident column kernels, the row kernels that walk rows and the
+    tile lists run: which variant a case gets follows from the random SLM shape (register slots occupied, shifted rows)."""
+    case = draw(seed, np.float32, large=True)
+    h, o32, _ = run(case, np.float32, 2)
+    _, o64, _ = run(case, np.float64, 2, engine=False)
+    direct, eng, ref = errors(case, h, o32), errors(case, h, o64), errors(case, o32, o64)
+    report(f"fuzz large fp32 [{seed}] {describe(case)}", **{f"{k}_vs_f64": v for k, v in eng.items()},
            **{f"{k}_oracle32_vs_f64": v for k, v in ref.items()}, **{f"{k}_vs_oracle32": v for k, v in direct.items()})
     for k, floor in FP32_FLOOR.items():
         assert eng[k] < max(floor, 5 * ref[k]), (describe(case), k, eng, ref)
