@@ -197,3 +197,68 @@ def test_random_large_case_fp32(seed):
     for k, floor in FP32_FLOOR.items():
         assert eng[k] < max(floor, 5 * ref[k]), (describe(case), k, eng, ref)
     h._release_engine()
+
+
+# ---- CompressedSpotHologram ---------------------------------------------------------------------------------------------
+def draw_compressed(seed):
+    rng = np.random.default_rng(seed)
+    case = {"seed": seed, "slm": (int(rng.integers(12, 140)), int(rng.integers(12, 180))), "N": int(rng.choice([3, 17, 64, 65, 137, 300]))}
+    case["basis"] = str(rng.choice(["kxy2", "kxy3", "zern"]))
+    m, kw = METHODS[int(rng.integers(len(METHODS)))]
+    case["method"], case["kw"] = m, dict(kw)
+    case["amp"] = bool(rng.random() < 0.4)
+    case["kernel"] = bool(rng.random() < 0.4)
+    case["spot_amp"] = bool(rng.random() < 0.5)
+    # the three forms of the transform pair: matrix cores where the basis factorises, run kernels, per-pixel kernels
+    case["opts"] = {L.OPT_SEPARABLE: int(rng.integers(2)), L.OPT_RUN_KERNELS: int(rng.integers(2))}
+    if rng.random() < 0.5:
+        case["opts"][L.OPT_SEPARABLE_MIN_SPOTS] = 1
+    return case
+
+
+def build_compressed(case, dtype):
+    from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
+    from slmsuite_amd.holography import toolbox
+    from slmsuite_amd.holography.algorithms import CompressedSpotHologram
+    slm, N, seed = case["slm"], case["N"], case["seed"]
+    fs = SimpleFourierSLM(SimpleSLM(slm, pitch_um=(8, 8), wav_um=0.78))
+    v = np.vstack([0.03 * (synth.uniform01(seed, (N,), k) - 0.5) for k in range(2)])
+    basis = "kxy"
+    if case["basis"] != "kxy2":
+        v = np.vstack((v, 4e-6 * (synth.uniform01(seed, (N,), 2) - 0.5)))
+    if case["basis"] == "zern":                    # tilts + focus + both astigmatisms: not separable
+        z, _ = toolbox.convert_vector_zernike(v, "kxy", fs)
+        v = np.vstack([z, np.pi * (2 * synth.uniform01(seed, (2, N), 3) - 1)])
+        basis = np.array([2, 1, 4, 3, 5])
+    common = dict(dtype=dtype)
+    amp = None
+    if case["amp"]:                                # (the class takes its amplitude from the SLM's measured source, _feedback.py:86-101)
+        amp = synth.gaussian_amp(slm, dtype=np.float32).astype(dtype)
+        fs.slm._get_source_amplitude = lambda: amp
+    if case["kernel"]:
+        common["propagation_kernel"] = (0.3 * synth.seed_phase(seed + 5, slm)).astype(np.float32).astype(dtype)
+    spot_amp = (0.5 + synth.uniform01(seed + 1, (N,), 0)) if case["spot_amp"] else None
+    phase = synth.seed_phase(seed + 2, slm, dtype=np.float32).astype(dtype)
+    h = CompressedSpotHologram(v, basis=basis, spot_amp=spot_amp, cameraslm=fs, engine_options=case["opts"], **common)
+    h.reset_phase(phase.copy())
+    o = orc.OracleCompressedSpotHologram(h.spot_zernike, h._xg, h._yg, zernike_basis=h.zernike_basis, spot_amp=spot_amp,
+                                         amp=amp, phase=phase.copy(), **common)
+    return h, o
+
+
+@pytest.mark.parametrize("seed", range(8000, 8024))
+def test_random_compressed_case_fp64(seed):
+    """Free-floating spots: 2-D / 3-D tilts (separable: matrix-core form allowed or not) and a five-term Zernike basis, spot
+    counts around the chunk sizes of the kernels, the run / per-pixel forms -- three bodies in float64 against the oracle."""
+    case = draw_compressed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        h, o = build_compressed(case, np.float64)
+        h.optimize(case["method"], maxiter=3, verbose=False, **case["kw"])
+        o.optimize(case["method"], maxiter=3, **case["kw"])
+    errs = dict(phase=phase_rel_l2(h.phase, o.phase), amp_ff=rel_l2(h.amp_ff, o.amp_ff), weights=rel_l2(h.weights, o.weights),
+                farfield=rel_l2(h.farfield, o.farfield))
+    report(f"fuzz compressed fp64 [{seed}] {case}", **errs)
+    assert max(errs.values()) < 1e-9, (case, errs)
+    assert h.stats["flags"].get("fixed_phase") == o.stats["flags"].get("fixed_phase"), case
+    h._release_engine()
