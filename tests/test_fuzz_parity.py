@@ -262,3 +262,128 @@ def test_random_compressed_case_fp64(seed):
     assert max(errs.values()) < 1e-9, (case, errs)
     assert h.stats["flags"].get("fixed_phase") == o.stats["flags"].get("fixed_phase"), case
     h._release_engine()
+
+
+# ---- sequences of operations on one object ----------------------------------------------------------------------------------
+def _ops(rng, n, spots):
+    """A random walk through the class surface: what a session does to one hologram between its optimize() calls."""
+    names = ["optimize", "optimize", "optimize", "optimize_callback", "new_phase", "tensor_phase", "scale_weights", "new_target", "reset",
+             "read", "column_policy", "reset_phase", "release"]
+    if spots:
+        names.remove("new_target")                 # (a SpotHologram's raster follows from its spots)
+    return [str(rng.choice(names)) for _ in range(n)]
+
+
+def walk(seed, tol=1e-9, log=None):
+    """The random walk of test_random_operation_sequence_fp64 (``log``: a callable that gets one line per step)."""
+    rng = np.random.default_rng(seed)
+    dt = np.float64
+    spots = bool(rng.random() < 0.4)
+    H, W = int(rng.choice([64, 96, 128, 256])), int(rng.choice([64, 100, 128, 512]))
+    slm = (int(rng.integers(8, H + 1)), int(rng.integers(8, W + 1)))
+    phase = synth.seed_phase(seed, slm, dtype=dt)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if spots:
+            vec = orc.rectangular_array((H, W), (3, 4), (W // 5, H // 6))      # (columns, rows), (x pitch, y pitch)
+            h = SpotHologram((H, W), vec, basis="knm", slm_shape=slm, phase=phase.copy(), dtype=dt)
+            o = orc.OracleSpotHologram((H, W), vec, slm_shape=slm, phase=phase.copy(), dtype=dt)
+        else:
+            target = synth.random_target(seed + 1, (H, W), 0.2, 1.0, dtype=dt)
+            if rng.random() < 0.4:
+                target[: H // 5, :] = np.nan       # (MRAF only acts when a run passes mraf_factor)
+            h = Hologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=dt)
+            o = orc.OracleHologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=dt)
+        trail = []
+        for k, op in enumerate(_ops(rng, 12, spots)):
+            trail.append(op)
+            if op == "optimize":
+                m, kw = METHODS[int(rng.integers(len(METHODS)))]
+                kw = dict(kw)
+                if "fix_phase_iteration" in kw:
+                    kw["fix_phase_iteration"] = int(o.iter + rng.integers(0, 3))
+                if not spots and rng.random() < 0.3:
+                    kw["mraf_factor"] = float(rng.choice([0.5, 1.0]))
+                n = int(rng.integers(1, 4))
+                groups = ["computational"] if rng.random() < 0.3 else []
+                h.optimize(m, maxiter=n, verbose=False, stat_groups=groups, **kw)
+                o.optimize(m, maxiter=n, stat_groups=groups, **kw)
+                trail[-1] = f"optimize({m}, {n}, {kw}, {groups})"
+            elif op == "optimize_callback":        # a callback takes the loop to the host: one engine call per operator
+                m, kw = METHODS[int(rng.integers(len(METHODS)))]
+                kw = dict(kw)
+                if "fix_phase_iteration" in kw:
+                    kw["fix_phase_iteration"] = int(o.iter + rng.integers(0, 3))
+                n = int(rng.integers(1, 4))
+                seen = []
+                h.optimize(m, maxiter=n, verbose=False, callback=lambda hh: seen.append(hh.iter) and False, **kw)
+                o.optimize(m, maxiter=n, **kw)
+                assert len(seen) == n, (trail, seen)
+                trail[-1] = f"optimize_callback({m}, {n}, {kw})"
+                op = "optimize"
+            elif op == "tensor_phase":             # a phase that lives on the GPU (torch tensor): device -> engine, no host copy
+                import torch
+                p = synth.seed_phase(seed + 60 + k, slm, dtype=dt)
+                h.phase = torch.as_tensor(p.copy(), device="cuda")
+                o.phase = p.copy()
+            elif op == "release":                  # the engine goes away: the next call rebuilds it from what the object holds
+                h._release_engine()
+            elif op == "new_phase":
+                p = synth.seed_phase(seed + 10 + k, slm, dtype=dt)
+                h.phase = p.copy()
+                o.phase = p.copy()
+            elif op == "reset_phase":
+                p = synth.seed_phase(seed + 40 + k, slm, dtype=dt)
+                h.reset_phase(p.copy())
+                o.phase = p.copy()
+            elif op == "scale_weights":
+                f = 1 + 0.2 * synth.uniform01(seed + 20 + k, (H, W), 0)
+                h.weights = np.nan_to_num(np.asarray(h.weights)) * f
+                o.weights = np.nan_to_num(o.weights) * f
+            elif op == "new_target":
+                t = synth.random_target(seed + 30 + k, (H, W), 0.2, 1.0, dtype=dt)
+                rw = bool(rng.random() < 0.5)
+                h.set_target(t.copy(), reset_weights=rw)
+                o.set_target(t.copy(), reset_weights=rw)
+                trail[-1] = f"new_target(reset_weights={rw})"
+            elif op == "reset":
+                h.reset(reset_phase=False, reset_flags=False)
+                o.reset()
+            elif op == "read":
+                _ = (np.asarray(h.phase).sum(), np.nan_to_num(np.asarray(h.weights)).sum(), h.get_farfield().sum())
+                if o.amp_ff is not None:           # get_farfield() at the hologram's own shape refreshes amp_ff / phase_ff
+                    o.populate_results()           # once they exist (_hologram.py:900-903)
+            elif op == "column_policy":
+                if h._engine is not None:
+                    h._engine.set_option(L.OPT_SPARSE_COLUMNS, int(rng.integers(2)))
+            assert h.iter == o.iter, trail
+            errs = dict(phase=phase_rel_l2(h.phase, o.phase), weights=rel_l2(np.nan_to_num(np.asarray(h.weights)), np.nan_to_num(o.weights)))
+            if o.amp_ff is not None and h.amp_ff is not None:
+                errs["amp_ff"] = rel_l2(h.amp_ff, o.amp_ff)
+            assert (o.amp_ff is None) == (h.amp_ff is None), trail
+            if log is not None:
+                log(f"{k:2d} {trail[-1]}: {errs}")
+            assert max(errs.values()) < tol, (trail, errs)
+            # teacher forcing: the oracle continues from the engine's numbers, so that every step is judged on its own (a dense
+            # pixel-wise rule amplifies the 1e-13 of three bodies to 3e-6 over the thirty of a walk: measured without this).
+            if op == "optimize":
+                o.phase = np.array(h.phase, dtype=dt)
+                o.weights = np.nan_to_num(np.array(h.weights, dtype=dt))
+                o.populate_results()               # amp_ff / phase_ff of the forced phase (a fixed phase reads phase_ff next time)
+    h._release_engine()
+    return f"{'spots' if spots else 'image'} {(H, W)} {slm}: {len(trail)} operations", errs
+
+
+@pytest.mark.parametrize("seed", range(9000, 9060))
+def test_random_operation_sequence_fp64(seed):
+    """
+    One hologram and one oracle object taken through the same random sequence -- optimize() with changing methods and
+    options (flags persist, ``iter`` runs on: WGS-Kim's fixing iteration is an absolute count), a new phase, rescaled
+    weights, a new target with and without a weight reset, reset(), read accesses (phase, weights, amp_ff; get_farfield, which
+    refreshes amp_ff and phase_ff once they exist),
+    a change of the engine's column policy, reset_phase(), a callback (host-driven loop), a phase handed over as a torch CUDA
+    tensor, the engine released and rebuilt -- compared after every step.  Whatever the engine keeps on the
+    device between calls (weights, phase, farfield validity, column lists, stored phase_ff) has to follow the host object.
+    """
+    what, errs = walk(seed)
+    report(f"fuzz sequence fp64 [{seed}] {what}", **errs)
