@@ -274,12 +274,24 @@ def _ops(rng, n, spots):
     return [str(rng.choice(names)) for _ in range(n)]
 
 
-def walk(seed, tol=1e-9, log=None):
-    """The random walk of test_random_operation_sequence_fp64 (``log``: a callable that gets one line per step)."""
+def _sparse_blocks(seed, shape, dt):
+    """A mostly empty image target: a few small blocks (the engine transforms only the columns they touch)."""
+    t = synth.random_target(seed, shape, 0.2, 1.0, dtype=dt)
+    keep = np.zeros(shape, bool)
+    r = np.random.default_rng(seed)
+    for _ in range(3):
+        y, x = int(r.integers(0, shape[0] - 8)), int(r.integers(0, shape[1] - 8))
+        keep[y:y + int(r.integers(1, 9)), x:x + int(r.integers(1, 9))] = True
+    return np.where(keep, t, 0).astype(dt)
+
+
+def walk(seed, tol=1e-7, log=None, dt=np.float64, big=False, steps=12):
+    """The random walk of test_random_operation_sequence_* (``log``: a callable that gets one line per step)."""
     rng = np.random.default_rng(seed)
-    dt = np.float64
     spots = bool(rng.random() < 0.4)
     H, W = int(rng.choice([64, 96, 128, 256])), int(rng.choice([64, 100, 128, 512]))
+    if big:                                        # the tile-resident kernels and their column / tile lists
+        H, W = [(4096, 4096), (4096, 2048), (2048, 4096), (8192, 2048)][int(rng.integers(4))]
     slm = (int(rng.integers(8, H + 1)), int(rng.integers(8, W + 1)))
     phase = synth.seed_phase(seed, slm, dtype=dt)
     with warnings.catch_warnings():
@@ -295,7 +307,7 @@ def walk(seed, tol=1e-9, log=None):
             h = Hologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=dt)
             o = orc.OracleHologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=dt)
         trail = []
-        for k, op in enumerate(_ops(rng, 12, spots)):
+        for k, op in enumerate(_ops(rng, steps, spots)):
             trail.append(op)
             if op == "optimize":
                 m, kw = METHODS[int(rng.integers(len(METHODS)))]
@@ -341,7 +353,8 @@ def walk(seed, tol=1e-9, log=None):
                 h.weights = np.nan_to_num(np.asarray(h.weights)) * f
                 o.weights = np.nan_to_num(o.weights) * f
             elif op == "new_target":
-                t = synth.random_target(seed + 30 + k, (H, W), 0.2, 1.0, dtype=dt)
+                # dense image or a few blocks: the engine's column lists have to follow the target through the change
+                t = _sparse_blocks(seed + 30 + k, (H, W), dt) if rng.random() < 0.5 else synth.random_target(seed + 30 + k, (H, W), 0.2, 1.0, dtype=dt)
                 rw = bool(rng.random() < 0.5)
                 h.set_target(t.copy(), reset_weights=rw)
                 o.set_target(t.copy(), reset_weights=rw)
@@ -366,6 +379,8 @@ def walk(seed, tol=1e-9, log=None):
             assert max(errs.values()) < tol, (trail, errs)
             # teacher forcing: the oracle continues from the engine's numbers, so that every step is judged on its own (a dense
             # pixel-wise rule amplifies the 1e-13 of three bodies to 3e-6 over the thirty of a walk: measured without this).
+            # Bound 1e-7 in float64: a step is typically at 1e-14 .. 1e-10; three bodies of a dense rule that meet a speckle zero
+            # reach 1e-8 (seed 9022, step 7: the same with and without the operations around it); lost state shows at 1e-3.
             if op == "optimize":
                 o.phase = np.array(h.phase, dtype=dt)
                 o.weights = np.nan_to_num(np.array(h.weights, dtype=dt))
@@ -387,3 +402,13 @@ def test_random_operation_sequence_fp64(seed):
     """
     what, errs = walk(seed)
     report(f"fuzz sequence fp64 [{seed}] {what}", **errs)
+
+
+@pytest.mark.parametrize("seed", range(9500, 9508))
+def test_random_operation_sequence_fp32_large(seed):
+    """The same walk in float32 at 4096 / 8192 points per axis (tile-resident kernels, tile lists, row walks; eight steps).
+    Per step and teacher-forced, so the bound only has to hold three float32 bodies of a dense rule (up to 1e-4 on the phase
+    in the two-body cases above): 1e-3 -- state that is not carried over (stale weights, a column list of the old target,
+    a phase_ff of another phase) shows at 1e-2 and above."""
+    what, errs = walk(seed, tol=1e-3, dt=np.float32, big=True, steps=8)
+    report(f"fuzz sequence fp32 large [{seed}] {what}", **errs)
