@@ -221,6 +221,7 @@ class GridProblem:
                 target[a:b, a:b] = synth.random_target(5, (b - a, b - a), 0.2, 1.0, dtype=self.np_dtype)
                 self.flags = {"mraf_factor": 0.5}
                 self.signal_cols, self.noise_cols = 2048, 3072      # columns with a finite non-zero / a NaN target
+                self.noise_pixels = 3072 * 3072 - 2048 * 2048
                 self.n_targets = 2048 * 2048
                 self.desc = "Hologram MRAF (mraf_factor 0.5; NaN noise box 3072^2, image 2048^2)"
             elif w == "cfg1":
@@ -296,6 +297,17 @@ class GridProblem:
                 mraf_note = ("; MRAF with a weight update in ONE column pass: the signal and the noise part of the rebuilt field "
                              f"are written separately (GH + the noise part in the {self.noise_cols} columns that hold a NaN target) "
                              "and joined by the row kernel")
+            elif (self.args.dtype == "f64" and Pw >= 4096 and os.environ.get("HGS_MRAF_SPLIT", "1") != "0"
+                  and os.environ.get("HGS_MRAF_SPLIT64", "1") != "0"):
+                # float64: one pass of the per-column kernel (reads GH, w, t; writes w, the signal part back into GH and the
+                # noise part as farfield values at the NaN-target pixels), then col_kernel<LOAD | INV> over the columns that
+                # hold noise (reads their farfield columns, writes their rows of the noise part); the row kernel reads both
+                gh2 = gh * self.noise_cols // Pw
+                col = (gh + 2 * P * r + w_write + gh + self.noise_pixels * c) + (self.noise_cols * Ph * c + gh2)
+                row = 2 * gh + gh2
+                mraf_note = ("; float64 MRAF with a weight update in ONE pass of the per-column kernel: the noise part leaves as farfield "
+                             f"values ({self.noise_pixels} NaN-target pixels) and an inverse-only launch over the {self.noise_cols} columns "
+                             "that hold them writes it next to GH; joined by the row kernel")
             else:
                 # two column passes: forward + weight rule (reads GH, w, t; writes w), then forward + rebuild + inverse
                 col = (gh + 2 * P * r + w_write) + (2 * gh + 2 * P * r)

@@ -225,6 +225,15 @@ template <typename R> struct Engine : EngineBase {
     int opt_row_pref = 1;                  // developer A/B (HGS_ROW_PREF=0 at create): prefetching row kernel off
     int opt_mraf_split = 1;                // developer A/B (HGS_MRAF_SPLIT=0 at create): MRAF weight updates in two column passes
     bool row_split = false;                // the next row kernel joins gh and gh2 (single-pass MRAF)
+    // float64 (per-column kernel) single-pass MRAF: noise part as farfield values, the columns that hold it, their inverse pass
+    C* ffb = nullptr;                      // [B][P], layout of ff; only NaN-target pixels are ever written, the rest stays zero
+    int* col_list_noise = nullptr;         // [B][Pw] columns with a NaN target (bit 4 of col_active), compacted
+    int* n_noise_dev = nullptr;            // [B]
+    unsigned short* lane_mask_tmp = nullptr;
+    int n_noise_max = 0;
+    bool noise_valid = false;              // col_list_noise / the zeros of ffb match the current target
+    bool row_split_noise_only = false;     // ... and the row kernel must read gh2 in those columns only (nothing else was written)
+    int opt_mraf_split64 = 1;              // developer A/B (HGS_MRAF_SPLIT64=0 at create): float64 MRAF weight updates in two passes
     int row_blocks_pref = 0;               // its grid: two workgroups per CU, whole XCD line groups
     // statistics of the fused path (hgs_iterate_stats)
     double* stats_scratch = nullptr;  // hgs_stats group 0: per-block partials of the two passes
@@ -294,7 +303,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
-        void* ptrs[] = {lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
+        void* ptrs[] = {ffb, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -375,6 +384,7 @@ template <typename R> struct Engine : EngineBase {
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
+        opt_mraf_split64 = env_int("HGS_MRAF_SPLIT64", 1);
         opt_gh2_mask = env_int("HGS_GH2_MASK", 1);
         opt_tile_list = env_int("HGS_TILE_LIST", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
@@ -1020,7 +1030,7 @@ template <typename R> struct Engine : EngineBase {
     }
     static int tile_split(int, int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
     static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) { return launch_row_split(N, mode, grid, s, a); }
-    static int row_split_launch(int, int, dim3, hipStream_t, const RowArgs<double>&) { return (int)hipErrorInvalidValue; }
+    static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a) { return launch_row_split(N, mode, grid, s, a); }
 
     int fill_wscale_one() {
         hipLaunchKernelGGL(set_scalar<R>, dim3((B + 63) / 64), dim3(64), 0, stream, wscale, B, (R)1);
@@ -1427,8 +1437,9 @@ template <typename R> struct Engine : EngineBase {
                 a.gh2 = gh2;
                 // (a column-list launch already reads the listed columns only, and a noise box fills its list: there the
                 //  second mask costs its fetch -- 42.4 -> 46.1 us at cfg 5 -- and saves nothing)
-                a.gh2_mask = (opt_gh2_mask && !sparse_dirty && !a.load_mask) ? lane_mask_noise : nullptr;
+                a.gh2_mask = (row_split_noise_only || (opt_gh2_mask && !sparse_dirty && !a.load_mask)) ? lane_mask_noise : nullptr;
                 row_split = false;
+                row_split_noise_only = false;
                 LCHK(row_split_launch(g.Pw, mode, dim3(blocks, B), stream, a));
                 return 0;
             }
@@ -1526,6 +1537,29 @@ template <typename R> struct Engine : EngineBase {
         n_active_min = *std::min_element(h.begin(), h.end());
         sparse_dirty = false;
         dil_valid = false;
+        noise_valid = false;
+        return 0;
+    }
+    // float64 single-pass MRAF: the columns that hold a NaN target as a list, the buffer of the noise part zeroed (its NaN-target
+    // pixels are rewritten by every pass; everything else must read as zero, also after the target moved)
+    int refresh_noise() {
+        if (int e = refresh_sparse()) return e;
+        if (noise_valid) return 0;
+        if (!col_list_noise) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list_noise), (size_t)B * g.Pw * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_noise_dev), (size_t)B * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_tmp), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
+        }
+        if (!ffb) { if (dalloc(&ffb, (size_t)B * g.Ph * g.Pw)) return HGS_ERR_DEVICE; }
+        HIPCHK(hipMemsetAsync(ffb, 0, (size_t)B * g.Ph * g.Pw * sizeof(C), stream));
+        hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
+                           col_list_noise, n_noise_dev, lane_mask_tmp, 4);
+        HIPCHK(hipGetLastError());
+        std::vector<int> h(B);
+        HIPCHK(hipMemcpyAsync(h.data(), n_noise_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        n_noise_max = *std::max_element(h.begin(), h.end());
+        noise_valid = true;
         return 0;
     }
     ColArgs<R> col_args() {
@@ -1543,7 +1577,7 @@ template <typename R> struct Engine : EngineBase {
 
     int n2f(int store_pff) override {
         RoctxRange range(opt_roctx, "hgs_nearfield2farfield");
-        row_split = false;       // (a single-pass MRAF call that failed between its column and row launch must not leak)
+        row_split = row_split_noise_only = false;       // (a single-pass MRAF call that failed between its column and row launch must not leak)
         if (cfg.kind == 1) return n2f_compressed(store_pff);
         if (general) return n2f_general(store_pff);
         if (int e = need_ff()) return e;
@@ -1564,7 +1598,7 @@ template <typename R> struct Engine : EngineBase {
 
     int f2n() override {
         RoctxRange range(opt_roctx, "hgs_farfield2nearfield");
-        row_split = false;
+        row_split = row_split_noise_only = false;
         if (cfg.kind == 1) return f2n_compressed();
         if (general) return f2n_general(false);
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
@@ -1890,7 +1924,7 @@ template <typename R> struct Engine : EngineBase {
 
     int iterate(hgs_step* st, int n, uint8_t* hist) override {
         RoctxRange range(opt_roctx, "hgs_iterate");
-        row_split = false;
+        row_split = row_split_noise_only = false;
         if (n < 0) return fail(HGS_ERR_ARG, "n_iter must be >= 0");
         if (n == 0) return 0;
         if (int e = check_step(st)) return e;
@@ -1953,7 +1987,13 @@ template <typename R> struct Engine : EngineBase {
             // (a column list rounded to whole tiles: the same kernels walk the list)
             const int tile_grid = sp ? std::max(1, std::min(tile_blocks, n_active_max / 4)) : tile_blocks;
             const bool split = two_pass && tile_path && g.Pw >= 4096 && opt_mraf_split;
-            if (split && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
+            // ... and the float64 per-column kernel the same way, its noise part through a farfield buffer and an inverse-only
+            // launch over the columns that hold noise (CParams::split): one forward transform and one read of weights and
+            // target per column instead of two
+            const bool split64 = two_pass && !tile_path && sizeof(R) == 8 && g.Pw >= 4096 && opt_mraf_split && opt_mraf_split64;
+            const bool split_any = split || split64;
+            if (split_any && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
+            if (split64) { if (int e = refresh_noise()) return e; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
             // one more forward-only pass that just accumulates it
             const bool nog = st->method == HGS_WGS_NOGRETTE && p.do_update;
@@ -1969,7 +2009,7 @@ template <typename R> struct Engine : EngineBase {
                 });
                 if (r) return r;
             }
-            for (int pass = nog ? -1 : 0; pass < (two_pass && !split ? 2 : 1) && !r; ++pass) {
+            for (int pass = nog ? -1 : 0; pass < (two_pass && !split_any ? 2 : 1) && !r; ++pass) {
                 r = timed(HGS_K_COL_FUSED, [&]() -> int {
                     ColArgs<R> a = col_args();
                     a.cp = cparams(st, p);
@@ -1981,9 +2021,14 @@ template <typename R> struct Engine : EngineBase {
                     } else if (nog) {
                         a.cp.nog = nog_dev;
                     }
-                    if (two_pass && !split && pass == 0) {
+                    if (two_pass && !split_any && pass == 0) {
                         a.cp.weights_only = 1;
                         phase_mode = 0;
+                    }
+                    if (split64 && pass == 0) {
+                        a.cp.split = 1;
+                        a.ffb = ffb;
+                        row_split = row_split_noise_only = true;
                     }
                     if (two_pass && pass == 1) a.cp.do_update = 0;
                     if (stat_ctx && pass == 0 && (!sp || (stat_ctx->groups & 1))) {
@@ -2048,6 +2093,14 @@ template <typename R> struct Engine : EngineBase {
                         hipLaunchKernelGGL(reduce_to_scale<R>, dim3(B), dim3(256), 0, stream, (const double*)wpartial, wpartial_n,
                                            sums + 2 * B, wscale);
                         HIPCHK(hipGetLastError());
+                    }
+                    if (split64 && pass == 0 && n_noise_max > 0) {        // the noise part: farfield values -> gh2, noise columns only
+                        ColArgs<R> nb = col_args();
+                        nb.ff = ffb;
+                        nb.gh = gh2;
+                        nb.col_list = col_list_noise;
+                        nb.n_active = n_noise_dev;
+                        LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(list_blocks(n_noise_max), B), stream, nb));
                     }
                     return 0;
                 });

@@ -112,6 +112,11 @@ template <typename R> struct CParams {
     R p_exp, p_fac, mraf_factor, zero_factor;
     R inv_fnorm;      // 1/||amp_ff|| (Parseval constant ||amp|| in the fused path)
     R log2_inv_fnorm;
+    int split;        // col_fused_kernel: MRAF with a weight update in ONE pass -- the signal part (un-normalised new weights)
+                      // is transformed back here, the noise part mraf_factor * F leaves as farfield values through
+                      // ColArgs::ffb (only the pixels with a NaN target are written: the rest of the buffer stays zero) and a
+                      // col_kernel<LOAD | INV> launch over the columns that hold noise transforms it into gh2; the row kernel
+                      // (SPLIT) joins the two once ||w'|| is known.  The float64 counterpart of col_tile_kernel RULE 3.
 };
 
 // sin/cos in fp32 with the range reduction by pi/2 done in ONE fp64 fma (exact enough for any
@@ -914,6 +919,7 @@ template <typename R> struct ColArgs {
     // farfield is exactly zero, so its inverse transform is zero and the row kernel does not read it.
     int list_xmap;         // the same for column-list launches: list groups PASSES k .. PASSES k + PASSES - 1 (the columns
                            // of one tile where the active set is dense) on one XCD together (gridDim.x a multiple of 8 * PASSES)
+    Cx<R>* ffb;            // col_fused_kernel with CParams::split: noise part of the constrained farfield, layout of ff
     Cx<R>* gh2;            // col_tile_kernel RULE 3 (single-pass MRAF): column-transformed noise-region part, layout of gh
     int gh2_sparse;        // ... stored only for tiles (NR <= 4) / columns (NR > 4) that hold a noise pixel: the row kernel
                            //     reads it through RowArgs::gh2_mask, which marks exactly the columns with a NaN target
@@ -1097,6 +1103,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const bool x_mraf = RULE != 0 ? false : cp.mraf != 0;
     const bool x_nog = RULE != 0 ? false : cp.nog_pass != 0;
     const bool x_wonly = RULE != 0 ? false : cp.weights_only != 0;
+    const bool x_split = RULE != 0 ? false : (cp.split != 0 && cp.mraf != 0);
     const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
@@ -1294,8 +1301,13 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             if (x_mraf) {                                   // mixed-region amplitude freedom (:1606-1653)
                 const R t = tr[m];
                 if (is_nan(t)) {
-                    const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
-                    vm = F * mf;
+                    if (x_split) {                          // the noise part goes its own way (CParams::split)
+                        if (vcol) a.ffb[cb + idx] = cp.has_mraf_factor ? F * cp.mraf_factor : F;
+                        vm = mk<R>(0, 0);
+                    } else {
+                        const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
+                        vm = F * mf;
+                    }
                 } else if (t == (R)0) {
                     vm = mk<R>(0, 0);
                     if constexpr (PHASE == 1) { if (vcol) pfc[idx] = (R)0; }
@@ -2347,8 +2359,9 @@ static __global__ void dilate_active_cols(const unsigned char* active, int Pw, i
     dil[(size_t)b * Pw + c] = on;
 }
 // one workgroup per hologram: ordered compaction of the active columns
+// (mask: the bits of scan_active_cols that count -- 0xff: any, 4: the columns that hold a NaN target)
 static __global__ void compact_active_cols(const unsigned char* active, int Pw, int* list, int* n_active,
-                                           unsigned short* lane_mask) {
+                                           unsigned short* lane_mask, int mask = 0xff) {
     __shared__ int base;
     __shared__ int wsum[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -2356,7 +2369,7 @@ static __global__ void compact_active_cols(const unsigned char* active, int Pw, 
     __syncthreads();
     for (int c0 = 0; c0 < Pw; c0 += blockDim.x) {
         const int c = c0 + threadIdx.x;
-        const bool on = c < Pw && active[(size_t)b * Pw + c] != 0;
+        const bool on = c < Pw && (active[(size_t)b * Pw + c] & mask) != 0;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
         if (lane == 0) wsum[wid] = __builtin_popcountll(m);
         __syncthreads();
@@ -2375,7 +2388,7 @@ static __global__ void compact_active_cols(const unsigned char* active, int Pw, 
     const int T = Pw / 16;
     for (int j = threadIdx.x; j < T; j += blockDim.x) {
         unsigned m16 = 0;
-        for (int m = 0; m < 16; ++m) m16 |= (unsigned)(active[(size_t)b * Pw + j + m * T] != 0) << m;
+        for (int m = 0; m < 16; ++m) m16 |= (unsigned)((active[(size_t)b * Pw + j + m * T] & mask) != 0) << m;
         lane_mask[(size_t)b * T + j] = (unsigned short)m16;
     }
 }

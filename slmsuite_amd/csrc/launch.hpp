@@ -36,6 +36,7 @@ int launch_tile_rule_listed(int N, int phase_mode, int rule, dim3 grid, hipStrea
 int launch_tile_split(int N, int phase_mode, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
 int launch_tile_split_stats(int N, int phase_mode, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);   // a.do_stats
 int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a);
+int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a);   // float64: rows of 4096 / 8192 (launch_row_f64.hip)
 
 // per-column fused kernel with the rule compiled in (fp32, no statistics, none of the MRAF / Nogrette / forward-only extras)
 int launch_fused_rule1(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<float>& a);    // Leonardo / Kim update

@@ -76,6 +76,27 @@ template <> int launch_row<HGS_REAL>(int N, int mode, dim3 grid, hipStream_t s, 
     return (int)hipErrorInvalidValue;
 }
 
+#ifndef HGS_REAL_IS_FLOAT
+// float64 single-pass MRAF (col_fused_kernel with CParams::split + col_kernel<LOAD | INV> into gh2): the row kernel that joins
+// the two parts, H = gh * wscale + gh2 (a.gh2 and a.gh2_mask set); rows of 4096 / 8192 (the split form has one-row workgroups)
+template <int N, int MODE>
+static int launch_row_split64_one(dim3 grid, hipStream_t s, const RowArgs<double>& a) {
+    constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<double>);
+    auto k = row_kernel<double, N, MODE, 16, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dispatch_note(dispatch_site<KRow, double, N, MODE, 16, false, true>(), row_flags(grid, a));
+    hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
+    return (int)hipGetLastError();
+}
+int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a) {
+    if (mode != 1 && mode != 2) return (int)hipErrorInvalidValue;
+    if (N == 4096) return mode == 1 ? launch_row_split64_one<4096, 1>(grid, s, a) : launch_row_split64_one<4096, 2>(grid, s, a);
+    if (N == 8192) return mode == 1 ? launch_row_split64_one<8192, 1>(grid, s, a) : launch_row_split64_one<8192, 2>(grid, s, a);
+    return (int)hipErrorInvalidValue;
+}
+#endif
+
 template <> size_t row_lds_bytes<HGS_REAL>(int N) {
     const int T = N / 16, WG = T >= 256 ? T : 256;
     return (size_t)(WG / T) * (N + N / 16) * sizeof(Cx<HGS_REAL>);

@@ -258,3 +258,62 @@ def test_dispatch_read_buffer_protocol_and_device_upload_errors():
     with pytest.raises(ValueError):
         e.set_from_device(99, t.data_ptr(), t.numel() * 4)
     e.close()
+
+
+# ---- float64 MRAF with a weight update in one column pass ---------------------------------------------------------------
+def _mraf_frame(shape, dtype, box=True):
+    """Image in the middle, NaN (noise) frame around it, zeros outside -- or (box False) NaN rows across the whole width."""
+    H, W = shape
+    t = np.zeros(shape, dtype)
+    if box:
+        t[H // 4:3 * H // 4, W // 2 - W // 8:W // 2 + W // 8] = np.nan
+        t[H // 3:2 * H // 3, W // 2 - W // 16:W // 2 + W // 16] = synth.random_target(5, (2 * H // 3 - H // 3, W // 8), 0.2, 1.0, dtype=dtype)
+    else:
+        t[:] = synth.random_target(5, shape, 0.2, 1.0, dtype=dtype)
+        t[: H // 5, :] = np.nan
+        t[:, : W // 6] = 0
+    return t
+
+
+@pytest.mark.parametrize("shape, slm", [((64, 4096), (40, 1500)), ((256, 8192), (100, 3000)), ((4096, 4096), (600, 900))])
+@pytest.mark.parametrize("method, extra", [("WGS-Leonardo", {}), ("WGS-Kim", dict(fix_phase_iteration=1)), ("WGS-Nogrette", {})])
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_float64_single_pass_mraf(shape, slm, method, extra, sparse, monkeypatch):
+    """
+    float64 has no tile-resident kernel; its per-column kernel takes an MRAF weight update in one pass as well
+    (CParams::split): signal part transformed back in place, noise part mraf_factor * F out as farfield values, one
+    col_kernel<LOAD | INV> launch over the columns that hold a NaN target, row_kernel<double, ..., SPLIT> joins the two once
+    ||w'|| is known.  Against the two-pass form (HGS_MRAF_SPLIT64 = 0) and the oracle, dense launches and column lists, a
+    noise box (few noise columns) and noise rows across the whole width; dispatch asserted.
+    """
+    from oracle import hgs_oracle as orc
+    if shape == (4096, 4096) and (method != "WGS-Leonardo"):
+        pytest.skip("one method at the large size")
+    dt = np.float64
+    target = _mraf_frame(shape, dt, box=bool(sparse))
+    phase0 = synth.seed_phase(17, slm, dtype=dt)
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("HGS_MRAF_SPLIT64", split)
+        h = Hologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+        h.optimize(method, maxiter=3, verbose=False, mraf_factor=0.5, **extra)
+        d = dispatch_of(h)
+        nog = 2 if method == "WGS-Nogrette" else 0           # its forward-only pass, in each of the two updating bodies
+        lst = ["list"] if sparse else []
+        if split == "1":     # body 0: one plain pass; bodies 1, 2: one pass + the inverse of the noise part + a SPLIT row launch
+            assert d.count("col_fused_kernel", N=shape[0], flags=lst) == 3 + nog, d
+            assert d.count("col_kernel", N=shape[0], MODE=24, flags=["list"]) == 2, d
+            assert d.count("row_kernel", N=shape[1], SPLIT=True) == 2, d
+        else:
+            assert d.count("col_fused_kernel", N=shape[0], flags=lst) == 5 + nog, d
+            assert d.count("col_kernel", MODE=24) == 0 and d.count("row_kernel", SPLIT=True) == 0, d
+        out[split] = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)), h.amp_ff.copy())
+        h._release_engine()
+    o = orc.OracleHologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt)
+    o.optimize(method, maxiter=3, mraf_factor=0.5, **extra)
+    errs = dict(phase_vs_two_pass=phase_rel_l2(out["1"][0], out["0"][0]), weights_vs_two_pass=rel_l2(out["1"][1], out["0"][1]),
+                phase=phase_rel_l2(out["1"][0], o.phase), weights=rel_l2(out["1"][1], np.nan_to_num(o.weights)),
+                amp_ff=rel_l2(out["1"][2], o.amp_ff))
+    report(f"float64 single-pass MRAF {shape} {slm} {method} sparse={sparse}", **errs)
+    assert max(errs.values()) < 1e-9, errs
+    assert errs["phase_vs_two_pass"] > 0          # (two different sequences of launches)
