@@ -282,6 +282,7 @@ class GridProblem:
         kim = m == "WGS-Kim"                          # after the fixing iteration the stored phase_ff is read back
         col = 2 * gh + P * r + (P * r if (wgs or self.mraf) else 0) + (w_write if wgs else 0) + (P * r if kim else 0)
         passes = 1
+        other = 0                                     # launches of an iteration besides the column pass(es) and the row launch
         row = 2 * gh                                  # MODE 2 (between fused iterations): H read, G written
         mraf_note = ""
         if self.mraf and wgs:
@@ -303,7 +304,10 @@ class GridProblem:
                 # noise part as farfield values at the NaN-target pixels), then col_kernel<LOAD | INV> over the columns that
                 # hold noise (reads their farfield columns, writes their rows of the noise part); the row kernel reads both
                 gh2 = gh * self.noise_cols // Pw
-                col = (gh + 2 * P * r + w_write + gh + self.noise_pixels * c) + (self.noise_cols * Ph * c + gh2)
+                # (float64 leaves changed weights four pixels = 32 bytes at a time: the image pixels, not whole columns)
+                w_write = self.n_targets * r
+                col = gh + 2 * P * r + w_write + gh + self.noise_pixels * c
+                other = self.noise_cols * Ph * c + gh2       # the inverse-only launch (profile slot col_inv)
                 row = 2 * gh + gh2
                 mraf_note = ("; float64 MRAF with a weight update in ONE pass of the per-column kernel: the noise part leaves as farfield "
                              f"values ({self.noise_pixels} NaN-target pixels) and an inverse-only launch over the {self.noise_cols} columns "
@@ -316,7 +320,7 @@ class GridProblem:
         canon_col = (4 * P * c + (3 if wgs else 1) * P * r)
         canon_iter = ((15 if wgs else 13) * P + 2 * S) * r
         ws = gh + P * r * (2 if (wgs or self.mraf) else 1)           # GH + weights (+ target)
-        return dict(col=col * B, col_passes=passes, row=row * B, canon_col=canon_col * B, canon_iter=canon_iter * B,
+        return dict(col=col * B, col_passes=passes, row=row * B, other=other * B, canon_col=canon_col * B, canon_iter=canon_iter * B,
                     working_set=ws * B,
                     col_model=f"GH tile read + write (2 x Sh*Pw*{c} B) + weights read (P*{r}) + "
                               f"{'target read (P*%d) + ' % r if (wgs or self.mraf) else ''}"
@@ -771,6 +775,7 @@ def main():
         value = iters_total / wall
         want_pmc = args.pmc if args.pmc is not None else (1 if (world == 1 and dist is None) else 0)
         roof = None
+        bm = {}
         if compressed and prof is not None and args.workload == "cfg4zern":
             # direct kernels: one value of exp(+-i phi_n(p)) and one complex MAC per (spot, pixel) and direction; counted as
             # SURVEY 8(d) counts the reference's evaluation: (2 D + 8 + 2) flop each (phase polynomial, sin, cos, complex MAC)
@@ -875,9 +880,9 @@ def main():
                     "row_kernel": {"launch_us": row_dur * 1e6, "bytes_per_launch": bm["row"], "bytes_model": bm["row_model"],
                                    "achieved": bm["row"] / row_dur / 1e9, "frac": bm["row"] / row_dur / HBM_PEAK,
                                    "traffic": tr_row, "traffic_over_model": None if tr_row is None else tr_row / bm["row"]},
-                    "iteration": {"moved_bytes": (bm["col"] + bm["row"]) * args.streams,
-                                  "achieved": (bm["col"] + bm["row"]) * args.streams * iter_s / 1e9,
-                                  "frac": (bm["col"] + bm["row"]) * args.streams * iter_s / HBM_PEAK,
+                    "iteration": {"moved_bytes": (bm["col"] + bm["row"] + bm.get("other", 0)) * args.streams,
+                                  "achieved": (bm["col"] + bm["row"] + bm.get("other", 0)) * args.streams * iter_s / 1e9,
+                                  "frac": (bm["col"] + bm["row"] + bm.get("other", 0)) * args.streams * iter_s / HBM_PEAK,
                                   "canonical_bytes": bm["canon_iter"] * args.streams,
                                   "canonical_equivalent_frac": bm["canon_iter"] * args.streams * iter_s / HBM_PEAK,
                                   "note": "all stream groups of this rank together" if args.streams > 1 else None},
@@ -885,6 +890,11 @@ def main():
                               "1 - 2 us to a launch (the rocprofv3 --kernel-trace average of the same kernel, profiles/, is "
                               "the sharper figure)" + ("; this pass runs the stream groups one after the other, so that a launch's "
                               "event interval holds that launch only" if args.streams > 1 else "")}
+        if roof is not None and prof is not None and bm.get("other") and prof.get("col_inv", {}).get("launches", 0) > 0:
+            inv_dur = prof["col_inv"]["ms"] * 1e-3 / prof["col_inv"]["launches"]
+            roof["noise_inverse_launch"] = {"kernel": "col_kernel<double, N, LOAD | INV> over the columns that hold a NaN target",
+                                            "launch_us": inv_dur * 1e6, "bytes_per_launch": bm["other"],
+                                            "frac": bm["other"] / inv_dur / HBM_PEAK}
         if roof is not None and roof.get("traffic_over_model") is not None and abs(roof["traffic_over_model"] - 1) > 0.05:
             roof["traffic_explanation"] = traffic_explanation(args, prob, roof)
         cpu = cpu_baseline(args) if world == 1 else None

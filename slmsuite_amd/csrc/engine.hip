@@ -2094,18 +2094,22 @@ template <typename R> struct Engine : EngineBase {
                                            sums + 2 * B, wscale);
                         HIPCHK(hipGetLastError());
                     }
-                    if (split64 && pass == 0 && n_noise_max > 0) {        // the noise part: farfield values -> gh2, noise columns only
-                        ColArgs<R> nb = col_args();
-                        nb.ff = ffb;
-                        nb.gh = gh2;
-                        nb.col_list = col_list_noise;
-                        nb.n_active = n_noise_dev;
-                        LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(list_blocks(n_noise_max), B), stream, nb));
-                    }
                     return 0;
                 });
             }
             if (r) return r;
+            if (split64 && n_noise_max > 0) {        // the noise part: farfield values -> gh2, noise columns only (own profile slot)
+                r = timed(HGS_K_COL_INV, [&]() -> int {
+                    ColArgs<R> nb = col_args();
+                    nb.ff = ffb;
+                    nb.gh = gh2;
+                    nb.col_list = col_list_noise;
+                    nb.n_active = n_noise_dev;
+                    LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(list_blocks(n_noise_max), B), stream, nb));
+                    return 0;
+                });
+                if (r) return r;
+            }
             if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
             if (p.do_update) w_pending = true;
