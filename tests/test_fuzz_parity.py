@@ -412,3 +412,62 @@ def test_random_operation_sequence_fp32_large(seed):
     a phase_ff of another phase) shows at 1e-2 and above."""
     what, errs = walk(seed, tol=1e-3, dt=np.float32, big=True, steps=8)
     report(f"fuzz sequence fp32 large [{seed}] {what}", **errs)
+
+
+# ---- batches: several holograms with different targets in one engine (or a few stream groups) ---------------------------------
+@pytest.mark.parametrize("seed", range(9800, 9824))
+def test_random_batch_fp64(seed):
+    """
+    HologramBatch with two to six holograms, every one with its own kind of target -- dense image, a few blocks, an MRAF
+    frame, an empty target next to full ones (the per-hologram column lists differ, or a hologram's list is empty and the
+    batch has to fall back to dense launches) -- in one to three stream groups, random column policy, against the same
+    holograms optimised one at a time: the kernels never mix holograms, so float64 results agree to rounding.
+    """
+    from slmsuite_amd.batch import HologramBatch
+    rng = np.random.default_rng(seed)
+    dt = np.float64
+    H, W = int(rng.choice([64, 128, 256, 200])), int(rng.choice([64, 128, 512, 90]))
+    slm = (int(rng.integers(8, H + 1)), int(rng.integers(8, W + 1)))
+    n = int(rng.integers(2, 7))
+    kinds = [str(rng.choice(["image", "blocks", "blocks", "mraf"])) for _ in range(n)]
+    targets = []
+    for i, kind in enumerate(kinds):
+        if kind == "blocks":
+            t = _sparse_blocks(seed + 10 * i, (H, W), dt)
+        else:
+            t = synth.random_target(seed + 10 * i, (H, W), 0.2, 1.0, dtype=dt)
+            if kind == "mraf":
+                t[: max(1, H // 5), :] = np.nan
+        targets.append(t)
+    targets = np.stack(targets)
+    phases = np.stack([synth.seed_phase(seed + 100 + i, slm, dtype=dt) for i in range(n)])
+    m, kw = METHODS[int(rng.integers(len(METHODS)))]
+    kw = dict(kw)
+    if "mraf" in kinds:
+        kw["mraf_factor"] = 0.5
+    streams = int(rng.integers(1, 4))
+    sparse = int(rng.integers(2))
+    bodies = int(rng.integers(2, 5))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hb = HologramBatch((H, W), slm, targets, phases, dtype=dt, streams=streams)
+        try:
+            hb.set_option(L.OPT_SPARSE_COLUMNS, sparse)
+            hb.optimize(m, maxiter=bodies, **kw)
+            if rng.random() < 0.5:                 # a second call: flags and the iteration count carry over
+                hb.optimize(m, maxiter=2, **kw)
+                bodies += 2
+            got = hb.phases()
+        finally:
+            hb.close()
+        worst = 0.0
+        for i in range(n):
+            h = Hologram(targets[i].copy(), phase=phases[i].copy(), slm_shape=slm, dtype=dt, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+            one = dict(kw)
+            if "mraf" in kinds and kinds[i] != "mraf":
+                pass                               # (mraf_factor without NaN in the target changes nothing, as in the reference)
+            h.optimize(m, maxiter=bodies, verbose=False, **one)
+            worst = max(worst, phase_rel_l2(got[i], h.phase))
+            h._release_engine()
+    report(f"fuzz batch fp64 [{seed}] {(H, W)} {slm} {kinds} {m} streams={streams} sparse={sparse} bodies={bodies}", phase=worst)
+    assert worst < 1e-9, (kinds, m, streams, sparse, worst)
