@@ -225,7 +225,8 @@ template <typename R> struct Engine : EngineBase {
     int opt_row_pref = 1;                  // developer A/B (HGS_ROW_PREF=0 at create): prefetching row kernel off
     int opt_mraf_split = 1;                // developer A/B (HGS_MRAF_SPLIT=0 at create): MRAF weight updates in two column passes
     bool row_split = false;                // the next row kernel joins gh and gh2 (single-pass MRAF)
-    // float64 (per-column kernel) single-pass MRAF: noise part as farfield values, the columns that hold it, their inverse pass
+    // per-column kernel (float64; float32 where the tile-resident kernel does not run) single-pass MRAF: noise part as farfield
+    // values, the columns that hold it, their inverse pass
     C* ffb = nullptr;                      // [B][P], layout of ff; only NaN-target pixels are ever written, the rest stays zero
     int* col_list_noise = nullptr;         // [B][Pw] columns with a NaN target (bit 4 of col_active), compacted
     int* n_noise_dev = nullptr;            // [B]
@@ -1990,7 +1991,8 @@ template <typename R> struct Engine : EngineBase {
             // ... and the float64 per-column kernel the same way, its noise part through a farfield buffer and an inverse-only
             // launch over the columns that hold noise (CParams::split): one forward transform and one read of weights and
             // target per column instead of two
-            const bool split64 = two_pass && !tile_path && sizeof(R) == 8 && g.Pw >= 4096 && opt_mraf_split && opt_mraf_split64;
+            // (float32 too where the tile-resident kernel does not run: SLM rows over more than six register slots, short columns)
+            const bool split64 = two_pass && !tile_path && g.Pw >= 4096 && opt_mraf_split && opt_mraf_split64;
             const bool split_any = split || split64;
             if (split_any && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
             if (split64) { if (int e = refresh_noise()) return e; }

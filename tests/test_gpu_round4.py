@@ -317,3 +317,40 @@ def test_float64_single_pass_mraf(shape, slm, method, extra, sparse, monkeypatch
     report(f"float64 single-pass MRAF {shape} {slm} {method} sparse={sparse}", **errs)
     assert max(errs.values()) < 1e-9, errs
     assert errs["phase_vs_two_pass"] > 0          # (two different sequences of launches)
+
+
+@pytest.mark.parametrize("shape, slm", [((256, 4096), (100, 1500)), ((4096, 4096), (2048, 1920))])
+@pytest.mark.parametrize("method, extra", [("WGS-Leonardo", {}), ("WGS-Kim", dict(fix_phase_iteration=1))])
+def test_float32_single_pass_mraf_on_the_per_column_kernel(shape, slm, method, extra, monkeypatch):
+    """The same route in float32 where the tile-resident kernel does not run (short columns; an SLM whose rows spread over
+    eight register slots): one pass of col_fused_kernel + the inverse of the noise part + a SPLIT row launch, against the
+    two-pass form (the body that splits differs by the rounding of the join) and the oracle's float32 <-> float64 distance."""
+    from oracle import hgs_oracle as orc
+    target = _mraf_frame(shape, np.float32, box=False)
+    phase0 = synth.seed_phase(19, slm)
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("HGS_MRAF_SPLIT64", split)
+        h = Hologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: 0})
+        h.optimize(method, maxiter=2, verbose=False, mraf_factor=0.5, **extra)
+        d = dispatch_of(h)
+        assert d.count("col_tile_kernel") == 0, d
+        if split == "1":
+            assert d.count("col_fused_kernel", N=shape[0]) == 2 and d.count("col_kernel", N=shape[0], MODE=24, flags=["list"]) == 1, d
+            assert d.count("row_kernel", N=shape[1], SPLIT=True) == 1, d
+        else:
+            assert d.count("col_fused_kernel", N=shape[0]) == 3 and d.count("col_kernel", MODE=24) == 0 and d.count("row_kernel", SPLIT=True) == 0, d
+        out[split] = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
+        h._release_engine()
+    ep, ew = phase_rel_l2(out["1"][0], out["0"][0]), rel_l2(out["1"][1], out["0"][1])
+    runs = {}
+    for dt in (np.float32, np.float64):
+        o = orc.OracleHologram(target.astype(dt), phase=phase0.astype(dt), slm_shape=slm, dtype=dt)
+        o.optimize(method, maxiter=2, mraf_factor=0.5, populate=False, **extra)
+        runs[dt] = (o.phase, np.nan_to_num(o.weights))
+    yp, yw = phase_rel_l2(runs[np.float32][0], runs[np.float64][0]), rel_l2(runs[np.float32][1], runs[np.float64][1])
+    gp, gw = phase_rel_l2(out["1"][0], runs[np.float64][0]), rel_l2(out["1"][1], runs[np.float64][1])
+    report(f"float32 single-pass MRAF on the per-column kernel {shape} {slm} {method}", phase_vs_two_pass=ep, weights_vs_two_pass=ew,
+           phase_vs_f64=gp, weights_vs_f64=gw, oracle32_phase_vs_f64=yp, oracle32_weights_vs_f64=yw)
+    assert ew < 1e-6 and ep < 3e-6, (ep, ew)
+    assert gp < max(3e-5, 3 * yp) and gw < max(1e-5, 3 * yw), (gp, yp, gw, yw)
