@@ -232,7 +232,8 @@ template <typename R> struct Engine : EngineBase {
     int* n_noise_dev = nullptr;            // [B]
     unsigned short* lane_mask_tmp = nullptr;
     int n_noise_max = 0;
-    bool noise_valid = false;              // col_list_noise / the zeros of ffb match the current target
+    bool noise_valid = false;              // col_list_noise matches the current target
+    bool ffb_zeroed = false;               // ... and so do the zeros of ffb (written since at NaN-target pixels only)
     bool row_split_noise_only = false;     // ... and the row kernel must read gh2 in those columns only (nothing else was written)
     int opt_mraf_split64 = 1;              // developer A/B (HGS_MRAF_SPLIT64=0 at create): float64 MRAF weight updates in two passes
     int row_blocks_pref = 0;               // its grid: two workgroups per CU, whole XCD line groups
@@ -1541,8 +1542,9 @@ template <typename R> struct Engine : EngineBase {
         noise_valid = false;
         return 0;
     }
-    // float64 single-pass MRAF: the columns that hold a NaN target as a list, the buffer of the noise part zeroed (its NaN-target
-    // pixels are rewritten by every pass; everything else must read as zero, also after the target moved)
+    // per-column single-pass MRAF: the columns that hold a NaN target as a list (the buffer of the noise part is zeroed by the
+    // caller once it decides for the single pass: its NaN-target pixels are rewritten by every pass, everything else must read
+    // as zero, also after the target moved)
     int refresh_noise() {
         if (int e = refresh_sparse()) return e;
         if (noise_valid) return 0;
@@ -1551,8 +1553,7 @@ template <typename R> struct Engine : EngineBase {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_noise_dev), (size_t)B * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_tmp), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
         }
-        if (!ffb) { if (dalloc(&ffb, (size_t)B * g.Ph * g.Pw)) return HGS_ERR_DEVICE; }
-        HIPCHK(hipMemsetAsync(ffb, 0, (size_t)B * g.Ph * g.Pw * sizeof(C), stream));
+        ffb_zeroed = false;
         hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
                            col_list_noise, n_noise_dev, lane_mask_tmp, 4);
         HIPCHK(hipGetLastError());
@@ -1992,10 +1993,21 @@ template <typename R> struct Engine : EngineBase {
             // launch over the columns that hold noise (CParams::split): one forward transform and one read of weights and
             // target per column instead of two
             // (float32 too where the tile-resident kernel does not run: SLM rows over more than six register slots, short columns)
-            const bool split64 = two_pass && !tile_path && g.Pw >= 4096 && opt_mraf_split && opt_mraf_split64;
+            const bool split64_ok = two_pass && !tile_path && g.Pw >= 4096 && opt_mraf_split && opt_mraf_split64;
+            // (a column list: only where at most half of the listed columns hold noise -- where every one does, as around a noise
+            //  box, the single pass saves no transform and pays the extra launch: measured 119 against 105 us at 4096^2)
+            bool split64 = split64_ok;
+            if (split64) {
+                if (int e = refresh_noise()) return e;
+                if (sp && n_noise_max * 2 > n_active_max) split64 = false;
+            }
+            if (split64 && !ffb_zeroed) {
+                if (!ffb) { if (dalloc(&ffb, (size_t)B * g.Ph * g.Pw)) return HGS_ERR_DEVICE; }
+                HIPCHK(hipMemsetAsync(ffb, 0, (size_t)B * g.Ph * g.Pw * sizeof(C), stream));
+                ffb_zeroed = true;
+            }
             const bool split_any = split || split64;
             if (split_any && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
-            if (split64) { if (int e = refresh_noise()) return e; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
             // one more forward-only pass that just accumulates it
             const bool nog = st->method == HGS_WGS_NOGRETTE && p.do_update;

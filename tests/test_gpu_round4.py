@@ -262,12 +262,12 @@ def test_dispatch_read_buffer_protocol_and_device_upload_errors():
 
 # ---- float64 MRAF with a weight update in one column pass ---------------------------------------------------------------
 def _mraf_frame(shape, dtype, box=True):
-    """Image in the middle, NaN (noise) frame around it, zeros outside -- or (box False) NaN rows across the whole width."""
+    """Image in the middle with a NaN (noise) patch above part of it, zeros outside -- or (box False) NaN rows across the whole width."""
     H, W = shape
     t = np.zeros(shape, dtype)
-    if box:
-        t[H // 4:3 * H // 4, W // 2 - W // 8:W // 2 + W // 8] = np.nan
-        t[H // 3:2 * H // 3, W // 2 - W // 16:W // 2 + W // 16] = synth.random_target(5, (2 * H // 3 - H // 3, W // 8), 0.2, 1.0, dtype=dtype)
+    if box:      # (noise in a quarter of the image's columns: a column list takes the single pass where at most half of it holds noise)
+        t[H // 3:2 * H // 3, W // 2 - W // 8:W // 2 + W // 8] = synth.random_target(5, (2 * H // 3 - H // 3, W // 4), 0.2, 1.0, dtype=dtype)
+        t[H // 8:H // 3, W // 2 - W // 32:W // 2 + W // 32] = np.nan
     else:
         t[:] = synth.random_target(5, shape, 0.2, 1.0, dtype=dtype)
         t[: H // 5, :] = np.nan

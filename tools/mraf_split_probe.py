@@ -17,7 +17,8 @@ def target(n):
     return t
 
 
-for n, slm in ((4096, (800, 1280)), (4096, (1152, 1920)), (8192, (1152, 1920)), (8192, (2600, 1920))):
+# (the last two: SLM rows over more than six register slots -- no tile-resident kernel, the per-column kernel's single pass)
+for n, slm in ((4096, (800, 1280)), (4096, (1152, 1920)), (8192, (1152, 1920)), (8192, (2600, 1920)), (4096, (2048, 1920)), (8192, (3600, 1920))):
     t = target(n)
     for sparse in (0, 1):
         res = {}
