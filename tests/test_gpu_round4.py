@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch          # before the first engine: torch's HIP runtime opens the GPU first (slmsuite_amd._lib)
 
-from conftest import dispatch_of, rel_l2, phase_rel_l2, report
+from conftest import Dispatch, dispatch_of, rel_l2, phase_rel_l2, report
 from slmsuite_amd import _lib as L
 from slmsuite_amd import synth
 from slmsuite_amd.engine import Engine
@@ -354,3 +354,27 @@ def test_float32_single_pass_mraf_on_the_per_column_kernel(shape, slm, method, e
            phase_vs_f64=gp, weights_vs_f64=gw, oracle32_phase_vs_f64=yp, oracle32_weights_vs_f64=yw)
     assert ew < 1e-6 and ep < 3e-6, (ep, ew)
     assert gp < max(3e-5, 3 * yp) and gw < max(1e-5, 3 * yw), (gp, yp, gw, yw)
+
+
+def test_float64_single_pass_mraf_in_a_batch():
+    """Three holograms in one engine, per-hologram noise columns (one of them has no NaN at all): the noise list, the
+    farfield buffer of the noise part and the SPLIT row launch are per hologram -- against the same holograms one at a time."""
+    from slmsuite_amd.batch import HologramBatch
+    shape, slm, dt = (64, 4096), (40, 1500), np.float64
+    targets = np.stack([_mraf_frame(shape, dt, box=False), _mraf_frame(shape, dt, box=True),
+                        synth.random_target(9, shape, 0.2, 1.0, dtype=dt)])
+    phases = np.stack([synth.seed_phase(70 + i, slm, dtype=dt) for i in range(3)])
+    hb = HologramBatch(shape, slm, targets, phases, dtype=dt)
+    try:
+        hb.set_option(L.OPT_SPARSE_COLUMNS, 0)
+        hb.optimize("WGS-Leonardo", maxiter=3, mraf_factor=0.5)
+        d = Dispatch(hb.engine.dispatch_read())
+        got = hb.phases()
+    finally:
+        hb.close()
+    assert d.count("col_kernel", N=64, MODE=24, flags=["list"]) == 2 and d.count("row_kernel", N=4096, SPLIT=True) == 2, d
+    for i in range(3):
+        h = Hologram(targets[i].copy(), phase=phases[i].copy(), slm_shape=slm, dtype=dt, engine_options={L.OPT_SPARSE_COLUMNS: 0})
+        h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5)
+        assert phase_rel_l2(got[i], h.phase) < 1e-10, i
+        h._release_engine()
