@@ -378,3 +378,22 @@ def test_float64_single_pass_mraf_in_a_batch():
         h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5)
         assert phase_rel_l2(got[i], h.phase) < 1e-10, i
         h._release_engine()
+
+
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_float64_single_pass_mraf_with_statistics(sparse):
+    """... with stat_groups = ["computational"] (the statistics unit of the per-column kernel takes the same single pass) and
+    WGS-Kim fixing by efficiency off: history of efficiency / uniformity and end state against the oracle."""
+    from oracle import hgs_oracle as orc
+    shape, slm, dt = (128, 4096), (70, 1800), np.float64
+    target = _mraf_frame(shape, dt, box=bool(sparse))
+    phase0 = synth.seed_phase(23, slm, dtype=dt)
+    h = Hologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+    h.optimize("WGS-Leonardo", maxiter=4, verbose=False, mraf_factor=0.5, stat_groups=["computational"])
+    d = dispatch_of(h)
+    assert d.count("col_fused_kernel", N=128, STATS=True) == 4 and d.count("col_kernel", MODE=24) == 3 and d.count("row_kernel", SPLIT=True) == 3, d
+    o = orc.OracleHologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt)
+    o.optimize("WGS-Leonardo", maxiter=4, mraf_factor=0.5, stat_groups=["computational"])
+    assert phase_rel_l2(h.phase, o.phase) < 1e-9 and rel_l2(np.nan_to_num(h.weights), np.nan_to_num(o.weights)) < 1e-9
+    for key in ("efficiency", "uniformity", "pkpk_err", "std_err"):
+        np.testing.assert_allclose(h.stats["stats"]["computational"][key], o.stats["stats"]["computational"][key], rtol=1e-8, atol=1e-12, err_msg=key)
