@@ -221,6 +221,8 @@ template <typename R> struct Engine : EngineBase {
     int opt_sep_min = 96;                  // smallest spot count the matrix-core form is used for (tools/sep_crossover.py)
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
+    int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
+    int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
     int opt_row_pref = 1;                  // developer A/B (HGS_ROW_PREF=0 at create): prefetching row kernel off
     int opt_mraf_split = 1;                // developer A/B (HGS_MRAF_SPLIT=0 at create): MRAF weight updates in two column passes
@@ -384,6 +386,8 @@ template <typename R> struct Engine : EngineBase {
         // HGS_TRACE_INIT=1: where hgs_create spends its time (developer aid, stderr)
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
+        opt_tile_nr4 = env_int("HGS_TILE_NR4", 1);
+        opt_tile_shift16 = env_int("HGS_TILE_SHIFT16", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
         opt_mraf_split64 = env_int("HGS_MRAF_SPLIT64", 1);
@@ -1023,10 +1027,10 @@ template <typename R> struct Engine : EngineBase {
         return launch_fused<R>(g.Ph, phase_mode, grid, stream, a);
     }
     // (the tile-resident kernel is fp32 only; this branch is never taken for double)
-    static int tile_rule(int N, int phase, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-        return a.col_list != nullptr ? launch_tile_rule_listed(N, phase, rule, grid, s, a, m0) : launch_tile_rule(N, phase, rule, grid, s, a, m0);
+    static int tile_rule(int N, int phase, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
+        return a.col_list != nullptr ? launch_tile_rule_listed(N, phase, rule, nr, grid, s, a, m0) : launch_tile_rule(N, phase, rule, nr, grid, s, a, m0);
     }
-    static int tile_rule(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
+    static int tile_rule(int, int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
     static int tile_split(int N, int phase, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
         return a.do_stats ? launch_tile_split_stats(N, phase, nr, rule_ok, grid, s, a, m0) : launch_tile_split(N, phase, nr, rule_ok, grid, s, a, m0);
     }
@@ -1472,10 +1476,13 @@ template <typename R> struct Engine : EngineBase {
         return 0;
     }
     // the tile-resident fused column kernel applies: fp32, 4096 / 8192 rows, the SLM rows within six register slots
+    // (the kernel shifts its transform input by tile_shift() rows -- any multiple of 16 keeps the shift-theorem factor a
+    //  per-lane constant -- so the SLM rows start in the first 16 rows of register slot 0)
+    int tile_shift() const { return opt_tile_shift16 ? (g.r0 / 16) * 16 : (g.r0 / (g.Ph / 16)) * (g.Ph / 16); }
+    int tile_slots() const { const int Tc = g.Ph / 16; return (g.r0 - tile_shift() + g.Sh + Tc - 1) / Tc; }
     bool tile_geometry_ok() const {
         if (sizeof(R) != 4 || g.Ph < 4096 || !opt_tile) return false;
-        const int Tc = g.Ph / 16;
-        return (g.r0 + g.Sh - 1) / Tc - g.r0 / Tc + 1 <= 6;
+        return tile_slots() <= 6;
     }
     // columns a workgroup pass of the column kernels handles side by side (ColCfg<N>::CPAR)
     int col_cpar() const {
@@ -1983,8 +1990,7 @@ template <typename R> struct Engine : EngineBase {
             // ... unless the tile-resident kernel runs the column pass: the inverse transform is linear, so it transforms the
             // signal part (un-normalised new weights) and the noise part separately in ONE pass and the row kernel joins
             // them once ||w'|| is known (col_tile_kernel RULE 3, row_kernel SPLIT)
-            const int Tc = g.Ph / 16;
-            const int m0 = g.r0 / Tc, m1 = (g.r0 + g.Sh - 1) / Tc;      // slots of the load layout the SLM rows occupy
+            const int m0 = tile_shift(), m1 = m0 + tile_slots() - 1;   // (m0: row shift; m1 - m0 + 1 = slots of the load layout the SLM rows occupy)
             const bool tile_path = (!sp || sparse_tiles) && tile_geometry_ok();
             // (a column list rounded to whole tiles: the same kernels walk the list)
             const int tile_grid = sp ? std::max(1, std::min(tile_blocks, n_active_max / 4)) : tile_blocks;
@@ -2090,7 +2096,7 @@ template <typename R> struct Engine : EngineBase {
                             const int rule = !opt_tile_rule ? 0 : !a.cp.do_update ? 2
                                              : (a.cp.method == HGS_WGS_LEONARDO || a.cp.method == HGS_WGS_KIM) ? 1 : 0;
                             if (a.do_stats) LCHK(launch_tile_stats<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
-                            else if (rule != 0) LCHK(tile_rule(g.Ph, phase_mode, rule, dim3(tile_grid, B), stream, a, m0));
+                            else if (rule != 0) LCHK(tile_rule(g.Ph, phase_mode, rule, opt_tile_nr4 ? m1 - m0 + 1 : 6, dim3(tile_grid, B), stream, a, m0));
                             else LCHK(launch_tile<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
                         }
                     } else {

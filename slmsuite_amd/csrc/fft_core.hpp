@@ -45,6 +45,9 @@
 #ifndef HGS_TRACE_OFF
 #define HGS_TRACE_OFF 49152
 #endif
+#ifndef HGS_TRACE_SKIP
+#define HGS_TRACE_SKIP 0          // events of a wave that are passed over before the first one is recorded
+#endif
 
 namespace hgs {
 
@@ -52,8 +55,8 @@ namespace hgs {
 __device__ __forceinline__ void trace_event(int& n, int ev) {
     extern __shared__ __attribute__((aligned(16))) char trace_smem[];
     const unsigned long long t = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0 && n < 128)
-        reinterpret_cast<unsigned long long*>(trace_smem + HGS_TRACE_OFF)[(threadIdx.x >> 6) * 128 + n] =
+    if ((threadIdx.x & 63) == 0 && n >= HGS_TRACE_SKIP && n < HGS_TRACE_SKIP + 128)
+        reinterpret_cast<unsigned long long*>(trace_smem + HGS_TRACE_OFF)[(threadIdx.x >> 6) * 128 + (n - HGS_TRACE_SKIP)] =
             (t & 0x00ffffffffffffffull) | ((unsigned long long)ev << 56);
     ++n;
 }
@@ -804,14 +807,19 @@ template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k
         } else {
             static_for<0, 16>([&](auto n_) { constexpr int n2 = n_; u[n2] = v[n2]; });
         }
+        HGS_T(tr_n, 16);                               // radix-2 step + pair exchange done
+        core.tr_n = tr_n;
         core.template forward_flow<-1, (2 * NI < 16 ? (2 * NI < 4 ? 4 : 2 * NI) : 16)>(u, lds + (j & 1) * IMG, j >> 1);
+        tr_n = core.tr_n;
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = u[m]; });
     }
     template <bool LEAD, int NOUT> __device__ __forceinline__ void mirror(Cx<R> (&v)[16], Cx<R>* lds, int j) {
         static_assert(NOUT >= 2 && NOUT <= 16, "WgFftL8k: leading wanted registers");
         constexpr bool HALF = NOUT <= 8;               // registers 8.. of the result are not wanted
         constexpr int NI = HALF ? NOUT : 8;
+        core.tr_n = tr_n;
         core.template mirror_flow<+1, LEAD, (2 * NI < 16 ? 2 * NI : 16)>(v, lds + (j & 1) * IMG, j >> 1);
+        tr_n = core.tr_n;
         Cx<R> y0[8], y1[8];
         if (!HGS_ABL_XCHG) {
             wave_lds_order();                          // the core's last exchange read these regions
@@ -831,6 +839,7 @@ template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k
                 if constexpr (!HALF) v[i + 8] = y0[i] - t;
             });
         }
+        HGS_T(tr_n, 26);                               // pair exchange + radix-2 step done
     }
     __device__ __forceinline__ void fwd(Cx<R> (&v)[16], Cx<R>* lds, int j) { forward<16>(v, lds, j); }
     template <int NZ> __device__ __forceinline__ void fwd_lead(Cx<R> (&v)[16], Cx<R>* lds, int j) { forward<NZ>(v, lds, j); }

@@ -1218,11 +1218,17 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         col_of(q, ct, c4);
         const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c4) * g.Ph;
         const bool vcol = col_valid(q);
+        HGS_T(fft.tr_n, 1);
+#if HGS_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        HGS_T(fft.tr_n, 2);
         static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
         // fp64: this column's weights / targets land under its forward transform (8192: after it -- the 64 registers
         // would not fit next to the transform's own)
         if constexpr (LEAN && N < 8192) issue_wt(q);
         fft.fwd(v, lds, j);
+        HGS_T(fft.tr_n, 3);
         // fp64: the 16 transformed values of a lane (64 VGPRs) wait in the idle LDS image while the constraint runs --
         // lane-private slots [m * T + j], conflict-free, no barrier -- so that the rule (inlined double log2 / exp2,
         // atan2, sincos) does not sit on top of them: with v, weights and targets all in registers every fp64
@@ -1232,6 +1238,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; park[m * T] = v[m]; });
             if constexpr (N >= 8192) issue_wt(q);
         }
+#if HGS_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        HGS_T(fft.tr_n, 4);
 
         // ---- constraint + weight update on F = sc * v ----
         R* wc = a.w + cb;
@@ -1336,6 +1346,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             });
             if constexpr (STATS) sacc.flush(stat_slot);
         }
+        HGS_T(fft.tr_n, 5);
         // ---- prefetch the next column while this one is transformed back ----
         if (q + 1 < ncols) {
             if constexpr (!LEAN) {
@@ -1363,17 +1374,28 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 });
             }
         }
+        HGS_T(fft.tr_n, 6);
         if constexpr (!LEAN) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = gn[m]; });
         } else if (q + 1 < ncols) {
             issue_g(q + 1, v);
         }
     }
+    HGS_T(fft.tr_n, 7);
     if constexpr (STATS) StatAcc<R>::slot_store(stat_slot, a.spartial, b);
     if (do_upd) {
         const double s = block_sum((double)acc_w, scratch);
         if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }
+#if HGS_TRACE
+    __syncthreads();
+    {   // dump this workgroup's events (128 per wave) through fpartial
+        const int nev = ((int)blockDim.x >> 6) * 128;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fpartial) + (size_t)blockIdx.x * nev;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + HGS_TRACE_OFF);
+        for (int i = tid; i < nev; i += blockDim.x) dst[i] = src[i];
+    }
+#endif
 }
 
 // =====================================================================================================
@@ -1382,10 +1404,13 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
 // accesses into registers, the four columns are transformed from/to those registers, and the tile
 // is stored back with 32-byte accesses -- every GH byte crosses the memory system once per kernel.
 //
-// The SLM rows start at r0, i.e. at register slot m0 = r0/T of the load layout.  A circular shift
-// of the transform input by s = m0*T rows makes the occupied slots 0..NR-1 for every geometry
-// (static register indices); by the shift theorem it multiplies output k by exp(-2 pi i k m0/16),
-// which is a per-lane constant (k = j mod 16 in load layout) folded into the scale multiply.
+// The SLM rows start at r0.  A circular shift of the transform input by s rows makes the occupied
+// register slots of the load layout 0..NR-1 for every geometry (static register indices); by the
+// shift theorem it multiplies output k = j + m T by exp(-2 pi i k s / N), and for every s that is a
+// multiple of 16 that is a per-lane constant (m T s / N = m s / 16 is an integer), folded into the
+// scale multiply.  s = r0 rounded down to a multiple of 16 (round 5; rounds 2 - 4 shifted by whole
+// slots, s = (r0 / T) T): the SLM rows then start in the first 16 rows of slot 0 and occupy
+// ceil((r0 % 16 + Sh) / T) slots -- 1152 rows on 4096: 5 instead of 6, on 8192: 3 instead of 4.
 // =====================================================================================================
 // one tile row = 4 adjacent columns = 32 bytes (fp32): two 16-byte accesses per lane
 __device__ __forceinline__ void load_row4(const Cx<float>* p, Cx<float> (&o)[4]) {
@@ -1446,7 +1471,7 @@ template <typename R, int N> constexpr size_t col_tile_split_lds_bytes() {
 // LISTED: -1 = the tile schedule is decided at run time (a.col_list), 0 / 1 = compiled in (the hot dense launches lose
 // 0.4 us of 51.5 with the run-time form).
 template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0, int LISTED = -1>
-__global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int m0) {
+__global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs<R> a, int shift) {
     using M = Math<R>;
     constexpr int T = N / 16;
     static_assert(T >= 256, "tile-resident kernel is for one column per workgroup pass");
@@ -1472,9 +1497,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     const size_t P = (size_t)g.Ph * g.Pw;
     const R wsc = a.wscale[b];
     // shift-theorem factor of this lane, with the (-1)^k sign and the ortho scale folded in
-    Cx<R> om = a.tw[((m0 * (j & 15)) & 15) * (N / 16)];
+    Cx<R> om = a.tw[(j * shift) & (N - 1)];          // (shift: rows, a multiple of 16)
     om = om * (sgn * a.scale);
-    const int r_lane = js + m0 * T - g.r0;  // SLM row of slot m is r_lane + m*T
+    const int r_lane = js + shift - g.r0;   // SLM row of slot m is r_lane + m*T
     // tile schedule: every tile of 4 columns, or (col_list != nullptr: sparse targets whose active set the host has
     // rounded to whole tiles) the tiles of the listed columns -- entries 4 i .. 4 i + 3 of the list are tile list[4 i] / 4
     const bool listed = LISTED < 0 ? a.col_list != nullptr : LISTED != 0;
@@ -1507,7 +1532,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     // TPREF: staging image of the workgroup's next tile, wave-private 1 KiB blocks [slot][half][wave][lane * 16 bytes];
     // used when the SLM rows fit the first TILE_PREF_SLOTS register slots (uniform)
     char* pstage = reinterpret_cast<char*>(scratch + SCRATCH_DOUBLES);
-    const bool tpref = TPREF && !SPLIT && (TILE_PREF_SLOTS * T + m0 * T - g.r0 >= g.Sh);
+    const bool tpref = TPREF && !SPLIT && (TILE_PREF_SLOTS * T + shift - g.r0 >= g.Sh);
     // SPLIT: the staging space holds the noise part of the column (lane-private: element m of lane j at m T + j) and a flag
     Cx<R>* park = reinterpret_cast<Cx<R>*>(pstage);
     int* nflag = reinterpret_cast<int*>(pstage + (size_t)N * sizeof(Cx<R>));
@@ -1701,6 +1726,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 } else if constexpr (SPLIT) {
                     park[m * T + j] = mk<R>(0, 0);
                 }
+                // PHASE 1: the stored phase leaves four pixels (16 contiguous bytes) at a time -- sixteen of them kept until
+                // after the loop put the 4096 / 8192-point RULE 1 instances 12 / 8 registers over their 256
+                if constexpr (PHASE == 1 && m % 4 == 3) {
+                    static_for<m - 3, m + 1>([&](auto i_) { constexpr int i = i_; pfc[lane_pos<T>(j, i)] = pf[i]; });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 4) - 1) __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (SPLIT) { if (noise_any) *nflag = 1; }
@@ -1709,8 +1740,6 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             if (do_upd && w_changed) {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
             }
-            if constexpr (PHASE == 1)
-                static_for<0, 16>([&](auto m_) { constexpr int m = m_; pfc[lane_pos<T>(j, m)] = pf[m]; });
             // weights/target of the next column (or of the first column of the next tile) land
             // under the inverse transform below and the next forward transform
             {
@@ -1746,10 +1775,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 //  inverse above was skipped)
                 const int any = cflags >= 0 ? ((cflags & 4) != 0) : __builtin_amdgcn_readfirstlane(*nflag);
                 tile_noise |= any;
+                HGS_T(fft.tr_n, 8);
                 if (any) {
                     static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = park[m * T + j]; });
                     fft.template inv_trail<NR>(v, lds, j);
                 }
+                HGS_T(fft.tr_n, 9);
 #pragma unroll
                 for (int m = 0; m < NR; ++m) {
                     const Cx<R> h = any ? v[m] * (sgs * a.scale) : mk<R>(0, 0);
@@ -1799,10 +1830,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     }
 #if HGS_TRACE
     __syncthreads();
-    {   // dump this workgroup's events: wpartial doubles as the destination in the microbenchmark
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fpartial) + (size_t)blockIdx.x * 512;
+    {   // dump this workgroup's events (128 per wave): fpartial doubles as the destination in the microbenchmark
+        const int nev = ((int)blockDim.x >> 6) * 128;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fpartial) + (size_t)blockIdx.x * nev;
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + HGS_TRACE_OFF);
-        for (int i = j; i < 512; i += blockDim.x) dst[i] = src[i];
+        for (int i = j; i < nev; i += blockDim.x) dst[i] = src[i];
     }
 #endif
 }

@@ -28,8 +28,9 @@ template <typename R> int launch_tile_extras(int N, int phase_mode, dim3 grid, h
 template <typename R> int launch_tile_extras_stats(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<R>& a, int m0);
 
 // ... and with the weight rule compiled in (rule 1: WGS-Leonardo / WGS-Kim update, 2: no update; no statistics, no extras)
-int launch_tile_rule(int N, int phase_mode, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
-int launch_tile_rule_listed(int N, int phase_mode, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);   // a.col_list set
+// (nr: register slots the SLM rows occupy; <= 4 runs the NR = 4 instances)
+int launch_tile_rule(int N, int phase_mode, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
+int launch_tile_rule_listed(int N, int phase_mode, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);   // a.col_list set
 
 // single-pass MRAF with a weight update (col_tile_kernel RULE 3 writes a.gh / a.gh2, row_kernel SPLIT joins them); fp32,
 // N in {4096, 8192}

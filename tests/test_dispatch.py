@@ -40,7 +40,7 @@ def test_record_names_template_arguments_and_clears():
 @pytest.mark.parametrize("n, dtype, family, extra", [
     (512, np.float32, "col_fused_kernel", dict(R="float", N=512)),
     (2048, np.float32, "col_fused_kernel", dict(R="float", N=2048)),
-    (4096, np.float32, "col_tile_kernel", dict(R="float", N=4096, NR=6, LISTED=0)),
+    (4096, np.float32, "col_tile_kernel", dict(R="float", N=4096, NR=5, LISTED=0)),     # 1032 SLM rows from row 1532: five slots of 256
     (1024, np.float64, "col_fused_kernel", dict(R="double", N=1024, RULE=0)),
     (4096, np.float64, "col_fused_kernel", dict(R="double", N=4096, RULE=0)),      # the tile-resident kernel is fp32 only
 ])

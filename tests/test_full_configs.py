@@ -38,7 +38,7 @@ def assert_cfg2_column_path(h, path, update=True):
         assert d.count("row_kernel", flags=["load_mask", "store_mask"], MODE=2) > 0 or d.count("row_kernel", MODE=2) == 0, d
         assert d.count("row_kernel", PREF=True) == 0, d
     elif path == "dense":
-        assert d.count("col_tile_kernel", without=["list"], R="float", N=4096, NR=6, RULE=rule, LISTED=0, STATS=False, EXTRAS=False) > 0, d
+        assert d.count("col_tile_kernel", without=["list"], R="float", N=4096, NR=5, RULE=rule, LISTED=0, STATS=False, EXTRAS=False) > 0, d
         assert d.count("col_fused_kernel") == 0 and d.count("col_tile_kernel", flags=["list"]) == 0, d
         n2 = d.count("row_kernel", MODE=2)
         assert n2 == 0 or d.count("row_kernel", MODE=2, NS=8, PREF=True, SPLIT=False, without=["load_mask", "store_mask"]) == n2, d

@@ -326,7 +326,7 @@ def test_single_pass_mraf_matches_the_two_pass_form(n, slm, method, extra, monke
         h.optimize(method, maxiter=2, verbose=False, mraf_factor=0.5, **extra)
         d = dispatch_of(h)
         Tc = n // 16
-        nr_slots = ((n - slm[0]) // 2 + slm[0] - 1) // Tc - ((n - slm[0]) // 2) // Tc + 1
+        nr_slots = (((n - slm[0]) // 2) % 16 + slm[0] + Tc - 1) // Tc         # (the kernel shifts by r0 rounded down to 16 rows)
         nr = 4 if nr_slots <= 4 else 6
         # body 0 has no weight update (one plain MRAF pass); body 1 updates: ONE pass of RULE 3 + a SPLIT row launch, or
         # two passes of the generic kernel (forward + rule, then forward + rebuild + inverse) + a plain row launch

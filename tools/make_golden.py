@@ -8,7 +8,7 @@ fixtures do).  Nothing from the reference is copied: fixtures hold inputs and ou
 
     python tools/make_golden.py            # small fixtures (seconds)
     python tools/make_golden.py --cfg2     # additionally the 4096^2 config-2 summaries: cfg2 (~3 min), cfg2kim
-                                           # (~2 min), cfg2seeds (16 runs, ~12 min on 4 cores), cfg2steps (~3 min, 27 MB); --only NAME picks one
+                                           # (~2 min), cfg2seeds, cfg2seedsb (16 runs each, ~12 min on 4 cores), cfg2steps (~3 min, 27 MB); --only NAME picks one
 """
 import argparse
 import json
@@ -560,13 +560,17 @@ def _cfg2_seed_run(job):
         np.stack([curve[k] for k in CFG2_CURVE_ITERS])
 
 
-def gen_cfg2_seeds(alg):
+CFG2_SEEDS_B = (17, 18, 19, 20, 21, 22, 23, 24)     # round 5: eight more, for the statistics of engine / ideal-fp32
+
+
+def gen_cfg2_seeds(alg, seeds=None, name="cfg2_seeds"):
     """
     cfg 2 from eight seed phases, each also from the seed perturbed by about one fp32 ulp: the spot amplitudes the
     reference ends on, and how far its OWN result moves under a 1-ulp change of the input (the floor under which no
     fp32 implementation that is not bit-identical to NumPy can be expected to land).  ~2.5 min per run, 4 at a time.
     """
     import multiprocessing as mp
+    CFG2_SEEDS = tuple(seeds) if seeds is not None else globals()["CFG2_SEEDS"]
     jobs = [(s, p) for s in CFG2_SEEDS for p in (False, True)]
     with mp.get_context("spawn").Pool(4) as pool:
         res = pool.map(_cfg2_seed_run, jobs)
@@ -579,7 +583,7 @@ def gen_cfg2_seeds(alg):
         (amp_p if pert else amp)[i] = a
         (w_p if pert else w)[i] = ww
         (cur_p if pert else cur)[i] = cv
-    save("cfg2_seeds", dict(kind="cfg2_seeds", seeds=list(CFG2_SEEDS), shape=(4096, 4096), slm_shape=(1152, 1920),
+    save(name, dict(kind="cfg2_seeds", seeds=list(CFG2_SEEDS), shape=(4096, 4096), slm_shape=(1152, 1920),
                             maxiter=50, method="WGS-Leonardo", curve_iters=list(CFG2_CURVE_ITERS),
                             perturbation="phase * (1 + 1e-7 * N(0,1)), default_rng(1000 + seed), rounded to fp32"),
          dict(spot_ampff=amp, spot_ampff_perturbed=amp_p, spot_weights=w, spot_weights_perturbed=w_p,
@@ -750,6 +754,7 @@ def main():
         steps["cfg2"] = lambda: gen_cfg2(alg)
         steps["cfg2kim"] = lambda: gen_cfg2kim(alg)
         steps["cfg2seeds"] = lambda: gen_cfg2_seeds(alg)
+        steps["cfg2seedsb"] = lambda: gen_cfg2_seeds(alg, CFG2_SEEDS_B, "cfg2_seeds_b")
         steps["cfg2steps"] = lambda: gen_cfg2_steps(alg)
     for name, fn in steps.items():
         if args.only and name != args.only:

@@ -34,6 +34,6 @@ int main() {
     hipLaunchKernelGGL((row_kernel<float, 4096, 0>), dim3(1152), dim3(256), lds, 0, ra);
     printf("ABL trans=%d xchg=%d bfly=%d : row<2> %.1f us   col_tile %.1f us\n", HGS_ABL_TRANS, HGS_ABL_XCHG, HGS_ABL_BFLY,
            timeit([&] { hipLaunchKernelGGL((row_kernel<float, 4096, 2>), dim3(1152), dim3(256), lds, 0, ra); }),
-           timeit([&] { hipLaunchKernelGGL((col_tile_kernel<float, 4096, 0, 6>), dim3(512), dim3(256), tlds, 0, ca, 5); }));
+           timeit([&] { hipLaunchKernelGGL((col_tile_kernel<float, 4096, 0, 6>), dim3(512), dim3(256), tlds, 0, ca, 5 * 256); }));
     return 0;
 }

@@ -31,9 +31,9 @@ int main() {
     auto k = col_tile_kernel<float, 4096, 0, 6, false, false>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(512), dim3(256), lds, 0, ca, 5);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(512), dim3(256), lds, 0, ca, 5 * 256);
     hipDeviceSynchronize(); hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k, dim3(512), dim3(256), lds, 0, ca, 5);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k, dim3(512), dim3(256), lds, 0, ca, 5 * 256);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("col_tile (traced build) %.1f us per launch\n", ms / 10 * 1e3f);
