@@ -221,6 +221,12 @@ template <typename R> struct Engine : EngineBase {
     int opt_sep_min = 96;                  // smallest spot count the matrix-core form is used for (tools/sep_crossover.py)
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
+    // G left behind (round 5): the last launch of a fused hgs_iterate call is row_kernel MODE 3 -- it writes the phase AND the
+    // row-transformed field of the next body -- and the next call (or hgs_nearfield2farfield) skips its own first row launch
+    // while nothing that G depends on (phase, amplitude, kernel, the set of stored columns) has changed.
+    //   gh_state: -1 = gh does not hold G; 0 = G of every column; 1 = of the active columns; 2 = of the dilated active columns
+    int gh_state = -1;
+    int opt_keep_g = 1;                    // developer A/B (HGS_KEEP_G=0 at create)
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
     int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
@@ -387,6 +393,7 @@ template <typename R> struct Engine : EngineBase {
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_tile_nr4 = env_int("HGS_TILE_NR4", 1);
+        opt_keep_g = env_int("HGS_KEEP_G", 1);
         opt_tile_shift16 = env_int("HGS_TILE_SHIFT16", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
@@ -1134,6 +1141,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int set_array(int which, const void* host, size_t nbytes, bool src_device) override {
+        if (which == HGS_PHASE || which == HGS_AMP || which == HGS_AMP_SCALAR || which == HGS_PROP_KERNEL) gh_state = -1;
         if (which == HGS_PROP_KERNEL && nbytes == 0) {       // "no kernel" (Hologram.propagation_kernel = None / 0)
             has_kern = false;
             farfield_valid = false;
@@ -1165,6 +1173,7 @@ template <typename R> struct Engine : EngineBase {
                     double* part = nullptr;
                     HIPCHK(hipMalloc(reinterpret_cast<void**>(&part), (size_t)nb * sizeof(double)));
                     hipLaunchKernelGGL(ew_sumsq<R>, dim3(nb, 1), dim3(256), 0, stream, (const R*)amp, S, part);
+                    if (hipGetLastError() != hipSuccess) { hipFree(part); return fail(HGS_ERR_DEVICE, "amplitude norm launch failed"); }
                     std::vector<double> hp(nb);
                     hipError_t e1 = hipMemcpyAsync(hp.data(), part, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, stream);
                     hipError_t e2 = hipStreamSynchronize(stream);
@@ -1173,7 +1182,8 @@ template <typename R> struct Engine : EngineBase {
                     for (double v : hp) s += v;
                 } else {
                     const R* h = (const R*)host;
-                    for (size_t i = 0; i < S; ++i) s += (double)h[i] * (double)h[i];
+                    // (NaN entries skipped, like ew_sumsq on the device path and the reference's nansum normalisation)
+                    for (size_t i = 0; i < S; ++i) { const double v = (double)h[i]; if (v == v) s += v * v; }
                 }
                 amp_norm2 = s;
                 farfield_valid = false;
@@ -1304,6 +1314,7 @@ template <typename R> struct Engine : EngineBase {
         }
         HIPCHK(hipStreamSynchronize(stream));
         farfield_valid = false;
+        gh_state = -1;
         return 0;
     }
 
@@ -1421,7 +1432,15 @@ template <typename R> struct Engine : EngineBase {
         return a;
     }
     // load / store: 0 = every column, 1 = active columns, 2 = active columns dilated by the spot windows
+    // mode: row_kernel MODE (3 = MODE 2 that also writes the phase; float32 only)
     int run_row(int mode, bool finalize, int load_sparse = 0, int store_sparse = 0) {
+        gh_state = -1;
+        int r_ = run_row_impl(mode, finalize, load_sparse, store_sparse);
+        if (r_ == 0 && mode != 1) gh_state = store_sparse;      // gh holds G of the columns this launch stored
+        return r_;
+    }
+    bool gh_holds(int need) const { return opt_keep_g && (gh_state == need || gh_state == 0 || (gh_state == 2 && need == 1 && dil_valid)); }
+    int run_row_impl(int mode, bool finalize, int load_sparse, int store_sparse) {
         return timed(HGS_K_ROW, [&]() -> int {
             RowArgs<R> a = row_args(finalize);
             a.load_mask = load_sparse == 1 ? lane_mask : load_sparse == 2 ? lane_mask_d : nullptr;
@@ -1456,6 +1475,7 @@ template <typename R> struct Engine : EngineBase {
     // active columns dilated by the offsets [lo, hi] of the spot integration window
     int refresh_dilated(int lo, int hi) {
         if (dil_valid && lo == dil_lo && hi == dil_hi) return 0;
+        if (gh_state == 2) gh_state = -1;
         if (!col_active_d) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_active_d), (size_t)B * g.Pw));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list_d), (size_t)B * g.Pw * sizeof(int)));
@@ -1493,6 +1513,7 @@ template <typename R> struct Engine : EngineBase {
     // (re)build the active-column list when weights or target changed since the last scan
     int refresh_sparse() {
         if (!sparse_dirty) return 0;
+        if (gh_state > 0) gh_state = -1;       // (a G stored on the old column lists; one of every column stays good)
         if (!col_active) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_active), (size_t)B * g.Pw));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list), (size_t)B * g.Pw * sizeof(int)));
@@ -1591,7 +1612,8 @@ template <typename R> struct Engine : EngineBase {
         if (general) return n2f_general(store_pff);
         if (int e = need_ff()) return e;
         if (store_pff) { if (int e = need_pff()) return e; }
-        if (int e = run_row(0, false)) return e;
+        // (a fused loop that ended on its dense row launch left G of every column behind: the transform starts with its column pass)
+        if (!(opt_keep_g && gh_state == 0)) { if (int e = run_row(0, false)) return e; }
         int r = timed(HGS_K_COL_FWD, [&]() -> int {
             ColArgs<R> a = col_args();
             a.store_pff = store_pff;
@@ -1612,6 +1634,7 @@ template <typename R> struct Engine : EngineBase {
         if (general) return f2n_general(false);
         if (!ff || !farfield_valid) return fail(HGS_ERR_STATE, "no farfield to transform back");
         int r = timed(HGS_K_COL_INV, [&]() -> int {
+            gh_state = -1;
             LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(col_blocks, B), stream, col_args()));
             return 0;
         });
@@ -1643,6 +1666,7 @@ template <typename R> struct Engine : EngineBase {
             return r;
         }
         int r = timed(HGS_K_COL_INV, [&]() -> int {
+            gh_state = -1;
             LCHK(launch_col<R>(g.Ph, C_LOAD | C_INV, dim3(col_blocks, B), stream, col_args()));
             return 0;
         });
@@ -1865,8 +1889,12 @@ template <typename R> struct Engine : EngineBase {
         };
         farfield_valid = false;
         Plan p = plan_iteration(st, hist ? hist : nullptr);
-        if (int e = run_row(0, false, 0, windows_needed(p) ? 2 : 1)) return e;
+        if (!gh_holds(windows_needed(p) ? 2 : 1)) { if (int e = run_row(0, false, 0, windows_needed(p) ? 2 : 1)) return e; }
+        // what the last launch of the call stores for the next one (MODE 3): the dilated columns whenever a window may be
+        // read (they include the active ones)
+        const int store_end = (st->feedback == HGS_FB_SPOT_WINDOW || (groups & 2)) ? 2 : 1;
         for (int i = 0; i < n; ++i) {
+            gh_state = -1;
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
             const CParams<R> cp = cparams(st, p);
             if (windows_needed(p)) {
@@ -1925,7 +1953,8 @@ template <typename R> struct Engine : EngineBase {
                 pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
                 store_next = windows_needed(pn) ? 2 : 1;
             }
-            if (int e = run_row(i + 1 < n ? 2 : 1, false, 1, store_next)) return e;
+            const int last_mode = (opt_keep_g && sizeof(R) == 4) ? 3 : 1;
+            if (int e = run_row(i + 1 < n ? 2 : last_mode, false, 1, i + 1 < n ? store_next : store_end)) return e;
             p = pn;
         }
         return 0;
@@ -1979,8 +2008,10 @@ template <typename R> struct Engine : EngineBase {
         const int store_sparse = spot_stats ? 2 : 1;
         Plan p = plan_iteration(st, hist ? hist : nullptr);
         const bool sp = sparse_enabled;
-        if (int e = run_row(0, false, 0, sp ? store_sparse : 0)) return e;
+        // (the previous call may have left G of these columns behind: gh_state, row_kernel MODE 3)
+        if (!gh_holds(sp ? store_sparse : 0)) { if (int e = run_row(0, false, 0, sp ? store_sparse : 0)) return e; }
         for (int i = 0; i < n; ++i) {
+            gh_state = -1;          // the column pass turns G into H in place
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
             // MRAF with a weight update takes two passes over the columns: the rebuilt field mixes the
             // NORMALISED weights (signal region) with the un-weighted farfield (noise region), so ||w'|| has
@@ -2139,7 +2170,10 @@ template <typename R> struct Engine : EngineBase {
             if (i + 1 < n) pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
             // the row kernel that follows folds the weight-norm partials into wscale (unless already done);
             // on the sparse path it reads the active columns and writes those the next column launches read
-            if (int e = run_row(i + 1 < n ? 2 : 1, p.do_update != 0 && !two_pass, sp ? 1 : 0, sp ? store_sparse : 0))
+            // the last launch of the call extracts the phase; in float32 (and unless a single-pass MRAF body has to join its
+            // two parts) it also leaves G of the next body behind (MODE 3), for the next call on an unchanged phase
+            const int last_mode = (opt_keep_g && sizeof(R) == 4 && !row_split) ? 3 : 1;
+            if (int e = run_row(i + 1 < n ? 2 : last_mode, p.do_update != 0 && !two_pass, sp ? 1 : 0, sp ? store_sparse : 0))
                 return e;
             p = pn;
         }
@@ -2380,6 +2414,7 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int set_option(int option, int value) override {
+        gh_state = -1;             // (a policy change may change which columns the next launch expects in gh)
         switch (option) {
             case HGS_OPT_SPARSE_COLUMNS: opt_sparse = value ? 1 : 0; return 0;
             case HGS_OPT_FORCE_STEPWISE: opt_stepwise = value ? 1 : 0; return 0;

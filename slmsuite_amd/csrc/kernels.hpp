@@ -50,6 +50,15 @@
 #endif
 // Ablation hooks for tools/microbench/ablate.hip (all 0 in the product build): compile the weight/target
 // loads (WT) or the GH tile loads and stores (GH) out of col_tile_kernel to see what they cost.
+#ifndef HGS_TILE_STAGE_WAIT
+#define HGS_TILE_STAGE_WAIT 0   // 1: rounds 3 - 4, a vmcnt(0) ahead of reading the staged tile (it waited for the previous tile's STORES)
+#endif
+#ifndef HGS_F64_WT_PREFETCH
+#define HGS_F64_WT_PREFETCH 1   // float64 8192-point fused kernel: the column's weight / target lines on their way into L2 under its forward transform
+#endif
+#ifndef HGS_SPLIT_L2_PREFETCH
+#define HGS_SPLIT_L2_PREFETCH 1 // single-pass MRAF tile kernel (no LDS left for the staging): the next tile's rows into L2 under the first transform
+#endif
 #ifndef HGS_ABL_WT
 #define HGS_ABL_WT 0
 #endif
@@ -421,6 +430,9 @@ __device__ __forceinline__ double rsqrt_full(double x) { return 1.0 / ::sqrt(x);
 //   MODE 1 : H -> phase            (row half of ifft2 :1070 + _nearfield_extract :1026)
 //   MODE 2 : H -> phase -> G       (MODE 1 then MODE 0 of the next iteration, fused: the row never
 //                                   leaves the CU between the two iterations)
+//   MODE 3 : MODE 2 that also writes the phase: the LAST launch of an hgs_iterate call leaves G behind, so
+//            that the next call on an unchanged phase starts with its column launch (round 5; the G it
+//            leaves is MODE 2's, i.e. a loop cut into several calls runs the same arithmetic as one call)
 // grid = (<= ceil(Sh / FPW), batch), block = WG;  FPW = WG / T rows per workgroup pass; a workgroup
 // strides over rows so the per-lane twiddle registers are fetched once per kernel.
 // =====================================================================================================
@@ -479,12 +491,19 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 template <typename R, int N, int MODE, int NS = 16, bool PREF = false, bool SPLIT = false>
 // (8192-wide rows: a workgroup is 8 waves, two per SIMD -- a second resident workgroup needs four waves per SIMD,
 //  i.e. at most 128 VGPRs)
-__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? HGS_ROW_OCC_8192 : PREF ? 2 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
+// (the phase-extracting forms over all 16 register slots, MODE 1 / 3 with NS = 16 from 4096 columns on -- one launch per
+//  engine call -- are compiled for two waves per SIMD: at three / four they spilled 8 .. 48 VGPRs)
+__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 || MODE == 3) && NS == 16 && N >= 4096 && !SPLIT) || (MODE == 3 && N <= 128)) ? 2 :
+                                             (N >= 8192 ? HGS_ROW_OCC_8192 : PREF ? 2 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
     static_assert(NS == 16 || (RowCfg<N>::FPW == 1 && NS >= 4 && NS < 16), "row_kernel: shifted form is for one-row workgroups");
     static_assert(!PREF || (sizeof(R) == 4 && N == 4096 && MODE == 2), "row_kernel: the prefetching form is fp32, 4096 wide, MODE 2");
     static_assert(!SPLIT || (!PREF && MODE != 0 && RowCfg<N>::T >= 256), "row_kernel: the split form reads H, one-row workgroups");
     using M = Math<R>;
     constexpr int T = RowCfg<N>::T, FPW = RowCfg<N>::FPW;
+    // pixels whose atan2 (phase extraction, MODE 1 / 3) the scheduler may interleave: four of them in flight cost ~40
+    // registers, which the instances that keep 16 unshifted slots next to a forward transform (MODE 3), run at four waves
+    // per SIMD (8192-wide rows) or carry two lane groups (narrow rows) do not have -- they spilled 8 .. 48 VGPRs
+    constexpr int AT_GROUP = (MODE == 3 || N >= 8192 || T < 256) ? 1 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo g = a.g;
     const int tid = threadIdx.x;
@@ -508,7 +527,10 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
     }
 
     // (fp64: 64 data registers per lane already; the stage twiddles are fetched per use instead of kept)
-    using Sel = FftSel<R, N, (sizeof(R) == 8 ? false : HGS_ROW_TW_RESIDENT), PREF>;
+    // (fp32 instances that ran out of registers with them -- every phase-extracting launch, i.e. one per engine call, and the
+    //  unshifted 8192-wide form -- fetch them per use as well: 8 .. 48 spilled VGPRs -> 0, tools/resusage.sh)
+    constexpr bool TW_RES = sizeof(R) == 8 ? false : (MODE == 1 || MODE == 3 || (N >= 8192 && NS == 16)) ? false : HGS_ROW_TW_RESIDENT;
+    using Sel = FftSel<R, N, TW_RES, PREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
 
@@ -620,9 +642,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                 HGS_T(fft.tr_n, 2);
-                if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
+                if constexpr (MODE >= 2) fft.inv_after_fwd(v, lds, j);
                 else fft.inv(v, lds, j);
-                if constexpr (MODE == 1) {
+                if constexpr (MODE == 1 || MODE == 3) {
                     const R sc = sgs * a.scale;
                     if (a.nf_out != nullptr) {
                         const Buf bnf(a.nf_out + (size_t)b * g.Sh * g.Sw + srow, row_bytes * 2u);
@@ -636,7 +658,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                             const unsigned co = c_off + (unsigned)m * c_step;
                             R p = M::atan2(v[m].y * sc, v[m].x * sc) - bkn.template ld<R>(co, 0u);   // (no kernel: reads 0)
                             bph.template st<R>(p, co, 0u);
-                            if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (m % AT_GROUP == AT_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                         });
                     }
                 }
@@ -648,7 +670,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                     R amv = bam.template ld<R>(co, 0u);                      // (no amplitude array: empty resource)
                     if (am == nullptr) amv = (co < row_bytes) ? a.amp_scalar : (R)0;
                     Cx<R> nf;
-                    if constexpr (MODE == 2) {
+                    if constexpr (MODE >= 2) {
                         // evaluated eagerly and selected (a conditional around it is a branch per element)
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         const Cx<R> on = v[m] * (amv * rsqrt_full(p2));
@@ -752,14 +774,14 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
             HGS_T(fft.tr_n, 2);
             // (MODE 2: the previous user of the LDS image was the forward transform of the row before)
             if constexpr (NS < 16) {
-                if constexpr (MODE == 2) fft.template inv_after_fwd_trail<NS>(v, lds, j);
+                if constexpr (MODE >= 2) fft.template inv_after_fwd_trail<NS>(v, lds, j);
                 else fft.template inv_trail<NS>(v, lds, j);
             } else {
-                if constexpr (MODE == 2) fft.inv_after_fwd(v, lds, j);
+                if constexpr (MODE >= 2) fft.inv_after_fwd(v, lds, j);
                 else fft.inv(v, lds, j);
             }
             const R sc = sgs * a.scale;
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 1 || MODE == 3) {
                 static_for<0, NS>([&](auto m_) {
                     constexpr int m = m_;
                     const int c = c_lane + m * T;
@@ -773,7 +795,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                             ph[c] = p;
                         }
                     }
-                    if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (m % AT_GROUP == AT_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                 });
             }
         }
@@ -791,12 +813,12 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (N >= 8192 ? H
                 Cx<R> nf = mk<R>(0, 0);
                 if (valid && c >= 0 && c < g.Sw) {
                     const R amv = (am != nullptr) ? am[c] : a.amp_scalar;
-                    if constexpr (MODE == 2 && HGS_ROW_PHASOR) {
+                    if constexpr (MODE >= 2 && HGS_ROW_PHASOR) {
                         // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         const Cx<R> on = v[m] * (amv * rsqrt_full(p2));      // (eager + select: no inner branches)
                         nf = mk<R>((p2 > (R)0) ? on.x : amv * sgs, (p2 > (R)0) ? on.y : (R)0);
-                    } else if constexpr (MODE == 2) {
+                    } else if constexpr (MODE >= 2) {
                         // the reference's own arithmetic: phase rounded to working precision, then exp(i phase)
                         const R scs = sgs * a.scale;
                         R p = M::atan2(v[m].y * scs, v[m].x * scs);
@@ -1227,7 +1249,20 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         // fp64: this column's weights / targets land under its forward transform (8192: after it -- the 64 registers
         // would not fit next to the transform's own)
         if constexpr (LEAN && N < 8192) issue_wt(q);
+        // 8192 points: the 64 registers of this column's weights / targets do not fit next to the forward transform, so they
+        // are requested after it -- and every CU asks for its 128 KB at the same moment, with nothing to do meanwhile: 12.9 k
+        // of the 47.6 k cycles of a column pass in the s_memtime trace (profiles/r05).  One word of each of the lane's two
+        // 128-byte lines is requested BEFORE the transform instead (two registers, used by nothing): the lines travel to L2
+        // under the transform and the real loads afterwards are L2 hits.
+        int pf_w = 0, pf_t = 0;
+        if constexpr (LEAN && N >= 8192 && HGS_F64_WT_PREFETCH) {
+            if (vcol) {
+                pf_w = reinterpret_cast<const int*>(a.w + cb + lane_pos<T>(j, 0))[0];
+                if (do_upd || STATS || x_mraf) pf_t = reinterpret_cast<const int*>(a.t + cb + lane_pos<T>(j, 0))[0];
+            }
+        }
         fft.fwd(v, lds, j);
+        if constexpr (LEAN && N >= 8192 && HGS_F64_WT_PREFETCH) asm volatile("" :: "v"(pf_w), "v"(pf_t));
         HGS_T(fft.tr_n, 3);
         // fp64: the 16 transformed values of a lane (64 VGPRs) wait in the idle LDS image while the constraint runs --
         // lane-private slots [m * T + j], conflict-free, no barrier -- so that the rule (inlined double log2 / exp2,
@@ -1569,7 +1604,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
         const bool staged = tpref && it != (int)blockIdx.x;
         if constexpr (TPREF) {
-            if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own pieces (no other wave reads them)
+            // This wave's own pieces (no other wave reads them) were issued a whole tile ago; every column since has waited
+            // for weights / targets that were requested AFTER them, and loads return in order -- they have landed.  Rounds 3 - 4
+            // put a vmcnt(0) here, which also waited for the acknowledgement of the tile STORES issued a few instructions
+            // earlier: 4.2 k cycles per tile in the s_memtime trace (profiles/r05/trace8k_timeline.txt), 6 % of the launch.
+            if (HGS_TILE_STAGE_WAIT && staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
@@ -1597,6 +1636,23 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             if (tpref && more(next_ct())) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the image has been read into registers
                 stage_next(next_ct());
+            }
+        }
+        // SPLIT: the LDS the staging would use holds the parked noise part, and the 8.2 k cycles a tile's rows take to arrive
+        // are on the critical path of the CU's only workgroup (s_memtime trace, profiles/r05).  One word of each row piece
+        // of the workgroup's NEXT tile is requested now (NR registers, used by nothing): the lines reach L2 while this tile
+        // is transformed.
+        int pf_next[NR];
+        if constexpr (SPLIT && TPREF && NR <= 4 && HGS_SPLIT_L2_PREFETCH) {     // (six slots: no registers to spare)
+#pragma unroll
+            for (int m = 0; m < NR; ++m) pf_next[m] = 0;
+            if (more(next_ct())) {
+                const Cx<R>* ghn = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)next_ct() * g.Sh * 4;
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const int r = r_lane + m * T;
+                    if (r >= 0 && r < g.Sh) pf_next[m] = reinterpret_cast<const int*>(ghn + (unsigned)r * 4u)[0];
+                }
             }
         }
         int tile_noise = 0;          // SPLIT: any column of this tile with a noise pixel (wave-uniform)
@@ -1796,6 +1852,10 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     }
                 }
             }
+        }
+        if constexpr (SPLIT && TPREF && NR <= 4 && HGS_SPLIT_L2_PREFETCH) {     // (six slots: no registers to spare)
+#pragma unroll
+            for (int m = 0; m < NR; ++m) asm volatile("" :: "v"(pf_next[m]));
         }
         if (EXTRAS && !FIXED && cp.weights_only) continue;
         if constexpr (BTILE) {

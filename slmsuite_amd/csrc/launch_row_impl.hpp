@@ -50,6 +50,7 @@ static int launch_row_n(int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a)
                 case 0: return launch_row_one<R, N, 0, 8>(grid, s, a);
                 case 1: return launch_row_one<R, N, 1, 8>(grid, s, a);
                 case 2: return launch_row_one<R, N, 2, 8>(grid, s, a);
+                case 3: return launch_row_one<R, N, 3, 8>(grid, s, a);      // (fp32 only: the engine keeps MODE 1 in float64)
             }
         }
     }
@@ -58,6 +59,9 @@ static int launch_row_n(int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a)
         case 0: return launch_row_one<R, N, 0>(grid, s, a);
         case 1: return launch_row_one<R, N, 1>(grid, s, a);
         case 2: return launch_row_one<R, N, 2>(grid, s, a);
+#ifdef HGS_REAL_IS_FLOAT
+        case 3: return launch_row_one<R, N, 3>(grid, s, a);      // MODE 2 that also writes the phase (last launch of a call)
+#endif
     }
     return (int)hipErrorInvalidValue;
 }

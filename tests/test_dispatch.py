@@ -30,11 +30,13 @@ def test_record_names_template_arguments_and_clears():
     d = dispatch_of(h)
     recs = {r["name"]: r for r in d.records}
     assert any(n.startswith("col_fused_kernel<R=float,N=256,PHASE=0,STATS=false,RULE=2>") for n in recs), d
-    assert d.count("row_kernel", R="float", N=256, MODE=0) == 1 and d.count("row_kernel", MODE=2) == 2 and d.count("row_kernel", MODE=1) == 1, d
+    # (the last row launch of a float32 call is MODE 3: it writes the phase and leaves G of the next body behind)
+    assert d.count("row_kernel", R="float", N=256, MODE=0) == 1 and d.count("row_kernel", MODE=2) == 2 and d.count("row_kernel", MODE=3) == 1, d
     assert dispatch_of(h).records == []                         # reading clears
     _ = h.amp_ff                                                # the trailing transform (_populate_results): stepwise operators
     d = dispatch_of(h)
-    assert d.count("col_kernel", N=256, MODE=3) == 1 and d.count("row_kernel", MODE=0) == 1 and len(d.records) == 2, d
+    # ... which is why this transform starts with its column pass (G of every column is already there)
+    assert d.count("col_kernel", N=256, MODE=3) == 1 and d.count("row_kernel") == 0 and len(d.records) == 1, d
 
 
 @pytest.mark.parametrize("n, dtype, family, extra", [

@@ -152,49 +152,72 @@ def test_cfg2_kim_every_column_path_matches_reference(path):
     assert errs["phase_sub"] < 3e-4
 
 
+# engine error <= max(1e-5, CFG2_YARD_FACTOR x the ideal-fp32 distance) at every recorded point of every seed
+CFG2_YARD_FACTOR = 3.0
+
+
 def test_cfg2_error_growth_over_seeds():
     """
-    Eight seed phases: the spot amplitudes after 5, 10, 20, 30, 40 and 50 WGS-Leonardo bodies against the reference's
-    (tests/golden/cfg2_seeds.npz).  Free-phase WGS amplifies rounding differences exponentially, so beyond ~10 bodies
-    no fp32 implementation that is not bit-identical to NumPy lands within a flat 1e-5.  The yardstick is NOT the
-    engine's own behaviour: tests/golden/cfg2_ideal_fp32.json (tools/conditioning_cfg2.py --variants all64 --curve,
-    CPU only) holds, per seed and iteration, how far an IDEAL fp32 implementation -- the reference's op sequence with
-    every FFT / arctan2 / exp evaluated in float64 and rounded once to float32 -- ends up from the reference.  Asserted:
-      * 5 and 10 bodies, every seed: the north-star 1e-5;
-      * every recorded iteration: error <= max(1e-5, 3 x the ideal implementation's distance) -- measured 0.2 .. 2.3 x;
-        a 2x loss of accuracy in the engine's arithmetic breaks this on the well-conditioned seeds (10, 13, 14, 16),
-        and the teacher-forced single bodies (test_cfg2_single_bodies_at_full_size_match_reference) catch it outright.
-    The distance the reference itself moves when its seed changes by one fp32 ulp (also in cfg2_seeds.npz) is reported.
+    Sixteen seed phases (tests/golden/cfg2_seeds.npz, round 2; cfg2_seeds_b.npz, round 5): the spot amplitudes after 5, 10,
+    20, 30, 40 and 50 WGS-Leonardo bodies against the reference's.  Free-phase WGS amplifies rounding differences
+    exponentially, so beyond ~10 bodies no fp32 implementation that is not bit-identical to NumPy lands within a flat 1e-5.
+    The yardstick is NOT the engine's own behaviour: tests/golden/cfg2_ideal_fp32{,_b}.json (tools/conditioning_cfg2.py
+    --variants all64 --curve, CPU only) hold, per seed and iteration, how far an IDEAL fp32 implementation -- the reference's
+    op sequence with every FFT / arctan2 / exp evaluated in float64 and rounded once to float32 -- ends up from the reference.
+    Asserted:
+      * 5 and 10 bodies: the north-star 1e-5 on every seed whose ideal-fp32 run is within 6e-6 there (15 of the 16);
+      * every recorded iteration: error <= max(1e-5, CFG2_YARD_FACTOR x the ideal implementation's distance);
+      * over all seeds and iterations the GEOMETRIC MEAN of engine error / ideal distance is <= 1.3 (round 4 measured a
+        worst ratio of 2.33 and could not say whether that was scatter or a worse operator: over the 48 points of the
+        first eight seeds the geometric mean is 1.06 with a log-scatter of 0.63, per-seed means 0.4 .. 1.8 -- the engine is
+        as far from the reference as an ideal fp32 implementation is; a 2x loss of accuracy anywhere doubles the mean);
+      * the same for the mean over seeds of the per-seed geometric means (the six points of one run are correlated).
+    The distance the reference itself moves when its seed changes by one fp32 ulp (also in the fixtures) is reported.
     """
     import json
     import os
     from conftest import GOLDEN
-    meta, gold = load_golden("cfg2_seeds")
-    ideal = json.load(open(os.path.join(GOLDEN, "cfg2_ideal_fp32.json")))["per_seed_curve"]
-    its = list(meta["curve_iters"]) + [meta["maxiter"]]
     worst_ratio = {"default": 0.0, "dense": 0.0}
-    for i, seed in enumerate(meta["seeds"]):
-        ref = np.concatenate((gold["curve_ampff"][i], gold["spot_ampff"][i][None]))
-        refp = np.concatenate((gold["curve_ampff_perturbed"][i], gold["spot_ampff_perturbed"][i][None]))
-        drift = np.array([rel_l2(refp[k], ref[k]) for k in range(len(its))])
-        yard = np.array([ideal[str(seed)]["all64"][str(k)] for k in its])
-        for path in ("default", "dense"):
-            h = cfg2_hologram(seed, path)
-            ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
-            err, done = [], 0
-            for k in its:
-                h.optimize("WGS-Leonardo", maxiter=k - done, verbose=False)
-                done = k
-                err.append(rel_l2(h.amp_ff[ky, kx], ref[len(err)]))
-            h._release_engine()
-            err = np.array(err)
-            report(f"cfg2 seed {seed} [{path}] engine error at bodies {its}", **{f"it{k}": e for k, e in zip(its, err)})
-            report(f"cfg2 seed {seed} ideal fp32 implementation at bodies {its}", **{f"it{k}": e for k, e in zip(its, yard)})
-            report(f"cfg2 seed {seed} reference 1-ulp drift at bodies {its}", **{f"it{k}": e for k, e in zip(its, drift)})
-            assert np.all(err[:2] < 1e-5), (seed, path, err)                 # 5 and 10 bodies: north-star tolerance
-            worst_ratio[path] = max(worst_ratio[path], float((err / yard).max()))
-            assert np.all(err < np.maximum(1e-5, 3 * yard)), (seed, path, err, yard)
+    logs = {"default": {}, "dense": {}}
+    for fixture, yardfile in (("cfg2_seeds", "cfg2_ideal_fp32.json"), ("cfg2_seeds_b", "cfg2_ideal_fp32_b.json")):
+        meta, gold = load_golden(fixture)
+        ideal = json.load(open(os.path.join(GOLDEN, yardfile)))["per_seed_curve"]
+        its = list(meta["curve_iters"]) + [meta["maxiter"]]
+        for i, seed in enumerate(meta["seeds"]):
+            ref = np.concatenate((gold["curve_ampff"][i], gold["spot_ampff"][i][None]))
+            refp = np.concatenate((gold["curve_ampff_perturbed"][i], gold["spot_ampff_perturbed"][i][None]))
+            drift = np.array([rel_l2(refp[k], ref[k]) for k in range(len(its))])
+            yard = np.array([ideal[str(seed)]["all64"][str(k)] for k in its])
+            for path in ("default", "dense"):
+                h = cfg2_hologram(seed, path)
+                ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+                err, done = [], 0
+                for k in its:
+                    h.optimize("WGS-Leonardo", maxiter=k - done, verbose=False)
+                    done = k
+                    err.append(rel_l2(h.amp_ff[ky, kx], ref[len(err)]))
+                h._release_engine()
+                err = np.array(err)
+                report(f"cfg2 seed {seed} [{path}] engine error at bodies {its}", **{f"it{k}": e for k, e in zip(its, err)})
+                report(f"cfg2 seed {seed} ideal fp32 implementation at bodies {its}", **{f"it{k}": e for k, e in zip(its, yard)})
+                report(f"cfg2 seed {seed} reference 1-ulp drift at bodies {its}", **{f"it{k}": e for k, e in zip(its, drift)})
+                # 5 and 10 bodies: the flat north-star tolerance, on the seeds whose ideal-fp32 run is itself within it there
+                # (seed 19 of the second set is 1.2e-5 / 1.8e-5 away after 5 / 10 bodies in exact arithmetic rounded once)
+                if np.all(yard[:2] < 6e-6):
+                    assert np.all(err[:2] < 1e-5), (seed, path, err)
+                worst_ratio[path] = max(worst_ratio[path], float((err / yard).max()))
+                logs[path][seed] = np.log(err / yard)
+                assert np.all(err < np.maximum(1e-5, CFG2_YARD_FACTOR * yard)), (seed, path, err, yard)
     report("cfg2 seed sweep: worst engine error / ideal-fp32 distance", **worst_ratio)
+    for path, per_seed in logs.items():
+        allp = np.concatenate(list(per_seed.values()))
+        gm_all = float(np.exp(allp.mean()))
+        gm_seeds = float(np.exp(np.mean([v.mean() for v in per_seed.values()])))
+        report(f"cfg2 seed sweep [{path}]: engine error / ideal-fp32 distance over {len(per_seed)} seeds x 6 bodies",
+               geometric_mean=gm_all, mean_of_per_seed_geometric_means=gm_seeds, log_scatter=float(allp.std()),
+               per_seed_min=float(np.exp(min(v.mean() for v in per_seed.values()))),
+               per_seed_max=float(np.exp(max(v.mean() for v in per_seed.values()))))
+        assert gm_all <= 1.3 and gm_seeds <= 1.3, (path, gm_all, gm_seeds)
 
 
 # ---- cfg 3: eight holograms per engine at 4096^2 ------------------------------------------------------------

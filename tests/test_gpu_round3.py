@@ -280,7 +280,7 @@ def test_prefetching_row_kernel_is_bit_identical(slm_shape, monkeypatch):
             assert d.count("row_kernel", MODE=2, NS=ns, PREF=True) == 4 and d.count("row_kernel", MODE=2, PREF=False) == 0, d
         else:
             assert d.count("row_kernel", MODE=2, NS=ns, PREF=False) == 4 and d.count("row_kernel", PREF=True) == 0, d
-        assert d.count("row_kernel", MODE=0, NS=ns) == 1 and d.count("row_kernel", MODE=1, NS=ns) == 1, d
+        assert d.count("row_kernel", MODE=0, NS=ns) == 1 and d.count("row_kernel", MODE=3, NS=ns) == 1, d
         out[pref] = (h.phase.copy(), h.weights[host.spot_knm_rounded[1], host.spot_knm_rounded[0]].copy())
         h._release_engine()
     np.testing.assert_array_equal(out["1"][0], out["0"][0])
