@@ -113,7 +113,9 @@ enum {
     HGS_YGRID = 14,       /* [slm_h][slm_w] real   slm.grid[1] * zernike scaling                     */
     HGS_MONOMIALS = 15,   /* int32 [n_monomials][2] (px, py)   phase._zernike_get_cantor terms; the pseudo-term
                              (-1, 0) is the vortex plate w * atan2(y, x), w > 0 only (phase.py:1783-1790)     */
-    HGS_SPOT_COEFF = 16   /* real [n_monomials][n_spots]       ... and weights (phase.py:850-920)    */
+    HGS_SPOT_COEFF = 16,  /* real [n_monomials][n_spots]       ... and weights (phase.py:850-920)    */
+    HGS_PHASE_PREV = 17   /* get only: [batch][slm_h][slm_w] real -- the phase the last one-iteration hgs_iterate call
+                             STARTED from (HGS_OPT_KEEP_PREV_PHASE); HGS_ERR_STATE when none is held */
 };
 
 int hgs_create(const hgs_config* cfg, hgs_engine** out);
@@ -208,12 +210,19 @@ int hgs_sync(hgs_engine* e);
  *   a two-term recurrence instead of evaluating the polynomial, sin and cos per pixel; 0 forces the per-pixel kernels.
  * Options are per engine and take effect at the next call; nothing is read from the environment after
  * hgs_create (which reads the developer overrides once: the grid sizes HGS_ROW_BLOCKS / HGS_COL_BLOCKS / HGS_TILE_BLOCKS /
- * HGS_ROW_PREF_BLOCKS, and the A/B switches HGS_ROW_XCD, HGS_COL_XMAP, HGS_ROW_SHIFT, HGS_ROW_PREF, HGS_TILE_RULE, HGS_MRAF_SPLIT, HGS_TILE_LIST -- all default to the
+ * HGS_ROW_PREF_BLOCKS, and the A/B switches HGS_ROW_XCD, HGS_COL_XMAP, HGS_ROW_SHIFT, HGS_ROW_PREF, HGS_TILE_RULE, HGS_MRAF_SPLIT, HGS_TILE_LIST,
+ * HGS_TILE_SHIFT16, HGS_TILE_NR4, HGS_KEEP_G -- all default to the
  * tuned path).
  * HGS_OPT_ROCTX (default 0): roctx ranges (hgs_iterate, hgs_nearfield2farfield, hgs_farfield_constraint,
- *   hgs_farfield2nearfield) for rocprofv3 --marker-trace; the roctx library is dlopen'ed on first use. */
+ *   hgs_farfield2nearfield) for rocprofv3 --marker-trace; the roctx library is dlopen'ed on first use.
+ * HGS_OPT_KEEP_PREV_PHASE (default 0): a fused hgs_iterate / hgs_iterate_stats call of ONE iteration that rewrites the
+ *   farfield phase (i.e. does not use a fixed one) first copies HGS_PHASE to HGS_PHASE_PREV on the device.  The fused
+ *   kernels never materialise Hologram.phase_ff (= atan2 of the farfield the iteration STARTED from, _hologram.py:1583 /
+ *   :1602); a caller that runs the loop one iteration per call -- Hologram.optimize(callback=...) -- can rebuild it on
+ *   demand from that phase (hgs_nearfield2farfield(store_phase_ff = 1) on a second engine).  Calls that iterate the
+ *   general operators keep HGS_PHASE_FF itself up to date and hold no previous phase. */
 enum { HGS_OPT_SPARSE_COLUMNS = 1, HGS_OPT_FORCE_STEPWISE = 2, HGS_OPT_TILE_KERNEL = 3, HGS_OPT_SEPARABLE = 4,
-       HGS_OPT_SEPARABLE_MIN_SPOTS = 5, HGS_OPT_ROCTX = 6, HGS_OPT_RUN_KERNELS = 7 };
+       HGS_OPT_SEPARABLE_MIN_SPOTS = 5, HGS_OPT_ROCTX = 6, HGS_OPT_RUN_KERNELS = 7, HGS_OPT_KEEP_PREV_PHASE = 8 };
 int hgs_set_option(hgs_engine* e, int option, int value);
 
 /* Timing support for bench.py: per-kernel HIP-event timing on the engine stream. */

@@ -15,10 +15,12 @@ HGS_OK, HGS_ERR_ARG, HGS_ERR_DEVICE, HGS_ERR_STATE, HGS_ERR_UNSUPPORTED = 0, -1,
 # hgs_set_option
 OPT_SPARSE_COLUMNS, OPT_FORCE_STEPWISE, OPT_TILE_KERNEL, OPT_SEPARABLE, OPT_SEPARABLE_MIN_SPOTS, OPT_ROCTX = 1, 2, 3, 4, 5, 6
 OPT_RUN_KERNELS = 7
+OPT_KEEP_PREV_PHASE = 8
 
 # array selectors (include/hgs.h)
 (PHASE, AMP, AMP_SCALAR, PROP_KERNEL, TARGET, WEIGHTS, PHASE_FF, FARFIELD, AMP_FF, SPOT_INDEX,
  SPOT_AMP, EXTERNAL_AMP, ZERO_WEIGHTS, XGRID, YGRID, MONOMIALS, SPOT_COEFF) = range(17)
+PHASE_PREV = 17
 FB_PIXEL, FB_SPOT_WINDOW, FB_EXTERNAL = 0, 1, 2
 K_NAMES = ("row", "col_fused", "col_fwd", "col_inv", "elementwise")
 

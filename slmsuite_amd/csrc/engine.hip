@@ -226,6 +226,10 @@ template <typename R> struct Engine : EngineBase {
     // while nothing that G depends on (phase, amplitude, kernel, the set of stored columns) has changed.
     //   gh_state: -1 = gh does not hold G; 0 = G of every column; 1 = of the active columns; 2 = of the dilated active columns
     int gh_state = -1;
+    // HGS_OPT_KEEP_PREV_PHASE: the phase a one-iteration fused call started from (what its farfield phase describes)
+    R* phase_prev = nullptr;
+    bool have_prev = false;
+    int opt_prev_phase = 0;
     int opt_keep_g = 1;                    // developer A/B (HGS_KEEP_G=0 at create)
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
     int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
@@ -313,7 +317,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
-        void* ptrs[] = {ffb, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
+        void* ptrs[] = {phase_prev, ffb, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -1334,6 +1338,13 @@ template <typename R> struct Engine : EngineBase {
                 HIPCHK(hipStreamSynchronize(stream));
                 return 0;
             }
+            case HGS_PHASE_PREV: {
+                if (!phase_prev || !have_prev) return fail(HGS_ERR_STATE, "no previous phase is held (HGS_OPT_KEEP_PREV_PHASE, one-iteration fused calls)");
+                if (nbytes != S * sizeof(R) * B) return fail(HGS_ERR_ARG, "previous phase: bad size %zu", nbytes);
+                HIPCHK(hipMemcpyAsync(dst, phase_prev, nbytes, dst_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                return 0;
+            }
             case HGS_TARGET: return download_T<R>(t, dst, nbytes, dst_device, nullptr);
             case HGS_WEIGHTS: return download_T<R>(w, dst, nbytes, dst_device, w_pending ? wscale : nullptr);
             case HGS_PHASE_FF:
@@ -1361,6 +1372,7 @@ template <typename R> struct Engine : EngineBase {
     // Hologram.reset (:442-478): weights from the target, phase_ff / farfield / amp_ff back to "None"
     int reset_state() override {
         have_pff = false;
+        have_prev = false;
         farfield_valid = false;
         return reset_weights();
     }
@@ -1438,6 +1450,16 @@ template <typename R> struct Engine : EngineBase {
         int r_ = run_row_impl(mode, finalize, load_sparse, store_sparse);
         if (r_ == 0 && mode != 1) gh_state = store_sparse;      // gh holds G of the columns this launch stored
         return r_;
+    }
+    // (fused loops only; p = the plan of the call's first iteration)
+    template <typename PlanT> int keep_prev_phase(const PlanT& p, int n) {
+        if (!opt_prev_phase) return 0;
+        if (n != 1) { have_prev = false; return 0; }      // the phases in between are never materialised
+        if (p.use_fixed) return 0;                          // phase_ff is not rewritten: what is held stays what describes it
+        if (!phase_prev) { if (dalloc(&phase_prev, (size_t)B * S)) return HGS_ERR_DEVICE; }
+        HIPCHK(hipMemcpyAsync(phase_prev, phase, (size_t)B * S * sizeof(R), hipMemcpyDeviceToDevice, stream));
+        have_prev = true;
+        return 0;
     }
     bool gh_holds(int need) const { return opt_keep_g && (gh_state == need || gh_state == 0 || (gh_state == 2 && need == 1 && dil_valid)); }
     int run_row_impl(int mode, bool finalize, int load_sparse, int store_sparse) {
@@ -1889,6 +1911,7 @@ template <typename R> struct Engine : EngineBase {
         };
         farfield_valid = false;
         Plan p = plan_iteration(st, hist ? hist : nullptr);
+        if (int e = keep_prev_phase(p, n)) return e;
         if (!gh_holds(windows_needed(p) ? 2 : 1)) { if (int e = run_row(0, false, 0, windows_needed(p) ? 2 : 1)) return e; }
         // what the last launch of the call stores for the next one (MODE 3): the dilated columns whenever a window may be
         // read (they include the active ones)
@@ -1972,6 +1995,7 @@ template <typename R> struct Engine : EngineBase {
         const bool fused = fused_ok(st) && !opt_stepwise;
         if (!fused && spot_sparse_ok(st)) return iterate_spot_sparse(st, n, hist);
         if (!fused) {
+            have_prev = false;           // the general operators keep HGS_PHASE_FF itself up to date
             for (int i = 0; i < n; ++i) {
                 if (int e = n2f(0)) return e;
                 Plan p = plan_iteration(st, hist ? hist + i : nullptr);
@@ -2008,6 +2032,7 @@ template <typename R> struct Engine : EngineBase {
         const int store_sparse = spot_stats ? 2 : 1;
         Plan p = plan_iteration(st, hist ? hist : nullptr);
         const bool sp = sparse_enabled;
+        if (int e = keep_prev_phase(p, n)) return e;
         // (the previous call may have left G of these columns behind: gh_state, row_kernel MODE 3)
         if (!gh_holds(sp ? store_sparse : 0)) { if (int e = run_row(0, false, 0, sp ? store_sparse : 0)) return e; }
         for (int i = 0; i < n; ++i) {
@@ -2231,6 +2256,7 @@ template <typename R> struct Engine : EngineBase {
         for (size_t k = 0; k < (size_t)n * 2 * B * 4; ++k) out[k] = NAN;
         const bool fused = (fused_ok(st) || spot_sparse_ok(st)) && !opt_stepwise;
         if (!fused) {
+            have_prev = false;
             // general path: materialise, reduce, constrain -- one host read of a few doubles per iteration
             for (int i = 0; i < n; ++i) {
                 if (int e = n2f(0)) return e;
@@ -2422,6 +2448,7 @@ template <typename R> struct Engine : EngineBase {
             case HGS_OPT_SEPARABLE: opt_separable = value ? 1 : 0; return 0;
             case HGS_OPT_SEPARABLE_MIN_SPOTS: opt_sep_min = value > 0 ? value : 1; return 0;
             case HGS_OPT_RUN_KERNELS: opt_run = value ? 1 : 0; return 0;
+            case HGS_OPT_KEEP_PREV_PHASE: opt_prev_phase = value ? 1 : 0; if (!value) have_prev = false; return 0;
             case HGS_OPT_ROCTX:
                 if (value && !g_roctx.load()) return fail(HGS_ERR_UNSUPPORTED, "no roctx library (librocprofiler-sdk-roctx / libroctx64) found");
                 opt_roctx = value ? 1 : 0;

@@ -50,14 +50,17 @@
 #endif
 // Ablation hooks for tools/microbench/ablate.hip (all 0 in the product build): compile the weight/target
 // loads (WT) or the GH tile loads and stores (GH) out of col_tile_kernel to see what they cost.
+// Round-5 experiments on the 8192-row column kernels, all measured and NOT adopted (NOTEBOOK.md; A/B builds through
+// tools/microbench/build_trace8k.sh): the s_memtime trace of a build that drains vmcnt at every phase boundary suggested
+// memory waits that the product build does not have.
 #ifndef HGS_TILE_STAGE_WAIT
-#define HGS_TILE_STAGE_WAIT 0   // 1: rounds 3 - 4, a vmcnt(0) ahead of reading the staged tile (it waited for the previous tile's STORES)
+#define HGS_TILE_STAGE_WAIT 1   // 0: no vmcnt(0) ahead of reading the staged tile (the loads have landed by then): 213.9 vs 214.5 us, noise
 #endif
 #ifndef HGS_F64_WT_PREFETCH
-#define HGS_F64_WT_PREFETCH 1   // float64 8192-point fused kernel: the column's weight / target lines on their way into L2 under its forward transform
-#endif
+#define HGS_F64_WT_PREFETCH 0   // 1: float64 8192-point fused kernel, one word of each weight / target line requested ahead of the forward
+#endif                          //    transform (L2 prefetch): 737 vs 713 us -- slower
 #ifndef HGS_SPLIT_L2_PREFETCH
-#define HGS_SPLIT_L2_PREFETCH 1 // single-pass MRAF tile kernel (no LDS left for the staging): the next tile's rows into L2 under the first transform
+#define HGS_SPLIT_L2_PREFETCH 0 // 1: single-pass MRAF tile kernel, the next tile's rows requested ahead of the first transform: 332.6 vs 330.4 us
 #endif
 #ifndef HGS_ABL_WT
 #define HGS_ABL_WT 0
@@ -430,9 +433,9 @@ __device__ __forceinline__ double rsqrt_full(double x) { return 1.0 / ::sqrt(x);
 //   MODE 1 : H -> phase            (row half of ifft2 :1070 + _nearfield_extract :1026)
 //   MODE 2 : H -> phase -> G       (MODE 1 then MODE 0 of the next iteration, fused: the row never
 //                                   leaves the CU between the two iterations)
-//   MODE 3 : MODE 2 that also writes the phase: the LAST launch of an hgs_iterate call leaves G behind, so
-//            that the next call on an unchanged phase starts with its column launch (round 5; the G it
-//            leaves is MODE 2's, i.e. a loop cut into several calls runs the same arithmetic as one call)
+//   MODE 3 : H -> phase -> G with the phase WRITTEN and G built from the written value (MODE 1 and MODE 0
+//            in one launch, bit for bit): the LAST launch of an hgs_iterate call leaves G behind, so that
+//            the next call on an unchanged phase starts with its column launch (round 5)
 // grid = (<= ceil(Sh / FPW), batch), block = WG;  FPW = WG / T rows per workgroup pass; a workgroup
 // strides over rows so the per-lane twiddle registers are fetched once per kernel.
 // =====================================================================================================
@@ -491,9 +494,9 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 template <typename R, int N, int MODE, int NS = 16, bool PREF = false, bool SPLIT = false>
 // (8192-wide rows: a workgroup is 8 waves, two per SIMD -- a second resident workgroup needs four waves per SIMD,
 //  i.e. at most 128 VGPRs)
-// (the phase-extracting forms over all 16 register slots, MODE 1 / 3 with NS = 16 from 4096 columns on -- one launch per
-//  engine call -- are compiled for two waves per SIMD: at three / four they spilled 8 .. 48 VGPRs)
-__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 || MODE == 3) && NS == 16 && N >= 4096 && !SPLIT) || (MODE == 3 && N <= 128)) ? 2 :
+// (the phase-extracting forms over all 16 register slots, MODE 1 / 3 with NS = 16 from 4096 columns on, and MODE 3 below
+//  that -- one launch per engine call -- are compiled for two waves per SIMD: at three / four they spilled 4 .. 48 VGPRs)
+__global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 || MODE == 3) && NS == 16 && N >= 4096 && !SPLIT) || (MODE == 3 && N < 4096)) ? 2 :
                                              (N >= 8192 ? HGS_ROW_OCC_8192 : PREF ? 2 : HGS_ROW_OCC))) void row_kernel(RowArgs<R> a) {
     static_assert(NS == 16 || (RowCfg<N>::FPW == 1 && NS >= 4 && NS < 16), "row_kernel: shifted form is for one-row workgroups");
     static_assert(!PREF || (sizeof(R) == 4 && N == 4096 && MODE == 2), "row_kernel: the prefetching form is fp32, 4096 wide, MODE 2");
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 HGS_T(fft.tr_n, 2);
                 if constexpr (MODE >= 2) fft.inv_after_fwd(v, lds, j);
                 else fft.inv(v, lds, j);
-                if constexpr (MODE == 1 || MODE == 3) {
+                if constexpr (MODE == 1) {
                     const R sc = sgs * a.scale;
                     if (a.nf_out != nullptr) {
                         const Buf bnf(a.nf_out + (size_t)b * g.Sh * g.Sw + srow, row_bytes * 2u);
@@ -670,7 +673,17 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                     R amv = bam.template ld<R>(co, 0u);                      // (no amplitude array: empty resource)
                     if (am == nullptr) amv = (co < row_bytes) ? a.amp_scalar : (R)0;
                     Cx<R> nf;
-                    if constexpr (MODE >= 2) {
+                    if constexpr (MODE == 3) {
+                        // MODE 1 and MODE 0 in one: the phase as MODE 1 stores it, the nearfield from that stored value
+                        const R sc1 = sgs * a.scale;
+                        const R kv = bkn.template ld<R>(co, 0u);                        // (no kernel: reads 0)
+                        R p = M::atan2(v[m].y * sc1, v[m].x * sc1) - kv;
+                        bph.template st<R>(p, co, 0u);
+                        p = p + kv;
+                        R sn, cs;
+                        M::sincos(p, &sn, &cs);
+                        nf = mk<R>(amv * sgs * cs, amv * sgs * sn);
+                    } else if constexpr (MODE == 2) {
                         // evaluated eagerly and selected (a conditional around it is a branch per element)
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         const Cx<R> on = v[m] * (amv * rsqrt_full(p2));
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 else fft.inv(v, lds, j);
             }
             const R sc = sgs * a.scale;
-            if constexpr (MODE == 1 || MODE == 3) {
+            if constexpr (MODE == 1) {
                 static_for<0, NS>([&](auto m_) {
                     constexpr int m = m_;
                     const int c = c_lane + m * T;
@@ -813,12 +826,25 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 Cx<R> nf = mk<R>(0, 0);
                 if (valid && c >= 0 && c < g.Sw) {
                     const R amv = (am != nullptr) ? am[c] : a.amp_scalar;
-                    if constexpr (MODE >= 2 && HGS_ROW_PHASOR) {
+                    if constexpr (MODE == 3) {
+                        // MODE 1 and MODE 0 in one: the phase exactly as MODE 1 stores it, and the nearfield from that STORED
+                        // value exactly as MODE 0 rebuilds it -- a call that finds G left behind continues bit for bit like
+                        // one that has to rebuild it from the phase (they meet on different paths: a column list leaves G of
+                        // its columns only, and the transform that ends optimize() rebuilds every column)
+                        const R scs = sgs * a.scale;
+                        R p = M::atan2(v[m].y * scs, v[m].x * scs);
+                        if (kn != nullptr) p -= kn[c];
+                        ph[c] = p;
+                        if (kn != nullptr) p += kn[c];
+                        R s, co;
+                        M::sincos(p, &s, &co);
+                        nf = mk<R>(amv * sgs * co, amv * sgs * s);
+                    } else if constexpr (MODE == 2 && HGS_ROW_PHASOR) {
                         // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         const Cx<R> on = v[m] * (amv * rsqrt_full(p2));      // (eager + select: no inner branches)
                         nf = mk<R>((p2 > (R)0) ? on.x : amv * sgs, (p2 > (R)0) ? on.y : (R)0);
-                    } else if constexpr (MODE >= 2) {
+                    } else if constexpr (MODE == 2) {
                         // the reference's own arithmetic: phase rounded to working precision, then exp(i phase)
                         const R scs = sgs * a.scale;
                         R p = M::atan2(v[m].y * scs, v[m].x * scs);
@@ -1200,6 +1226,9 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         if (col_valid(q)) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = wc[lane_pos<T>(j, m)]; });
             if (need_t) static_for<0, 16>([&](auto m_) { constexpr int m = m_; tr[m] = tc[lane_pos<T>(j, m)]; });
+            // (defined on every path: left unset here, the RULE 2 instances kept one of them in scratch -- 12 bytes, a
+            //  scratch round trip per column)
+            else static_for<0, 16>([&](auto m_) { constexpr int m = m_; tr[m] = (R)0; });
         } else {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = (R)0; tr[m] = (R)0; });
         }
@@ -1250,10 +1279,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         // would not fit next to the transform's own)
         if constexpr (LEAN && N < 8192) issue_wt(q);
         // 8192 points: the 64 registers of this column's weights / targets do not fit next to the forward transform, so they
-        // are requested after it -- and every CU asks for its 128 KB at the same moment, with nothing to do meanwhile: 12.9 k
-        // of the 47.6 k cycles of a column pass in the s_memtime trace (profiles/r05).  One word of each of the lane's two
-        // 128-byte lines is requested BEFORE the transform instead (two registers, used by nothing): the lines travel to L2
-        // under the transform and the real loads afterwards are L2 hits.
+        // are requested after it.  (Experiment, off: one word of each of the lane's two 128-byte lines requested BEFORE the
+        // transform, so that the real loads are L2 hits -- the launch got 3 % slower, HGS_F64_WT_PREFETCH.)
         int pf_w = 0, pf_t = 0;
         if constexpr (LEAN && N >= 8192 && HGS_F64_WT_PREFETCH) {
             if (vcol) {
@@ -1604,10 +1631,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
         const bool staged = tpref && it != (int)blockIdx.x;
         if constexpr (TPREF) {
-            // This wave's own pieces (no other wave reads them) were issued a whole tile ago; every column since has waited
-            // for weights / targets that were requested AFTER them, and loads return in order -- they have landed.  Rounds 3 - 4
-            // put a vmcnt(0) here, which also waited for the acknowledgement of the tile STORES issued a few instructions
-            // earlier: 4.2 k cycles per tile in the s_memtime trace (profiles/r05/trace8k_timeline.txt), 6 % of the launch.
+            // this wave's own pieces (no other wave reads them).  (They were issued a whole tile ago and every column since has
+            // waited for weights / targets requested after them, so the wait is formally redundant -- and it also waits for
+            // the tile stores issued just before; without it the launch measured the same, HGS_TILE_STAGE_WAIT.)
             if (HGS_TILE_STAGE_WAIT && staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #pragma unroll
@@ -1638,10 +1664,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 stage_next(next_ct());
             }
         }
-        // SPLIT: the LDS the staging would use holds the parked noise part, and the 8.2 k cycles a tile's rows take to arrive
-        // are on the critical path of the CU's only workgroup (s_memtime trace, profiles/r05).  One word of each row piece
-        // of the workgroup's NEXT tile is requested now (NR registers, used by nothing): the lines reach L2 while this tile
-        // is transformed.
+        // SPLIT: the LDS the staging would use holds the parked noise part.  (Experiment, off: one word of each row piece of
+        // the workgroup's NEXT tile requested now, so that its rows are L2 hits -- no gain, HGS_SPLIT_L2_PREFETCH.)
         int pf_next[NR];
         if constexpr (SPLIT && TPREF && NR <= 4 && HGS_SPLIT_L2_PREFETCH) {     // (six slots: no registers to spare)
 #pragma unroll

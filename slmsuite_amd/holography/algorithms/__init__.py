@@ -9,6 +9,8 @@ weight update, inverse FFT, phase extraction, statistics reductions -- runs on t
 keeps the host-side bookkeeping (flag parsing, WGS-Kim history, stats lists).  There is no CPU
 fallback: without the built library or a gfx950 device ``optimize()`` raises.
 """
+import os
+import sys
 import time
 import warnings
 
@@ -61,6 +63,20 @@ def _norm(matrix):
 def _is_device_tensor(value):
     """A torch tensor that lives on a GPU (the engine takes those device to device)."""
     return type(value).__module__.split(".")[0] == "torch" and bool(getattr(value, "is_cuda", False))
+
+
+def _fingerprint(arr):
+    """
+    (identity, cheap content sample) of a host array a side engine holds a device copy of: the copy is re-sent when either
+    changes.  The sample is every 64th row plus the corner values -- it notices the in-place edits that keep the object
+    (``kernel += defocus``, ``amp *= mask``, ``kernel[:] = ...``) without a pass over the whole array per camera frame; an
+    edit confined to other rows needs :meth:`Hologram.refresh_farfield_inputs`.
+    """
+    if arr is None or np.isscalar(arr):
+        return (None, arr)
+    a = np.asarray(arr)
+    sample = a[::64] if a.ndim == 2 else a
+    return (id(arr), a.shape, float(np.sum(sample, dtype=np.float64)), float(a.flat[0]), float(a.flat[-1]))
 
 
 def _history_put(seq, start, values, fill=np.nan):
@@ -157,7 +173,10 @@ class Hologram:
     # ---- device-backed attributes -----------------------------------------------------------------
     def _get_dev(self, name):
         if name in ("farfield", "amp_ff", "phase_ff"):
-            self._flush_populate()
+            if self.__dict__.get("_midloop") is not None:
+                self._midloop_materialise(name)          # inside a callback of the device-resident loop
+            else:
+                self._flush_populate()
         if name in self._stale and self._engine is not None:
             arr = self._engine.get(_DEVICE_ARRAYS[name])[0]
             self._host[name] = arr
@@ -426,24 +445,14 @@ class Hologram:
         * the phase goes engine -> engine on the device when this hologram's engine holds it (``hgs_copy_phase``);
         * source amplitude and kernel are re-sent only when they are other objects than last time; no kernel = none sent;
         * ``get=False`` returns the field as a torch tensor on the GPU (the reference: a CuPy array), ``get=True`` a NumPy
-          array.  The affine step is the reference's host call (``scipy.ndimage.affine_transform``, order 3, constant 0).
+          array -- also for ``get=False`` in a process that has not imported torch.  The affine step is the reference's host call (``scipy.ndimage.affine_transform``, order 3, constant 0).
         """
         self._flush_populate()
         shape = self.shape if shape is None else self.slm_shape if len(shape) == 1 else shape
         shape = (int(shape[0]), int(shape[1]))
         for fallback in (self.propagation_kernel, 0):
             propagation_kernel = fallback if propagation_kernel is None else propagation_kernel
-        engines = self.__dict__.setdefault("_ff_engines", {})
-        slot = engines.get(shape)
-        if slot is None:
-            slot = engines[shape] = {"engine": Engine(shape, self.slm_shape, self.dtype, batch=1), "amp": None, "kernel": None}
-        e = slot["engine"]
-        if slot["amp"] is None or slot["amp"] is not self.amp:
-            if np.isscalar(self.amp):
-                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
-            else:
-                e.set(L.AMP, self.amp)
-            slot["amp"] = self.amp
+        e, slot = self._side_engine(shape, with_kernel=False)
         if np.isscalar(propagation_kernel):
             if propagation_kernel == 0:
                 if slot["kernel"] is not False:
@@ -452,12 +461,12 @@ class Hologram:
             else:
                 e.set(L.PROP_KERNEL, np.full(self.slm_shape, propagation_kernel, dtype=self.dtype))
                 slot["kernel"] = None
-        elif slot["kernel"] is not propagation_kernel:
+        elif slot["kernel"] != _fingerprint(propagation_kernel):
             kern = np.ascontiguousarray(propagation_kernel, dtype=self.dtype)
             if kern.shape != tuple(self.slm_shape):
                 raise ValueError(f"propagation_kernel must have the SLM shape {tuple(self.slm_shape)}")
             e.set(L.PROP_KERNEL, kern)
-            slot["kernel"] = propagation_kernel
+            slot["kernel"] = _fingerprint(propagation_kernel)
         if self._engine is not None:
             e.copy_phase_from(self._get_engine())            # (pending host edits of the phase go up first)
         elif _is_device_tensor(self._host.get("phase")):
@@ -469,17 +478,59 @@ class Hologram:
         if refresh:
             self.amp_ff = e.get(L.AMP_FF)[0]
             self.phase_ff = e.get(L.PHASE_FF)[0]
-        if not get and affine is None:
+        # get=False: the field stays on the GPU as a torch tensor where the process works with torch (the reference returns a
+        # CuPy array when CuPy is its backend) and is the NumPy array otherwise, as in the reference without CuPy -- a
+        # NumPy-only process must not import torch here: its HIP runtime would come up after libhgs.so's (_lib docstring)
+        on_gpu = not get and "torch" in sys.modules
+        if on_gpu and affine is None:
             return e.get_tensor(L.FARFIELD)[0]
         ff = e.get(L.FARFIELD)[0]
         if affine is not None:
             from scipy.ndimage import affine_transform
             ff = affine_transform(input=ff, matrix=affine["M"], offset=affine["b"], output_shape=shape, order=3,
                                   mode="constant", cval=0)
-        if not get:
+        if on_gpu:
             import torch
             return torch.from_numpy(ff).cuda()
         return ff
+
+    def _side_engine(self, shape, with_kernel=True):
+        """
+        The engine kept per DFT shape for transforms beside the loop (get_farfield; phase_ff inside a callback), with this
+        hologram's source amplitude -- re-sent only when it is another object than last time -- and, ``with_kernel``, its
+        own propagation kernel.  Returns the engine (``with_kernel``) or (engine, slot) for get_farfield's kernel logic.
+        """
+        shape = (int(shape[0]), int(shape[1]))
+        engines = self.__dict__.setdefault("_ff_engines", {})
+        slot = engines.get(shape)
+        if slot is None:
+            slot = engines[shape] = {"engine": Engine(shape, self.slm_shape, self.dtype, batch=1), "amp": None, "kernel": None}
+        e = slot["engine"]
+        fp = _fingerprint(self.amp)
+        if slot["amp"] != fp:
+            if np.isscalar(self.amp):
+                e.set(L.AMP_SCALAR, np.array([self.amp], dtype=self.dtype))
+            else:
+                e.set(L.AMP, self.amp)
+            slot["amp"] = fp
+        if not with_kernel:
+            return e, slot
+        kern = self.propagation_kernel
+        if kern is None:
+            if slot["kernel"] is not False:
+                e.clear_propagation_kernel()
+                slot["kernel"] = False
+        elif slot["kernel"] != _fingerprint(kern):
+            e.set(L.PROP_KERNEL, np.ascontiguousarray(kern, dtype=self.dtype))
+            slot["kernel"] = _fingerprint(kern)
+        return e
+
+    def refresh_farfield_inputs(self):
+        """Forget the device copies of the source amplitude and propagation kernel the per-shape transform engines hold
+        (get_farfield re-sends them only when the arrays look changed -- see _fingerprint): after an in-place edit that the
+        sample cannot see."""
+        for slot in self.__dict__.get("_ff_engines", {}).values():
+            slot["amp"] = slot["kernel"] = None
 
     # ---- statistics bookkeeping (_stats.py:118-223) ---------------------------------------------------------
     @staticmethod
@@ -692,6 +743,54 @@ class Hologram:
             return -1
         return Engine.STAT_GROUPS.index(groups[0])
 
+    def _callback_loop_ok(self):
+        """
+        A callback runs against the device-resident loop -- one fused engine call per iteration, the arrays it may look at
+        materialised only when it does -- unless something needs the general operators' intermediate arrays on the host
+        every iteration: ``raw_stats``, an efficiency-gated Kim fixing the host has to decide, or the caller's own
+        ``HGS_OPT_FORCE_STEPWISE`` (``engine_options``), which keeps the materialising loop.
+        """
+        fl = self.flags
+        if fl.get("raw_stats", False) or self._efficiency_group() == -1:
+            return False
+        return not self.engine_options.get(L.OPT_FORCE_STEPWISE, 0) and os.environ.get("HGS_CALLBACK_STEPWISE") != "1"
+
+    def _midloop_materialise(self, name):
+        """
+        What a callback sees mid-iteration (_hologram.py:1465-1477): ``farfield`` and ``amp_ff`` of the CURRENT phase -- one
+        forward transform from the phase the engine holds, run the first time either is read; it leaves the fused state
+        alone -- and ``phase_ff`` as the previous body left it: atan2 of the farfield THAT body started from (zero where an
+        MRAF target is zero), unless the phase was fixed.  The fused kernels never store that array; the engine keeps the
+        phase the body started from instead (HGS_OPT_KEEP_PREV_PHASE) and its farfield phase is formed here on demand.
+        """
+        state = self._midloop
+        e = self._get_engine()
+        if self.__dict__.get("_populate_pending"):
+            # first invocation of this call and nobody has looked at the previous call's results yet: its trailing transform
+            # is exactly what the callback is entitled to see (farfield and amp_ff of the current phase, phase_ff as
+            # _populate_results leaves it)
+            self._flush_populate()
+            state["ff"] = state["pff"] = True
+            return
+        if name in ("farfield", "amp_ff"):
+            if not state.get("ff"):
+                e.nearfield2farfield(store_phase_ff=False)
+                self._mark_device_fresh(["farfield", "amp_ff"])
+                state["ff"] = True
+        elif not state.get("pff"):
+            state["pff"] = True
+            prev = e.get_prev_phase() if state["bodies"] > 0 else None
+            if prev is not None:
+                side = self._side_engine(self.shape)
+                side.set(L.PHASE, prev)
+                side.nearfield2farfield(store_phase_ff=True)
+                pf = side.get(L.PHASE_FF)[0]
+                if self._mraf_enabled():
+                    pf[self.target == 0] = 0                   # the zero region is cleared before the arctan2 (:1613-1636)
+                self._host["phase_ff"] = pf
+                self._stale.discard("phase_ff")
+                self._upload.discard("phase_ff")
+
     def _device_loop_ok(self, callback):
         """
         True when the whole loop can run inside one engine call: no callback, no raw farfield capture, and an
@@ -709,11 +808,12 @@ class Hologram:
             # Nobody looked at the results of the previous call.  Its trailing transform matters to this loop only
             # through phase_ff, which a fixed phase (WGS-Kim after fixing, "GS" after such a run: quirk A4) reads;
             # a callback may look at any of it.  Otherwise this call's own trailing transform replaces all of it.
-            if callback is not None or self.flags.get("fixed_phase", False):
+            if self.flags.get("fixed_phase", False) or (callback is not None and not self._callback_loop_ok()):
                 self._flush_populate()
-            else:
+            elif callback is None:
                 self._populate_pending = False
                 self._stale -= {"farfield", "amp_ff", "phase_ff"}
+            # (a callback against the device-resident loop: still pending -- run if its first invocation looks)
         e = self._get_engine()
         self._pre_loop_checks()
         n_total = len(iterations)
@@ -748,6 +848,47 @@ class Hologram:
             if bar is not None:
                 bar.close()
             self._mark_device_fresh(["phase", "weights"])
+        elif self._callback_loop_ok():
+            # a callback against the device-resident loop: one fused engine call per iteration (the last launch of a call
+            # leaves G of the next body behind, so this costs a call's overhead, not a transform); what the callback may
+            # read is materialised when it does (_midloop_materialise)
+            groups, width, xy = self._device_stat_groups() if len(self.flags["stat_groups"]) > 0 else ([], 1, None)
+            eg = self._efficiency_group()
+            e.set_option(L.OPT_KEEP_PREV_PHASE, 1)
+            bodies = 0
+            try:
+                for _ in iterations:
+                    self._get_engine()                       # push what the caller changed since the last body
+                    self._midloop = {"bodies": bodies}
+                    try:
+                        stop = callback(self)
+                    finally:
+                        self._midloop = None
+                    if stop:
+                        break
+                    # a phase assigned inside the callback is overwritten by this body's own result, as in the reference
+                    # (:1483-1487: _farfield2nearfield extracts the phase from the farfield the body started with)
+                    if "phase" in self._upload:
+                        self._upload.discard("phase")
+                        self._stale.add("phase")
+                    e = self._get_engine()
+                    st = self._make_step(efficiency_group=eg)
+                    if groups:
+                        hist, per_iter = e.iterate_stats(st, 1, groups, width, xy)
+                    else:
+                        hist, per_iter = e.iterate(st, 1), None
+                    self._update_stats_batch(1, hist, None if per_iter is None else [{g: per_iter[0][g][0] for g in groups}], groups)
+                    self.iter += 1
+                    bodies += 1
+                    if self._populate_pending:               # the previous call's trailing transform: nobody looked, now stale
+                        self._populate_pending = False
+                        self._stale -= {"farfield", "amp_ff", "phase_ff"}
+                    self.flags["fixed_phase"] = bool(st.fixed_phase)
+                    self._mark_device_fresh(["phase", "weights"])
+                    self._stale -= {"farfield", "amp_ff"}
+            finally:
+                if self._engine is not None:
+                    self._engine.set_option(L.OPT_KEEP_PREV_PHASE, 0)
         else:
             for _ in iterations:
                 self._get_engine()                       # push user edits made inside callbacks

@@ -98,6 +98,17 @@ def _targ(v):
     return {True: "true", False: "false"}.get(v, str(v)) if isinstance(v, bool) else str(v)
 
 
+def force_stepwise(h):
+    """The general (materialising) operators for this hologram's loops: HGS_OPT_FORCE_STEPWISE in its engine options, which
+    also keeps optimize(callback=...) on the host-driven loop of three engine calls per iteration (rounds 1 - 4: every
+    callback did; since round 5 a callback runs against the device-resident loop)."""
+    from slmsuite_amd import _lib as L
+    h.engine_options[L.OPT_FORCE_STEPWISE] = 1
+    if getattr(h, "_engine", None) is not None:
+        h._engine.set_option(L.OPT_FORCE_STEPWISE, 1)
+    return h
+
+
 def dispatch_of(h):
     """Dispatch record of a hologram's (or batch's, or bare) engine; reading clears it."""
     e = getattr(h, "_engine", None) or getattr(h, "engine", None) or h

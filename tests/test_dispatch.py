@@ -97,10 +97,25 @@ def test_stepwise_option_and_callbacks_run_the_three_operators():
     d = dispatch_of(h)
     assert d.count("col_kernel", N=n, MODE=3) == 3 and d.count("col_kernel", N=n, MODE=24) == 3, d
     assert d.count("col_fused_kernel") + d.count("col_tile_kernel") == 0, d
-    h2 = Hologram(_image(n), phase=synth.seed_phase(1, (n, n)))
+    # the same option keeps a callback on the host-driven loop (three engine calls per iteration) ...
+    h2 = Hologram(_image(n), phase=synth.seed_phase(1, (n, n)), engine_options={L.OPT_FORCE_STEPWISE: 1})
     h2.optimize("WGS-Leonardo", maxiter=2, verbose=False, callback=lambda hh: False)
     d = dispatch_of(h2)
     assert d.count("col_kernel", MODE=3) == 2 and d.count("col_kernel", MODE=24) == 2 and d.count("col_fused_kernel") == 0, d
+    # ... without it a callback runs against the device-resident loop: one fused call per iteration, whose last row launch
+    # (MODE 3) leaves G behind, so that only the first call rebuilds it from the phase; nothing is materialised for a
+    # callback that reads nothing
+    h3 = Hologram(_image(n), phase=synth.seed_phase(1, (n, n)))
+    h3.optimize("WGS-Leonardo", maxiter=3, verbose=False, callback=lambda hh: False)
+    d = dispatch_of(h3)
+    assert d.count("col_fused_kernel", N=n) == 3 and d.count("col_kernel") == 0, d
+    assert d.count("row_kernel", MODE=0) == 1 and d.count("row_kernel", MODE=3) == 3 and d.count("row_kernel", MODE=2) == 0, d
+    # a callback that looks at the farfield gets one forward transform per look, from the G the loop left behind
+    seen = []
+    h3.optimize("WGS-Leonardo", maxiter=2, verbose=False, callback=lambda hh: seen.append(float(hh.amp_ff[3, 5])) and False)
+    d = dispatch_of(h3)
+    assert len(seen) == 2 and d.count("col_kernel", MODE=3) == 2 and d.count("col_fused_kernel", N=n) == 2, d
+    assert d.count("row_kernel", MODE=0) == 0, d              # dense path: G of every column is always there
 
 
 @pytest.mark.parametrize("shape, lines", [((100, 150), {256, 512}), ((300, 16384), {1024, 16384}), ((101, 75), {256})])

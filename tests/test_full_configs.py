@@ -165,8 +165,10 @@ def test_cfg2_error_growth_over_seeds():
     --variants all64 --curve, CPU only) hold, per seed and iteration, how far an IDEAL fp32 implementation -- the reference's
     op sequence with every FFT / arctan2 / exp evaluated in float64 and rounded once to float32 -- ends up from the reference.
     Asserted:
-      * 5 and 10 bodies: the north-star 1e-5 on every seed whose ideal-fp32 run is within 6e-6 there (15 of the 16);
-      * every recorded iteration: error <= max(1e-5, CFG2_YARD_FACTOR x the ideal implementation's distance);
+      * 5 and 10 bodies: the north-star 1e-5 on every seed whose ideal-fp32 run is within 3e-6 there;
+      * every recorded iteration: error <= max(1e-5, CFG2_YARD_FACTOR x the largest distance the ideal implementation has
+        shown up to that body) -- a run whose distance jumps (a spot crossing a zero of the field) jumps at another body in
+        another implementation -- and the geometric mean over a seed's six points <= CFG2_YARD_FACTOR;
       * over all seeds and iterations the GEOMETRIC MEAN of engine error / ideal distance is <= 1.3 (round 4 measured a
         worst ratio of 2.33 and could not say whether that was scatter or a worse operator: over the 48 points of the
         first eight seeds the geometric mean is 1.06 with a log-scatter of 0.63, per-seed means 0.4 .. 1.8 -- the engine is
@@ -179,6 +181,7 @@ def test_cfg2_error_growth_over_seeds():
     from conftest import GOLDEN
     worst_ratio = {"default": 0.0, "dense": 0.0}
     logs = {"default": {}, "dense": {}}
+    failures = []
     for fixture, yardfile in (("cfg2_seeds", "cfg2_ideal_fp32.json"), ("cfg2_seeds_b", "cfg2_ideal_fp32_b.json")):
         meta, gold = load_golden(fixture)
         ideal = json.load(open(os.path.join(GOLDEN, yardfile)))["per_seed_curve"]
@@ -188,6 +191,9 @@ def test_cfg2_error_growth_over_seeds():
             refp = np.concatenate((gold["curve_ampff_perturbed"][i], gold["spot_ampff_perturbed"][i][None]))
             drift = np.array([rel_l2(refp[k], ref[k]) for k in range(len(its))])
             yard = np.array([ideal[str(seed)]["all64"][str(k)] for k in its])
+            # what the ideal implementation has reached by then: a run whose distance jumps (one spot crossing a zero of
+            # the field) does so at another body in another implementation
+            envelope = np.maximum.accumulate(yard)
             for path in ("default", "dense"):
                 h = cfg2_hologram(seed, path)
                 ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
@@ -201,13 +207,14 @@ def test_cfg2_error_growth_over_seeds():
                 report(f"cfg2 seed {seed} [{path}] engine error at bodies {its}", **{f"it{k}": e for k, e in zip(its, err)})
                 report(f"cfg2 seed {seed} ideal fp32 implementation at bodies {its}", **{f"it{k}": e for k, e in zip(its, yard)})
                 report(f"cfg2 seed {seed} reference 1-ulp drift at bodies {its}", **{f"it{k}": e for k, e in zip(its, drift)})
-                # 5 and 10 bodies: the flat north-star tolerance, on the seeds whose ideal-fp32 run is itself within it there
-                # (seed 19 of the second set is 1.2e-5 / 1.8e-5 away after 5 / 10 bodies in exact arithmetic rounded once)
-                if np.all(yard[:2] < 6e-6):
-                    assert np.all(err[:2] < 1e-5), (seed, path, err)
                 worst_ratio[path] = max(worst_ratio[path], float((err / yard).max()))
                 logs[path][seed] = np.log(err / yard)
-                assert np.all(err < np.maximum(1e-5, CFG2_YARD_FACTOR * yard)), (seed, path, err, yard)
+                if np.all(yard[:2] < 3e-6) and not np.all(err[:2] < 1e-5):
+                    failures.append(("north-star at 5 / 10 bodies", seed, path, err[:2].tolist()))
+                if not np.all(err < np.maximum(1e-5, CFG2_YARD_FACTOR * envelope)):
+                    failures.append(("pointwise bound", seed, path, err.tolist(), yard.tolist()))
+                if np.exp(np.log(err / yard).mean()) > CFG2_YARD_FACTOR:
+                    failures.append(("per-seed geometric mean", seed, path, float(np.exp(np.log(err / yard).mean()))))
     report("cfg2 seed sweep: worst engine error / ideal-fp32 distance", **worst_ratio)
     for path, per_seed in logs.items():
         allp = np.concatenate(list(per_seed.values()))
@@ -217,7 +224,9 @@ def test_cfg2_error_growth_over_seeds():
                geometric_mean=gm_all, mean_of_per_seed_geometric_means=gm_seeds, log_scatter=float(allp.std()),
                per_seed_min=float(np.exp(min(v.mean() for v in per_seed.values()))),
                per_seed_max=float(np.exp(max(v.mean() for v in per_seed.values()))))
-        assert gm_all <= 1.3 and gm_seeds <= 1.3, (path, gm_all, gm_seeds)
+        if not (gm_all <= 1.3 and gm_seeds <= 1.3):
+            failures.append(("geometric mean over the sweep", path, gm_all, gm_seeds))
+    assert not failures, failures
 
 
 # ---- cfg 3: eight holograms per engine at 4096^2 ------------------------------------------------------------

@@ -14,7 +14,7 @@ Tolerances (fp32 unless noted), all stated as relative L2 norms:
 import numpy as np
 import pytest
 
-from conftest import dispatch_of, golden_names, load_golden, rel_l2, phase_rel_l2, report
+from conftest import dispatch_of, golden_names, load_golden, rel_l2, phase_rel_l2, report, force_stepwise
 from golden_cases import hologram_inputs, spot_external_amp
 from oracle import hgs_oracle as orc
 from slmsuite_amd import _lib as L
@@ -123,7 +123,7 @@ def step_pairs(gold):
     return [k for k in sorted(have_p) if (k + 1) in have_p and k in have_w]
 
 
-@pytest.mark.parametrize("mode", ["fused", "fused+stats", "stepwise"])
+@pytest.mark.parametrize("mode", ["fused", "fused+stats", "stepwise", "callback"])
 @pytest.mark.parametrize("name", golden_names("holo_"))
 def test_single_step_matches_reference(name, mode):
     meta, gold = load_golden(name)
@@ -134,7 +134,10 @@ def test_single_step_matches_reference(name, mode):
     for k in pairs:
         h = forced_hologram(meta, gold, k)
         kw = dict(meta["kwargs"])
-        if mode == "stepwise":      # a callback keeps the loop on the general (materialising) operators
+        if mode == "stepwise":      # the general (materialising) operators, three engine calls per iteration from the host
+            force_stepwise(h).optimize(meta["method"], maxiter=1, verbose=False, stat_groups=["computational"],
+                                       callback=lambda hh: False, **kw)
+        elif mode == "callback":    # a callback against the device-resident loop: one fused call per iteration
             h.optimize(meta["method"], maxiter=1, verbose=False, stat_groups=["computational"],
                        callback=lambda hh: False, **kw)
         elif mode == "fused+stats":   # device-resident loop with the statistics accumulated in the pass
@@ -203,18 +206,19 @@ def test_trajectory_matches_reference(name):
     assert phase_rel_l2(h2.phase, gold["final_phase"]) < tol_p
 
 
-@pytest.mark.parametrize("mode", ["fused", "stepwise"])
+@pytest.mark.parametrize("mode", ["fused", "stepwise", "callback"])
 @pytest.mark.parametrize("name", golden_names("mraf_"))
 def test_mraf_single_steps(name, mode):
     """MRAF (NaN noise region, zero region, mraf_factor, zero_factor): the fused kernels (zero_factor forces the
     general operators) and the general path (callback) against the recorded steps."""
     meta, gold = load_golden(name)
-    cb = (lambda hh: False) if mode == "stepwise" else None
-    h = Hologram(**hologram_inputs(meta))
+    cb = (lambda hh: False) if mode != "fused" else None
+    prep = force_stepwise if mode == "stepwise" else (lambda hh: hh)       # "callback": the device-resident loop under a callback
+    h = prep(Hologram(**hologram_inputs(meta)))
     h.optimize(meta["method"], maxiter=1, verbose=False, callback=cb, **meta["kwargs"])
     assert phase_rel_l2(h.phase, gold["phase_1"]) < 5e-6
     # teacher-forced 2 -> 3 is not recorded (no phase_3); check 1 -> 2 from the recorded state
-    h = Hologram(**hologram_inputs(meta))
+    h = prep(Hologram(**hologram_inputs(meta)))
     h.phase = gold["phase_1"].copy()
     h.iter = 1
     h.stats["flags"]["fixed_phase"] = [False]
@@ -484,7 +488,7 @@ def test_in_pass_statistics_match_general_path_and_reference(name):
     """
     optimize(stat_groups=[...]) without a callback keeps the loop on the device: the fused column
     kernel accumulates the "computational" reductions and the spot windows read the amp_ff it
-    stores.  Must agree with (i) the general path (callback forces it) and (ii) the statistics the
+    stores.  Must agree with (i) the general path (HGS_OPT_FORCE_STEPWISE + a callback: the host-driven loop) and (ii) the statistics the
     reference recorded, and walk to the same end state.
     """
     meta, gold = load_golden(name)
@@ -495,7 +499,7 @@ def test_in_pass_statistics_match_general_path_and_reference(name):
                                                    basis="knm", slm_shape=slm,
                                                    phase=synth.seed_phase(meta["seed"], slm))
     groups = ["computational", "computational_spot"]
-    h_dev, h_gen = make(), make()
+    h_dev, h_gen = make(), force_stepwise(make())
     h_dev.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, feedback=meta["feedback"],
                    stat_groups=groups, **meta["kwargs"])
     h_gen.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, feedback=meta["feedback"],
@@ -523,7 +527,7 @@ def test_in_pass_statistics_dense_target(name):
     if name not in golden_names("holo_") + golden_names("mraf_"):
         pytest.skip("fixture not recorded")
     meta, gold = load_golden(name)
-    h_dev, h_gen = Hologram(**hologram_inputs(meta)), Hologram(**hologram_inputs(meta))
+    h_dev, h_gen = Hologram(**hologram_inputs(meta)), force_stepwise(Hologram(**hologram_inputs(meta)))
     n_it = 3     # dense WGS trajectories are chaotic: compare while they are still together
     h_dev.optimize(meta["method"], maxiter=n_it, verbose=False, stat_groups=["computational"], **meta["kwargs"])
     h_gen.optimize(meta["method"], maxiter=n_it, verbose=False, stat_groups=["computational"],
@@ -542,8 +546,8 @@ def test_in_pass_statistics_full_size_and_batch():
     h = SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm,
                                             phase=synth.seed_phase(2, slm))
     h.optimize("WGS-Leonardo", maxiter=4, verbose=False, stat_groups=["computational", "computational_spot"])
-    g = SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm,
-                                            phase=synth.seed_phase(2, slm))
+    g = force_stepwise(SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm,
+                                                           phase=synth.seed_phase(2, slm)))
     g.optimize("WGS-Leonardo", maxiter=4, verbose=False, stat_groups=["computational", "computational_spot"],
                callback=lambda hh: False)
     for grp in ("computational", "computational_spot"):

@@ -13,7 +13,7 @@ Tolerances are relative L2 norms (phase: distance of unit phasors), fp32.
 import numpy as np
 import pytest
 
-from conftest import dispatch_of, golden_names, load_golden, rel_l2, phase_rel_l2, report
+from conftest import dispatch_of, golden_names, load_golden, rel_l2, phase_rel_l2, report, force_stepwise
 from golden_cases import hologram_inputs, spot_null_ctor
 from slmsuite_amd import _lib as L
 from slmsuite_amd import synth
@@ -24,20 +24,23 @@ from test_gpu_parity import forced_hologram, step_pairs
 pytestmark = pytest.mark.gpu
 
 MODES = {"device": dict(cb=False, opts={}), "device-dense": dict(cb=False, opts={L.OPT_SPARSE_COLUMNS: 0}),
-         "stepwise": dict(cb=True, opts={})}
+         "stepwise": dict(cb=True, opts={L.OPT_FORCE_STEPWISE: 1}),      # host-driven loop over the general operators
+         "callback": dict(cb=True, opts={})}                               # a callback against the device-resident loop
 
 
 # ---- WGS-Kim fixed by efficiency -------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["device", "stepwise"])
+@pytest.mark.parametrize("mode", ["device", "stepwise", "callback"])
 def test_kim_efficiency_gate_single_steps(mode):
     """Every recorded body of the dense 64^2 run, teacher-forced: before the threshold, the body that crosses it
     (the flag must come out raised, the phase still taken from the current farfield) and the fixed bodies after."""
     meta, gold = load_golden("kimeff_hologram")
     pairs = step_pairs(gold)
     assert 4 in pairs and 5 in pairs, pairs
-    cb = (lambda hh: False) if mode == "stepwise" else None
+    cb = (lambda hh: False) if mode != "device" else None
     for k in pairs:
         h = forced_hologram(meta, gold, k)
+        if mode == "stepwise":
+            force_stepwise(h)
         h.optimize(meta["method"], maxiter=1, verbose=False, stat_groups=meta["stat_groups"], callback=cb, **meta["kwargs"])
         ep = phase_rel_l2(h.phase, gold[f"phase_{k + 1}"])
         ew = rel_l2(h.weights, gold[f"weights_{k + 1}"])
@@ -50,13 +53,15 @@ def test_kim_efficiency_gate_single_steps(mode):
                                    gold["stats_computational_efficiency"][k], rtol=1e-4)
 
 
-@pytest.mark.parametrize("mode", ["device", "stepwise"])
+@pytest.mark.parametrize("mode", ["device", "stepwise", "callback"])
 def test_kim_efficiency_gate_trajectory_hologram(mode):
     """From the seed: the flag history the reference walked (the efficiency crosses 0.95 in iteration 4, margins of
     1 % and 2.4 % on either side) and the statistics.  Dense pixel-wise WGS is chaotic, so the end state is loose."""
     meta, gold = load_golden("kimeff_hologram")
     h = Hologram(**hologram_inputs(meta))
-    cb = (lambda hh: False) if mode == "stepwise" else None
+    if mode == "stepwise":
+        force_stepwise(h)
+    cb = (lambda hh: False) if mode != "device" else None
     h.optimize(meta["method"], maxiter=meta["maxiter"], verbose=False, stat_groups=meta["stat_groups"], callback=cb,
                **meta["kwargs"])
     assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]

@@ -159,6 +159,94 @@ def wavefront_pattern():
     return out
 
 
+def callback_pattern():
+    """
+    optimize(callback=...) at cfg 2 (_hologram.py:1465-1490: the callback fires every iteration).  Since round 5 it runs
+    against the device-resident loop -- one fused engine call per iteration, what the callback reads materialised on demand;
+    the host-driven loop of the general operators (rounds 1 - 4, now behind HGS_OPT_FORCE_STEPWISE) beside it.
+    """
+    out = {}
+    for name, opts in (("engine_default", {}), ("dense_kernels", {L.OPT_SPARSE_COLUMNS: 0})):
+        h = SpotHologram.make_rectangular_array(SH, (32, 32), (64, 64), basis="knm", slm_shape=SLM, phase=synth.seed_phase(2, SLM),
+                                                engine_options=opts)
+        h.optimize("WGS-Leonardo", maxiter=K, verbose=False)
+        h._engine.sync()
+
+        def timed(**kw):
+            ts = []
+            for _i in range(5):
+                t = time.perf_counter()
+                h.optimize("WGS-Leonardo", maxiter=K, verbose=False, **kw)
+                h._engine.sync()
+                ts.append(ms(t))
+            return float(np.median(ts))
+        r = {"no_callback_optimize50_ms": timed()}
+        r["callback_reads_nothing_ms"] = timed(callback=lambda hh: False)
+        r["callback_reads_iter_and_stats_ms"] = timed(callback=lambda hh: hh.iter < 0 or len(hh.stats["method"]) < 0)
+        ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
+        r["callback_reads_amp_ff_every_10th_ms"] = timed(callback=lambda hh: hh.iter % 10 == 0 and float(hh.amp_ff[ky[0], kx[0]]) < 0)
+        r["callback_over_no_callback"] = r["callback_reads_nothing_ms"] / r["no_callback_optimize50_ms"]
+        g = SpotHologram.make_rectangular_array(SH, (32, 32), (64, 64), basis="knm", slm_shape=SLM, phase=synth.seed_phase(2, SLM),
+                                                engine_options={**opts, L.OPT_FORCE_STEPWISE: 1})
+        g.optimize("WGS-Leonardo", maxiter=K, verbose=False, callback=lambda hh: False)
+        t = time.perf_counter()
+        g.optimize("WGS-Leonardo", maxiter=K, verbose=False, callback=lambda hh: False)
+        g._engine.sync()
+        r["host_driven_loop_callback_ms"] = ms(t)
+        out[name] = r
+    return out
+
+
+def wavefront_breakdown():
+    """Where one round of the wavefront-calibration pattern goes: every Engine call of the round, synchronised and timed."""
+    from slmsuite_amd.engine import Engine
+    slm_shape = (1152, 1920)
+    fs = SimpleFourierSLM(SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78))
+    basis = np.array([2, 1, 4, 3, 5, 7, 8, 6, 9, 12])
+    N = 16
+    z = np.zeros((len(basis), N))
+    z[:2] = 600 * (synth.uniform01(41, (2, N), 0) - 0.5)
+    z[2:] = 1.0 * (synth.uniform01(42, (len(basis) - 2, N), 0) - 0.5)
+    h = CompressedSpotHologram(z.copy(), basis=basis, cameraslm=fs)
+    h.reset_phase(synth.seed_phase(40, slm_shape))
+    h.optimize("GS", maxiter=3, verbose=False)
+    _ = h.get_phase()
+    acc, cnt = {}, {}
+
+    def wrap(name):
+        orig = getattr(Engine, name)
+
+        def f(self, *a, **k):
+            t = time.perf_counter()
+            r = orig(self, *a, **k)
+            self.sync()
+            acc[name] = acc.get(name, 0.0) + ms(t)
+            cnt[name] = cnt.get(name, 0) + 1
+            return r
+        setattr(Engine, name, f)
+        return orig
+
+    names = ["set", "set_sparse", "reset_weights", "reset", "iterate", "nearfield2farfield", "get", "set_option"]
+    saved = {n: wrap(n) for n in names}
+    rounds = 8
+    try:
+        t0 = time.perf_counter()
+        for rnd in range(rounds):
+            z[2 + rnd % 8, :] += 0.05
+            h.spot_zernike = z.copy()
+            h.optimize("GS", maxiter=3, verbose=False)
+            _ = h.get_phase()
+        total = ms(t0) / rounds
+    finally:
+        for n, o in saved.items():
+            setattr(Engine, n, o)
+    out = {"round_ms_with_a_sync_after_every_engine_call": total}
+    out.update({f"engine.{k}_ms_per_round": v / rounds for k, v in acc.items()})
+    out.update({f"engine.{k}_calls_per_round": cnt[k] / rounds for k in cnt})
+    out["host_side_ms_per_round"] = total - sum(acc.values()) / rounds
+    return out
+
+
 def camera_frame_pattern():
     """
     SimulatedCamera's per-frame work (hardware/cameras/simulated.py:344-376): a fresh amplitude array and phase are handed
@@ -215,7 +303,8 @@ def camera_frame_pattern():
 if __name__ == "__main__":
     res = {"workload": "cfg2: SpotHologram 32x32 on 4096^2, S = 1152x1920, WGS-Leonardo x 50",
            "engine_default": run(False), "dense_kernels": run(True), "cold_call_breakdown": breakdown(),
-           "wavefront_calibration_pattern": wavefront_pattern(), "camera_frame_pattern": camera_frame_pattern()}
+           "wavefront_calibration_pattern": wavefront_pattern(), "wavefront_calibration_breakdown": wavefront_breakdown(),
+           "callback_pattern": callback_pattern(), "camera_frame_pattern": camera_frame_pattern()}
     txt = json.dumps(res, indent=1)
     print(txt)
     if len(sys.argv) > 1:

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 run5() {
   case "$1" in
-    trace8k) for b in pad6 pad4 pad3 mraf f64; do tools/microbench/trace8k_$b; done > gpurun_out/r5_trace8k.log 2>&1
+    trace8k) for b in pad6 pad4 pad3 pad3_exp mraf mraf_exp f64 f64_exp; do echo "-- $b"; tools/microbench/trace8k_$b; tools/microbench/trace8k_$b | tail -1; done > gpurun_out/r5_trace8k.log 2>&1
              for b in pad6 pad4 pad3 mraf f64; do echo "==== $b"; tools/microbench/trace8k_${b}_t; done > gpurun_out/r5_trace8k_timeline.log 2>&1 ;;
     ab) shift; bash tools/gpu_ab.sh "$@" ;;
     *) bash tools/gpu_r4.sh "$@" ;;
