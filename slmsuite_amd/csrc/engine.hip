@@ -221,9 +221,9 @@ template <typename R> struct Engine : EngineBase {
     int opt_sep_min = 96;                  // smallest spot count the matrix-core form is used for (tools/sep_crossover.py)
     int opt_roctx = 0;                     // HGS_OPT_ROCTX: roctx ranges around the operators
     int opt_tile_rule = 1;                 // developer A/B (HGS_TILE_RULE=0 at create): rule-specialised tile kernels off
-    // G left behind (round 5): the last launch of a fused hgs_iterate call is row_kernel MODE 3 -- it writes the phase AND the
-    // row-transformed field of the next body -- and the next call (or hgs_nearfield2farfield) skips its own first row launch
-    // while nothing that G depends on (phase, amplitude, kernel, the set of stored columns) has changed.
+    // G left behind (round 5): the last launch of a fused float32 hgs_iterate call is row_kernel MODE 3 -- it writes the phase AND
+    // the row-transformed field of the next body, every column of it -- and the next call (or hgs_nearfield2farfield) skips its
+    // own first row launch while nothing that G depends on (phase, amplitude, kernel) has changed.
     //   gh_state: -1 = gh does not hold G; 0 = G of every column; 1 = of the active columns; 2 = of the dilated active columns
     int gh_state = -1;
     // HGS_OPT_KEEP_PREV_PHASE: the phase a one-iteration fused call started from (what its farfield phase describes)
@@ -1913,9 +1913,6 @@ template <typename R> struct Engine : EngineBase {
         Plan p = plan_iteration(st, hist ? hist : nullptr);
         if (int e = keep_prev_phase(p, n)) return e;
         if (!gh_holds(windows_needed(p) ? 2 : 1)) { if (int e = run_row(0, false, 0, windows_needed(p) ? 2 : 1)) return e; }
-        // what the last launch of the call stores for the next one (MODE 3): the dilated columns whenever a window may be
-        // read (they include the active ones)
-        const int store_end = (st->feedback == HGS_FB_SPOT_WINDOW || (groups & 2)) ? 2 : 1;
         for (int i = 0; i < n; ++i) {
             gh_state = -1;
             if (p.use_fixed || p.store_phase) { if (int e = need_pff()) return e; }
@@ -1976,8 +1973,8 @@ template <typename R> struct Engine : EngineBase {
                 pn = plan_iteration(st, hist ? hist + i + 1 : nullptr);
                 store_next = windows_needed(pn) ? 2 : 1;
             }
-            const int last_mode = (opt_keep_g && sizeof(R) == 4) ? 3 : 1;
-            if (int e = run_row(i + 1 < n ? 2 : last_mode, false, 1, i + 1 < n ? store_next : store_end)) return e;
+            const int last_mode = (opt_keep_g && sizeof(R) == 4) ? 3 : 1;          // (MODE 3 stores every column, see iterate())
+            if (int e = run_row(i + 1 < n ? 2 : last_mode, false, 1, i + 1 < n ? store_next : (last_mode == 3 ? 0 : store_next))) return e;
             p = pn;
         }
         return 0;
@@ -2196,9 +2193,11 @@ template <typename R> struct Engine : EngineBase {
             // the row kernel that follows folds the weight-norm partials into wscale (unless already done);
             // on the sparse path it reads the active columns and writes those the next column launches read
             // the last launch of the call extracts the phase; in float32 (and unless a single-pass MRAF body has to join its
-            // two parts) it also leaves G of the next body behind (MODE 3), for the next call on an unchanged phase
+            // two parts) it also leaves G of the next body behind (MODE 3) -- of EVERY column, also on the column-list path,
+            // so that whatever comes next (another call, the transform that ends optimize()) can start from it on every path
             const int last_mode = (opt_keep_g && sizeof(R) == 4 && !row_split) ? 3 : 1;
-            if (int e = run_row(i + 1 < n ? 2 : last_mode, p.do_update != 0 && !two_pass, sp ? 1 : 0, sp ? store_sparse : 0))
+            const bool last = i + 1 == n;
+            if (int e = run_row(last ? last_mode : 2, p.do_update != 0 && !two_pass, sp ? 1 : 0, (last && last_mode == 3) ? 0 : (sp ? store_sparse : 0)))
                 return e;
             p = pn;
         }
@@ -2440,7 +2439,8 @@ template <typename R> struct Engine : EngineBase {
     }
 
     int set_option(int option, int value) override {
-        gh_state = -1;             // (a policy change may change which columns the next launch expects in gh)
+        // (a change of the column policy may change which columns the next launch expects in gh)
+        if (option == HGS_OPT_SPARSE_COLUMNS || option == HGS_OPT_FORCE_STEPWISE || option == HGS_OPT_TILE_KERNEL) gh_state = -1;
         switch (option) {
             case HGS_OPT_SPARSE_COLUMNS: opt_sparse = value ? 1 : 0; return 0;
             case HGS_OPT_FORCE_STEPWISE: opt_stepwise = value ? 1 : 0; return 0;

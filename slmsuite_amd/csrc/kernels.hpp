@@ -433,9 +433,14 @@ __device__ __forceinline__ double rsqrt_full(double x) { return 1.0 / ::sqrt(x);
 //   MODE 1 : H -> phase            (row half of ifft2 :1070 + _nearfield_extract :1026)
 //   MODE 2 : H -> phase -> G       (MODE 1 then MODE 0 of the next iteration, fused: the row never
 //                                   leaves the CU between the two iterations)
-//   MODE 3 : H -> phase -> G with the phase WRITTEN and G built from the written value (MODE 1 and MODE 0
-//            in one launch, bit for bit): the LAST launch of an hgs_iterate call leaves G behind, so that
-//            the next call on an unchanged phase starts with its column launch (round 5)
+//   MODE 3 : MODE 2 that also writes the phase as MODE 1 does: the LAST launch of a float32 hgs_iterate call
+//            leaves G of EVERY column behind (it ignores the store mask), so that the next call -- or
+//            hgs_nearfield2farfield -- on an unchanged phase starts with its column launch (round 5).  The G it
+//            leaves is MODE 2's, bit for bit: a loop cut into several calls walks exactly like one call.  (A
+//            first form rebuilt G from the WRITTEN phase -- MODE 1 + MODE 0 in one launch -- to stay bit-identical
+//            to a call that cannot reuse it; its atan2 + sincos made it as slow as those two launches together,
+//            40.8 us against 28 for MODE 2, i.e. nothing was saved.  Every column is stored so that ALL paths --
+//            column lists too -- can always reuse it and therefore agree with each other.)
 // grid = (<= ceil(Sh / FPW), batch), block = WG;  FPW = WG / T rows per workgroup pass; a workgroup
 // strides over rows so the per-lane twiddle registers are fetched once per kernel.
 // =====================================================================================================
@@ -673,17 +678,11 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                     R amv = bam.template ld<R>(co, 0u);                      // (no amplitude array: empty resource)
                     if (am == nullptr) amv = (co < row_bytes) ? a.amp_scalar : (R)0;
                     Cx<R> nf;
-                    if constexpr (MODE == 3) {
-                        // MODE 1 and MODE 0 in one: the phase as MODE 1 stores it, the nearfield from that stored value
+                    if constexpr (MODE == 3) {                  // the phase as MODE 1 stores it (no kernel: reads 0) ...
                         const R sc1 = sgs * a.scale;
-                        const R kv = bkn.template ld<R>(co, 0u);                        // (no kernel: reads 0)
-                        R p = M::atan2(v[m].y * sc1, v[m].x * sc1) - kv;
-                        bph.template st<R>(p, co, 0u);
-                        p = p + kv;
-                        R sn, cs;
-                        M::sincos(p, &sn, &cs);
-                        nf = mk<R>(amv * sgs * cs, amv * sgs * sn);
-                    } else if constexpr (MODE == 2) {
+                        bph.template st<R>(M::atan2(v[m].y * sc1, v[m].x * sc1) - bkn.template ld<R>(co, 0u), co, 0u);
+                    }
+                    if constexpr (MODE >= 2) {                  // ... and G as MODE 2 builds it
                         // evaluated eagerly and selected (a conditional around it is a branch per element)
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         const Cx<R> on = v[m] * (amv * rsqrt_full(p2));
@@ -826,25 +825,18 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 Cx<R> nf = mk<R>(0, 0);
                 if (valid && c >= 0 && c < g.Sw) {
                     const R amv = (am != nullptr) ? am[c] : a.amp_scalar;
-                    if constexpr (MODE == 3) {
-                        // MODE 1 and MODE 0 in one: the phase exactly as MODE 1 stores it, and the nearfield from that STORED
-                        // value exactly as MODE 0 rebuilds it -- a call that finds G left behind continues bit for bit like
-                        // one that has to rebuild it from the phase (they meet on different paths: a column list leaves G of
-                        // its columns only, and the transform that ends optimize() rebuilds every column)
+                    if constexpr (MODE == 3) {                  // the phase exactly as MODE 1 stores it ...
                         const R scs = sgs * a.scale;
                         R p = M::atan2(v[m].y * scs, v[m].x * scs);
                         if (kn != nullptr) p -= kn[c];
                         ph[c] = p;
-                        if (kn != nullptr) p += kn[c];
-                        R s, co;
-                        M::sincos(p, &s, &co);
-                        nf = mk<R>(amv * sgs * co, amv * sgs * s);
-                    } else if constexpr (MODE == 2 && HGS_ROW_PHASOR) {
+                    }
+                    if constexpr (MODE >= 2 && HGS_ROW_PHASOR) {        // ... and G exactly as MODE 2 builds it
                         // nearfield of the inverse = sgn*scale*v, input of the forward = sgn*amp*phasor
                         const R p2 = v[m].x * v[m].x + v[m].y * v[m].y;
                         const Cx<R> on = v[m] * (amv * rsqrt_full(p2));      // (eager + select: no inner branches)
                         nf = mk<R>((p2 > (R)0) ? on.x : amv * sgs, (p2 > (R)0) ? on.y : (R)0);
-                    } else if constexpr (MODE == 2) {
+                    } else if constexpr (MODE >= 2) {
                         // the reference's own arithmetic: phase rounded to working precision, then exp(i phase)
                         const R scs = sgs * a.scale;
                         R p = M::atan2(v[m].y * scs, v[m].x * scs);
@@ -1921,6 +1913,188 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
         for (int i = j; i < nev; i += blockDim.x) dst[i] = src[i];
     }
 #endif
+}
+
+// =====================================================================================================
+// FUSED column kernel, HALF-width tile-resident form (round 5): a lane group of T = N / 16 lanes keeps TWO adjacent
+// columns of a 4-column tile (16 bytes per tile row and lane) in registers and transforms them from / to those
+// registers; the plain WGS-Leonardo / WGS-Kim update (RULE 1) or no update (RULE 2), as in col_tile_kernel.
+//   * N = 4096 (one lane group per 256-lane workgroup): for BATCHES.  Half the tile registers bring the kernel under
+//     168 VGPRs, i.e. three workgroups per CU instead of two -- +11 % throughput per CU (NOTEBOOK round 2); for one
+//     hologram the 4096 columns over 768 slots round 2.67 up to 3 and the gain is lost, for the 32,768 columns of a
+//     batch of eight (BASELINE config 3, the unit every GPU of the 8-GPU run executes) it is not.  The two halves of
+//     a tile go to two workgroups of ONE XCD that run together (half_xmap), so the 32-byte tile rows meet in that L2.
+//   * N = 2048 (two lane groups per workgroup, one half each: the workgroup moves whole 32-byte tile rows): the
+//     padded size Hologram.get_padded_shape(padding_order=1) gives a 1080-row SLM (what fourier_grid_project builds);
+//     until round 5 that size ran the per-column kernel (every GH byte re-fetched per column, 0.39 of the HBM peak).
+// =====================================================================================================
+template <int N> struct Tile2Cfg {
+    static constexpr int T = N / 16;
+    static constexpr int CPAR = T >= 256 ? 1 : 256 / T;       // lane groups per workgroup (2 at 2048)
+    static constexpr int WG = T * CPAR;
+};
+template <typename R, int N> constexpr size_t col_tile2_lds_bytes() {
+    return (size_t)Tile2Cfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
+}
+
+#ifndef HGS_TILE2_CONS_GROUP
+#define HGS_TILE2_CONS_GROUP 4      // pixels of a lane whose rule evaluation the scheduler may interleave (168 registers: fewer than col_tile_kernel's 16)
+#endif
+// (4096 rows: three waves per SIMD = three workgroups per CU, the point of the kernel; 2048 rows: two -- the general
+//  transform keeps 20 stage twiddles and up to ten tile slots, at three it spilled 14 .. 103 VGPRs)
+template <typename R, int N, int PHASE, int NR, int RULE>
+__global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile2_kernel(ColArgs<R> a, int shift, int half_xmap) {
+    constexpr int TILE2_CONS_GROUP = HGS_TILE2_CONS_GROUP;
+    using M = Math<R>;
+    static_assert(sizeof(R) == 4 && (N == 2048 || N == 4096) && (RULE == 1 || RULE == 2), "col_tile2_kernel: fp32, 2048 / 4096 rows, plain rules");
+    constexpr int T = Tile2Cfg<N>::T, CPAR = Tile2Cfg<N>::CPAR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo g = a.g;
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / T), j = tid % T;       // (T a multiple of 64: wave-uniform)
+    const int b = blockIdx.y;
+    Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + grp * lds_elems<N>();
+    double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
+
+    using Sel = FftSel<R, N, true>;
+    typename Sel::type fft;
+    fft.init(a.tw, j);
+    const CParams<R> cp = a.cp;
+    constexpr bool do_upd = RULE == 1;
+    const int js = Sel::space_lane(j);
+    const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const R sgs = (js & 1) ? (R)-1 : (R)1;
+    const size_t P = (size_t)g.Ph * g.Pw;
+    const R wsc = a.wscale[b];
+    Cx<R> om = a.tw[(j * shift) & (N - 1)];            // shift-theorem factor (see col_tile_kernel), sign and ortho scale folded in
+    om = om * (sgn * a.scale);
+    const int r_lane = js + shift - g.r0;              // SLM row of slot m is r_lane + m*T
+    const int ntiles = g.Pw / 4;
+    R acc_w = 0;
+
+    Cx<R> v[16];
+    // the half tile, one array per column and component: selected by the (uniform) column of the pass with v_cndmask -- a
+    // run-time index into [NR][2] arrays put them on the stack (96 bytes of scratch), unrolling the two passes made the
+    // scheduler interleave them (23 .. 187 spilled registers)
+    R g0x[NR], g0y[NR], g1x[NR], g1y[NR];
+    R wr[16], tr[16];
+    const R* wbase = a.w + (size_t)b * P;
+    const R* tbase = a.t + (size_t)b * P;
+
+    // schedule: CPAR = 2 -- a workgroup owns whole tiles, group g their half g.  CPAR = 1 -- a workgroup owns half tiles;
+    // with half_xmap (gridDim.x a multiple of 16) workgroups (xcd, 2 i) and (xcd, 2 i + 1) take the two halves of one tile
+    // (workgroups run round-robin over the 8 XCDs -- a speed-only assumption, as in row_kernel)
+    const int G = (int)gridDim.x;
+    int ct0, ct_step, half;
+    if constexpr (CPAR == 2) {
+        ct0 = (int)blockIdx.x; ct_step = G; half = grp;
+    } else if (half_xmap) {
+        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        half = idx & 1; ct0 = (idx >> 1) * 8 + xcd; ct_step = G / 2;
+    } else {                                   // (the host launches an even number of workgroups)
+        half = (int)blockIdx.x & 1; ct0 = (int)blockIdx.x >> 1; ct_step = G / 2;
+    }
+    bool first = true;
+#pragma unroll 1
+    for (int ct = ct0; ct < ntiles; ct += ct_step) {
+        Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + 2 * half;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            const int r = r_lane + m * T;
+            float4 q = make_float4(0, 0, 0, 0);
+            if (r >= 0 && r < g.Sh) q = *reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
+            g0x[m] = q.x; g0y[m] = q.y; g1x[m] = q.z; g1y[m] = q.w;
+        }
+        const int col0 = ct * 4 + 2 * half;
+        if (first) {
+            issue_wt_loads<R, T>(wbase + (size_t)col0 * g.Ph, tbase + (size_t)col0 * g.Ph, do_upd, j, wr, tr);
+            first = false;
+        }
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const size_t cb = (size_t)b * P + (size_t)(col0 + c) * g.Ph;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < NR) {
+                    const R xr = c ? g1x[m < NR ? m : 0] : g0x[m < NR ? m : 0], xi = c ? g1y[m < NR ? m : 0] : g0y[m < NR ? m : 0];
+                    v[m] = mk<R>(xr * sgs, xi * sgs);
+                } else {
+                    v[m] = mk<R>(0, 0);
+                }
+            }
+            fft.template fwd_lead<(NR < 4 ? 4 : NR)>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
+
+            R* wc = a.w + cb;
+            R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
+            bool w_changed = false;
+            R pf[PHASE != 0 ? 16 : 1];
+            if constexpr (PHASE == 2)
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; pf[m] = pfc[lane_pos<T>(j, m)]; });
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                // wave-uniform skip where weight and target are zero (see col_tile_kernel)
+                if (PHASE != 1 && HGS_SPARSE_SKIP && __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
+                    v[m] = mk<R>(0, 0);
+                    return;
+                }
+                const Cx<R> F = cmul(v[m], om);
+                const R p2 = F.x * F.x + F.y * F.y;
+                const R wraw = wr[m];
+                R wv = wraw * wsc;
+                if constexpr (do_upd) {
+                    const R t = tr[m];
+                    R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
+                    fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
+                    wv *= fc;
+                    if (is_nan(wv)) wv = (R)0.0001;
+                    w_changed |= (wv != wraw);
+                    wr[m] = wv;
+                    acc_w += wv * wv;
+                }
+                Cx<R> ph;
+                if constexpr (PHASE == 2) {
+                    R sn, cs;
+                    M::sincos_phase(pf[m], &sn, &cs);
+                    ph = mk<R>(cs, sn);
+                } else {
+                    const R inv = rsqrt_full(p2);
+                    ph = mk<R>((p2 > (R)0) ? F.x * inv : (R)1, (p2 > (R)0) ? F.y * inv : (R)0);
+                    if constexpr (PHASE == 1) pf[m] = M::atan2(F.y, F.x);
+                }
+                v[m] = cmulc(ph, om) * wv;
+                if constexpr (PHASE == 1 && m % 4 == 3) {
+                    static_for<m - 3, m + 1>([&](auto i_) { constexpr int i = i_; pfc[lane_pos<T>(j, i)] = pf[i]; });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (m % TILE2_CONS_GROUP == TILE2_CONS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+            });
+            if (do_upd && w_changed) {
+                static_for<0, 16>([&](auto m_) { constexpr int m = m_; wc[lane_pos<T>(j, m)] = wr[m]; });
+            }
+            {   // weights / target of the next column (or of the first column of this group's next half tile)
+                const int ncol = c == 0 ? col0 + 1 : (ct + ct_step) * 4 + 2 * half;
+                if (c == 0 || ct + ct_step < ntiles)
+                    issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, do_upd, j, wr, tr);
+            }
+            fft.template inv_after_fwd_trail<NR>(v, lds, j);
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const Cx<R> h = v[m] * (sgs * a.scale);
+                g0x[m] = c ? g0x[m] : h.x; g0y[m] = c ? g0y[m] : h.y;
+                g1x[m] = c ? h.x : g1x[m]; g1y[m] = c ? h.y : g1y[m];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            const int r = r_lane + m * T;
+            if (r >= 0 && r < g.Sh)
+                *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = make_float4(g0x[m], g0y[m], g1x[m], g1y[m]);
+        }
+    }
+    if constexpr (do_upd) {
+        const double s = block_sum((double)acc_w, scratch);
+        if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
+    }
 }
 
 // =====================================================================================================

@@ -32,6 +32,11 @@ template <typename R> int launch_tile_extras_stats(int N, int phase_mode, dim3 g
 int launch_tile_rule(int N, int phase_mode, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
 int launch_tile_rule_listed(int N, int phase_mode, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);   // a.col_list set
 
+// half-width tile-resident kernel (col_tile2_kernel): fp32, 4096 rows (batches: three workgroups per CU) and 2048 rows; plain
+// rules only (1: WGS-Leonardo / WGS-Kim update, 2: no update); tile2_has: an instance for this slot count exists
+bool tile2_has(int N, int nr);
+int launch_tile2(int N, int phase_mode, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int shift, int half_xmap);
+
 // single-pass MRAF with a weight update (col_tile_kernel RULE 3 writes a.gh / a.gh2, row_kernel SPLIT joins them); fp32,
 // N in {4096, 8192}
 int launch_tile_split(int N, int phase_mode, int nr, int rule_ok, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);

@@ -152,8 +152,13 @@ def test_cfg2_kim_every_column_path_matches_reference(path):
     assert errs["phase_sub"] < 3e-4
 
 
-# engine error <= max(1e-5, CFG2_YARD_FACTOR x the ideal-fp32 distance) at every recorded point of every seed
-CFG2_YARD_FACTOR = 3.0
+# Bounds of the cfg 2 seed sweep, in units of the ideal-fp32 implementation's distance from the reference.  Measured in
+# round 5 over 16 seeds x 6 bodies: geometric mean 1.15, log-scatter 0.60 (a factor 1.8 either way), per-seed geometric means
+# 0.37 .. 2.26, single points 0.21 .. 3.42 -- at that scatter 3 % of the points of a perfectly ideal implementation lie beyond
+# 3 x, so the single-point bound is a backstop and the means are the test.
+CFG2_YARD_FACTOR = 3.0           # headline seed, end state (test_cfg2_leonardo_every_column_path_matches_reference); per-seed geometric mean
+CFG2_POINT_FACTOR = 5.0          # any single point of the sweep, against the largest distance the ideal run has shown by then
+CFG2_MEAN_FACTOR = 1.3           # geometric mean over the sweep
 
 
 def test_cfg2_error_growth_over_seeds():
@@ -166,13 +171,14 @@ def test_cfg2_error_growth_over_seeds():
     op sequence with every FFT / arctan2 / exp evaluated in float64 and rounded once to float32 -- ends up from the reference.
     Asserted:
       * 5 and 10 bodies: the north-star 1e-5 on every seed whose ideal-fp32 run is within 3e-6 there;
-      * every recorded iteration: error <= max(1e-5, CFG2_YARD_FACTOR x the largest distance the ideal implementation has
+      * every recorded iteration: error <= max(1e-5, CFG2_POINT_FACTOR x the largest distance the ideal implementation has
         shown up to that body) -- a run whose distance jumps (a spot crossing a zero of the field) jumps at another body in
         another implementation -- and the geometric mean over a seed's six points <= CFG2_YARD_FACTOR;
-      * over all seeds and iterations the GEOMETRIC MEAN of engine error / ideal distance is <= 1.3 (round 4 measured a
-        worst ratio of 2.33 and could not say whether that was scatter or a worse operator: over the 48 points of the
-        first eight seeds the geometric mean is 1.06 with a log-scatter of 0.63, per-seed means 0.4 .. 1.8 -- the engine is
-        as far from the reference as an ideal fp32 implementation is; a 2x loss of accuracy anywhere doubles the mean);
+      * over all seeds and iterations the GEOMETRIC MEAN of engine error / ideal distance is <= CFG2_MEAN_FACTOR (round 4
+        measured a worst ratio of 2.33 over eight seeds and could not say whether that was scatter or a worse operator: over
+        the 96 points of sixteen seeds the geometric mean is 1.15 with a log-scatter of 0.60, per-seed means 0.37 .. 2.26 --
+        the engine is as far from the reference as an fp32 implementation whose every operator is rounded ONCE, give or take
+        the 0.14 standard error of that mean; a 2x loss of accuracy anywhere doubles it);
       * the same for the mean over seeds of the per-seed geometric means (the six points of one run are correlated).
     The distance the reference itself moves when its seed changes by one fp32 ulp (also in the fixtures) is reported.
     """
@@ -211,7 +217,7 @@ def test_cfg2_error_growth_over_seeds():
                 logs[path][seed] = np.log(err / yard)
                 if np.all(yard[:2] < 3e-6) and not np.all(err[:2] < 1e-5):
                     failures.append(("north-star at 5 / 10 bodies", seed, path, err[:2].tolist()))
-                if not np.all(err < np.maximum(1e-5, CFG2_YARD_FACTOR * envelope)):
+                if not np.all(err < np.maximum(1e-5, CFG2_POINT_FACTOR * envelope)):
                     failures.append(("pointwise bound", seed, path, err.tolist(), yard.tolist()))
                 if np.exp(np.log(err / yard).mean()) > CFG2_YARD_FACTOR:
                     failures.append(("per-seed geometric mean", seed, path, float(np.exp(np.log(err / yard).mean()))))
@@ -224,7 +230,7 @@ def test_cfg2_error_growth_over_seeds():
                geometric_mean=gm_all, mean_of_per_seed_geometric_means=gm_seeds, log_scatter=float(allp.std()),
                per_seed_min=float(np.exp(min(v.mean() for v in per_seed.values()))),
                per_seed_max=float(np.exp(max(v.mean() for v in per_seed.values()))))
-        if not (gm_all <= 1.3 and gm_seeds <= 1.3):
+        if not (gm_all <= CFG2_MEAN_FACTOR and gm_seeds <= CFG2_MEAN_FACTOR):
             failures.append(("geometric mean over the sweep", path, gm_all, gm_seeds))
     assert not failures, failures
 
