@@ -77,6 +77,36 @@ class EngineGroup:
     def version(self):
         return self.engines[0].version()
 
+    # what callers of a single-engine batch use on ``HologramBatch.engine``: fanned out over the groups in hologram order
+    def get(self, which):
+        """Array ``which`` of every hologram, [n, ...] (the groups' batches concatenated; shared arrays from the first)."""
+        if which in (L.AMP, L.AMP_SCALAR, L.PROP_KERNEL, L.SPOT_INDEX, L.SPOT_AMP, L.EXTERNAL_AMP):
+            return self.engines[0].get(which)
+        return np.concatenate([e.get(which) for e in self.engines], axis=0)
+
+    def nearfield2farfield(self, store_phase_ff=False):
+        for e in self.engines:
+            e.nearfield2farfield(store_phase_ff)
+
+    def farfield2nearfield(self):
+        for e in self.engines:
+            e.farfield2nearfield()
+
+    def iterate(self, step, n_iter):
+        """``n_iter`` bodies on every group from copies of ``step``; the flag history (the same for all) of the first, and
+        ``step`` left as the first group's call leaves it."""
+        import copy
+        hist = None
+        for k, e in enumerate(self.engines):
+            st = step if k == 0 else copy.copy(step)
+            h = e.iterate(st, n_iter)
+            hist = h if hist is None else hist
+        return hist
+
+    def __getattr__(self, name):
+        raise AttributeError(f"EngineGroup has no '{name}': a HologramBatch with several stream groups holds one engine per "
+                             "group (HologramBatch.engines); address them one by one or use the batch's own methods")
+
 
 class HologramBatch:
     """
@@ -156,6 +186,9 @@ class HologramBatch:
         group; with several, host clock from the first enqueue to the last stream's completion."""
         if self.flags is None:
             self.flags = batch_flags(method, **flags)
+        else:
+            kept = {k: v for k, v in self.flags.items() if k != "method"}      # (as optimize(): another method on the next call)
+            self.flags = batch_flags(method, **{**kept, **flags})
         steps = self._steps(spot_window)
         if len(self.engines) == 1:
             ms = self.engines[0].iterate_timed(steps[0], n_iter)

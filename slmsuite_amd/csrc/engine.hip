@@ -230,6 +230,8 @@ template <typename R> struct Engine : EngineBase {
     R* phase_prev = nullptr;
     bool have_prev = false;
     int opt_prev_phase = 0;
+    int opt_tile2 = 1;                     // developer A/B (HGS_TILE2=0 at create): half-width tile kernel off
+    int env_tile2_blocks = 0;              // ... its workgroups per launch over the batch (HGS_TILE2_BLOCKS; 0 = 3 x / 2 x #CU)
     int opt_keep_g = 1;                    // developer A/B (HGS_KEEP_G=0 at create)
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
     int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
@@ -398,6 +400,8 @@ template <typename R> struct Engine : EngineBase {
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_tile_nr4 = env_int("HGS_TILE_NR4", 1);
         opt_keep_g = env_int("HGS_KEEP_G", 1);
+        opt_tile2 = env_int("HGS_TILE2", 1);
+        env_tile2_blocks = env_int("HGS_TILE2_BLOCKS", 0);
         opt_tile_shift16 = env_int("HGS_TILE_SHIFT16", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
@@ -1037,6 +1041,32 @@ template <typename R> struct Engine : EngineBase {
         }
         return launch_fused<R>(g.Ph, phase_mode, grid, stream, a);
     }
+    // half-width tile-resident kernel (col_tile2_kernel): the grid it runs on, or 0 where it does not apply -- fp32, a dense
+    // launch of a plain pass (Leonardo / Kim update or none; no statistics, MRAF, Nogrette sum or forward-only pass), and
+    //   4096 rows: a batch (>= 2 holograms), farfield phase neither stored nor read (PHASE 0: the phase-storing instances do
+    //              not fit 168 registers), SLM rows within six slots -- 3 x #CU workgroups over the batch, a multiple of 16
+    //              per hologram so that the two halves of a tile run on one XCD together;
+    //   2048 rows: SLM rows within ten slots -- 2 x #CU workgroups of two lane groups, one tile each at a time.
+    int tile2_grid(bool sp, bool tile_path, const ColArgs<R>& a, int phase_mode) const {
+        if (sizeof(R) != 4 || !opt_tile2 || sp || a.do_stats || !opt_tile_rule) return 0;
+        if (a.cp.mraf || a.cp.nog_pass || a.cp.weights_only || a.cp.nog != nullptr) return 0;
+        if (a.cp.do_update && a.cp.method != HGS_WGS_LEONARDO && a.cp.method != HGS_WGS_KIM) return 0;
+        const int nr = tile_slots();
+        if (g.Ph == 4096) {
+            if (B < 2 || phase_mode != 0 || !tile_path || !tile2_has(4096, nr)) return 0;
+            const int per = (env_tile2_blocks > 0 ? env_tile2_blocks : 3 * n_cu) / B;
+            return std::max(16, per / 16 * 16);
+        }
+        if (g.Ph == 2048) {
+            if (!tile2_has(2048, nr)) return 0;
+            return std::max(1, std::min(g.Pw / 4, (env_tile2_blocks > 0 ? env_tile2_blocks : 2 * n_cu) / B));
+        }
+        return 0;
+    }
+    static int tile2_launch(int N, int phase, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int shift, int xmap) {
+        return launch_tile2(N, phase, rule, nr, grid, s, a, shift, xmap);
+    }
+    static int tile2_launch(int, int, int, int, dim3, hipStream_t, const ColArgs<double>&, int, int) { return (int)hipErrorInvalidValue; }
     // (the tile-resident kernel is fp32 only; this branch is never taken for double)
     static int tile_rule(int N, int phase, int rule, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
         return a.col_list != nullptr ? launch_tile_rule_listed(N, phase, rule, nr, grid, s, a, m0) : launch_tile_rule(N, phase, rule, nr, grid, s, a, m0);
@@ -2137,6 +2167,12 @@ template <typename R> struct Engine : EngineBase {
                         if (sp) a.col_flags = col_active;       // (scanned with the weights / target this loop started from)
                         LCHK(tile_split(g.Ph, phase_mode, m1 - m0 + 1, opt_tile_rule, dim3(tile_grid, B), stream, a, m0));
                         row_split = true;
+                    } else if (int t2 = tile2_grid(sp, tile_path, a, phase_mode)) {
+                        // half-width tile-resident kernel: batches at 4096 rows (three workgroups per CU), dense launches at
+                        // 2048 rows (col_tile2_kernel); plain passes only
+                        wpartial_n = t2;
+                        LCHK(tile2_launch(g.Ph, phase_mode, a.cp.do_update ? 1 : 2, m1 - m0 + 1, dim3(t2, B), stream, a, m0,
+                                          (g.Ph >= 4096 && t2 % 16 == 0) ? 1 : 0));
                     } else if (tile_path) {
                         wpartial_n = tile_grid;
                         const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;

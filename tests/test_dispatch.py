@@ -41,7 +41,7 @@ def test_record_names_template_arguments_and_clears():
 
 @pytest.mark.parametrize("n, dtype, family, extra", [
     (512, np.float32, "col_fused_kernel", dict(R="float", N=512)),
-    (2048, np.float32, "col_fused_kernel", dict(R="float", N=2048)),
+    (2048, np.float32, "col_tile2_kernel", dict(R="float", N=2048, NR=8)),     # half-width tile-resident kernel (520 SLM rows: within eight slots of 128)
     (4096, np.float32, "col_tile_kernel", dict(R="float", N=4096, NR=5, LISTED=0)),     # 1032 SLM rows from row 1532: five slots of 256
     (1024, np.float64, "col_fused_kernel", dict(R="double", N=1024, RULE=0)),
     (4096, np.float64, "col_fused_kernel", dict(R="double", N=4096, RULE=0)),      # the tile-resident kernel is fp32 only
@@ -158,7 +158,9 @@ def test_batches_carry_the_batch_flag_and_keep_one_row_workgroups():
     hb.engine.set_option(L.OPT_SPARSE_COLUMNS, 0)
     hb.optimize("WGS-Leonardo", 3)
     d = dispatch_of(hb)
-    assert d.count("col_tile_kernel", flags=["batch"], RULE=1, LISTED=0) == 2, d
+    # a batch runs the half-width tile kernel (three workgroups per CU, the halves of a tile on one XCD) on its plain passes
+    assert d.count("col_tile2_kernel", flags=["batch", "xmap"], N=4096, NR=5, RULE=1) == 2 and d.count("col_tile2_kernel", RULE=2) == 1, d
+    assert d.count("col_tile_kernel") == 0, d
     assert d.count("row_kernel", flags=["batch"], MODE=2, NS=8, PREF=False) == 2 and d.count("row_kernel", PREF=True) == 0, d
     hb.close()
 

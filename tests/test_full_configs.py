@@ -247,6 +247,11 @@ def test_cfg3_batch_of_eight_matches_single_engines(path):
         hb.engine.set_option(opt, val)
     try:
         hb.optimize("WGS-Leonardo", maxiter=iters)
+        d = dispatch_of(hb)
+        if path == "dense":      # the batch-shaped column kernel: half-width tiles, three workgroups per CU (96 per hologram)
+            assert d.count("col_tile2_kernel", flags=["batch", "xmap"], N=4096, NR=5) == iters and d.count("col_tile_kernel") == 0, d
+        else:
+            assert d.count("col_fused_kernel", flags=["batch", "list"]) == iters and d.count("col_tile2_kernel") == 0, d
         got = hb.phases()
         w = hb.engine.get(L.WEIGHTS)
     finally:
