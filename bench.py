@@ -82,41 +82,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12          # bytes/s, MI355X_MICROARCH.md
-MFMA_F32_PEAK = 157.3e12   # flop/s, dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-MALL_BYTES = 256 * 2 ** 20
-
-SPOT_WORKLOADS = {
-    # name: (padded shape, slm shape, spot grid, pitch)
-    "cfg2": ((4096, 4096), (1152, 1920), (32, 32), (64, 64)),
-    "cfg3": ((4096, 4096), (1152, 1920), (32, 32), (64, 64)),
-    "small": ((1024, 1024), (288, 480), (16, 16), (32, 32)),
-    "hd": ((2048, 2048), (1080, 1920), (16, 16), (64, 64)),        # a 1920x1080 SLM at padding_order = 1
-    "cfg5pad": ((8192, 8192), (1152, 1920), (32, 32), (128, 128)),
-}
-IMAGE_WORKLOADS = {"cfg1": ((512, 512), (512, 512)), "cfg2dense": ((4096, 4096), (1152, 1920)), "cfg5mraf": ((8192, 8192), (1152, 1920))}
-REFBENCH_METHODS = ("GS", "WGS-Leonardo", "WGS-Kim", "WGS-Nogrette")      # test_algorithms.py:121
-COMPRESSED_WORKLOADS = {"cfg4": 2, "cfg4d3": 3, "cfg4zern": 5}
-# cfg4zern: a basis with a cross term (ANSI 2, 1, 4, 3, 5: tilts, focus, both astigmatisms) does not factor into x and y
-# parts, so it runs the direct kernels (exp(i phi) regenerated per pixel and spot, VALU / transcendental bound) -- the
-# shape of the CompressedSpotHologram that wavefront_calibrate_zernike re-optimises (cameraslms.py:1840-1930)
-ZERN_BASIS = [2, 1, 4, 3, 5]
-VALU_F32_PEAK = 157.3e12   # flop/s, packed fp32 vector peak (MI355X_MICROARCH.md)
-# cfg 4's DFT-grid companion: the same number of spots at distinct pixels of an 8192^2 grid, inside the
-# centred 3360^2 box that |k| <= 0.02 rad spans there (pitch 8 um, 0.78 um), WGS-Kim
-VECTOR_WORKLOADS = {"cfg4grid": ((8192, 8192), (1152, 1920), 3360)}
-ALL_WORKLOADS = sorted(list(SPOT_WORKLOADS) + list(IMAGE_WORKLOADS) + list(COMPRESSED_WORKLOADS) + list(VECTOR_WORKLOADS) + ["refbench"])
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from benchlib.byte_models import grid_bytes_models  # noqa: E402
+from benchlib.launcher import _gather_ints, apply_opts, self_launch as _self_launch  # noqa: E402
+from benchlib.pmc import pmc_traffic as _pmc_traffic  # noqa: E402
+from benchlib.workloads import (ALL_WORKLOADS, COMPRESSED_WORKLOADS, HBM_PEAK, IMAGE_WORKLOADS, MALL_BYTES, MFMA_F32_PEAK,  # noqa: E402
+                                REFBENCH_METHODS, SPOT_WORKLOADS, VALU_F32_PEAK, VECTOR_WORKLOADS, ZERN_BASIS, grid_spots)
 
 
-def grid_spots(shape, box, n):
-    """``n`` distinct pixels (x, y) inside the centred ``box`` x ``box`` window of ``shape``, from the counter PRNG."""
-    from slmsuite_amd import synth
-    lin = np.unique((synth.uniform01(4, (4 * n,), stream=7) * box * box).astype(np.int64))
-    if lin.size < n:
-        raise SystemExit(f"only {lin.size} distinct positions for {n} spots")
-    lin = np.sort(lin[np.argsort(synth.uniform01(5, (lin.size,), stream=8), kind="stable")[:n]])
-    lo_y, lo_x = (shape[0] - box) // 2, (shape[1] - box) // 2
-    return np.stack([lin % box + lo_x, lin // box + lo_y]).astype(np.float64)
+def pmc_traffic(args, kernel_substrings):
+    return _pmc_traffic(args, kernel_substrings, __file__)
+
+
+def self_launch(args):
+    return _self_launch(args, __file__)
 
 
 def parse():
@@ -263,73 +242,12 @@ class GridProblem:
     def close(self):
         self.hb.close()
 
-    # ---- byte models ----
+    # ---- byte models: tools/benchlib/byte_models.py, unit-tested on CPU ----
     def bytes_models(self):
-        Ph, Pw = self.shape
-        Sh, Sw = self.slm
-        P, S = Ph * Pw, Sh * Sw
-        r = 4 if self.args.dtype == "f32" else 8
-        c = 2 * r
-        B = -(-self.args.batch // self.args.streams)      # holograms per launch (one stream group)
-        m = self.args.method
-        wgs = m != "GS"
-        gh = Sh * Pw * c                              # half-transformed field: SLM rows only
-        # weights are written back per lane (its 16 values of a column, 64 contiguous bytes) where one of them changed:
-        # every lane of a column that holds a finite non-zero target, nothing elsewhere
-        w_write = (P * r) if not self.sparse_target else self.n_targets * 16 * r
-        if getattr(self, "signal_cols", None):
-            w_write = self.signal_cols * Ph * r
-        kim = m == "WGS-Kim"                          # after the fixing iteration the stored phase_ff is read back
-        col = 2 * gh + P * r + (P * r if (wgs or self.mraf) else 0) + (w_write if wgs else 0) + (P * r if kim else 0)
-        passes = 1
-        other = 0                                     # launches of an iteration besides the column pass(es) and the row launch
-        row = 2 * gh                                  # MODE 2 (between fused iterations): H read, G written
-        mraf_note = ""
-        if self.mraf and wgs:
-            Tc = Ph // 16
-            r0 = (Ph - Sh) // 2
-            slots = (r0 + Sh - 1) // Tc - r0 // Tc + 1
-            if self.args.dtype == "f32" and Ph >= 4096 and Pw >= 4096 and slots <= 6 and os.environ.get("HGS_MRAF_SPLIT", "1") != "0":
-                # one column pass (col_tile_kernel RULE 3): reads GH, w, t; writes w and the two parts of the rebuilt field
-                # (signal part un-normalised, noise part); the row kernel (SPLIT) reads both
-                gh2 = gh * self.noise_cols // Pw if os.environ.get("HGS_GH2_MASK", "1") != "0" else gh
-                col = gh + 2 * P * r + w_write + gh + gh2
-                row = 2 * gh + gh2
-                mraf_note = ("; MRAF with a weight update in ONE column pass: the signal and the noise part of the rebuilt field "
-                             f"are written separately (GH + the noise part in the {self.noise_cols} columns that hold a NaN target) "
-                             "and joined by the row kernel")
-            elif (self.args.dtype == "f64" and Pw >= 4096 and os.environ.get("HGS_MRAF_SPLIT", "1") != "0"
-                  and os.environ.get("HGS_MRAF_SPLIT64", "1") != "0"):
-                # float64: one pass of the per-column kernel (reads GH, w, t; writes w, the signal part back into GH and the
-                # noise part as farfield values at the NaN-target pixels), then col_kernel<LOAD | INV> over the columns that
-                # hold noise (reads their farfield columns, writes their rows of the noise part); the row kernel reads both
-                gh2 = gh * self.noise_cols // Pw
-                # (float64 leaves changed weights four pixels = 32 bytes at a time: the image pixels, not whole columns)
-                w_write = self.n_targets * r
-                col = gh + 2 * P * r + w_write + gh + self.noise_pixels * c
-                other = self.noise_cols * Ph * c + gh2       # the inverse-only launch (profile slot col_inv)
-                row = 2 * gh + gh2
-                mraf_note = ("; float64 MRAF with a weight update in ONE pass of the per-column kernel: the noise part leaves as farfield "
-                             f"values ({self.noise_pixels} NaN-target pixels) and an inverse-only launch over the {self.noise_cols} columns "
-                             "that hold them writes it next to GH; joined by the row kernel")
-            else:
-                # two column passes: forward + weight rule (reads GH, w, t; writes w), then forward + rebuild + inverse
-                col = (gh + 2 * P * r + w_write) + (2 * gh + 2 * P * r)
-                passes = 2
-                mraf_note = "; MRAF with a weight update = two column passes"
-        canon_col = (4 * P * c + (3 if wgs else 1) * P * r)
-        canon_iter = ((15 if wgs else 13) * P + 2 * S) * r
-        ws = gh + P * r * (2 if (wgs or self.mraf) else 1)           # GH + weights (+ target)
-        return dict(col=col * B, col_passes=passes, row=row * B, other=other * B, canon_col=canon_col * B, canon_iter=canon_iter * B,
-                    working_set=ws * B,
-                    col_model=f"GH tile read + write (2 x Sh*Pw*{c} B) + weights read (P*{r}) + "
-                              f"{'target read (P*%d) + ' % r if (wgs or self.mraf) else ''}"
-                              f"{'phase_ff read (P*%d, fixed phase) + ' % r if kim else ''}"
-                              f"weight writes where a weight changed ({w_write} B)"
-                              + mraf_note,
-                    row_model=f"H read + G written, SLM rows only (2 x Sh*Pw*{c} B); the phase itself is only "
-                              "written by the last row launch of a call"
-                              + ("; single-pass MRAF: the noise part is read as well, in the columns where it exists" if mraf_note and passes == 1 else ""))
+        return grid_bytes_models(self.shape, self.slm, self.args.dtype, self.args.batch, self.args.streams, self.args.method,
+                                 sparse_target=self.sparse_target, n_targets=self.n_targets, mraf=self.mraf,
+                                 signal_cols=getattr(self, "signal_cols", None), noise_cols=getattr(self, "noise_cols", None),
+                                 noise_pixels=getattr(self, "noise_pixels", None))
 
 
 class CompressedProblem:
@@ -543,100 +461,6 @@ def cpu_baseline(args):
 # ---------------------------------------------------------------------------------------------------
 # PMC traffic, measured in this run: child passes of this script under rocprofv3
 # ---------------------------------------------------------------------------------------------------
-def pmc_traffic(args, kernel_substrings):
-    """
-    Mean FETCH_SIZE / WRITE_SIZE per launch of the kernels whose name contains one of ``kernel_substrings``
-    (dict label -> substring).  Two child runs (the two counters do not fit one pass).  Returns
-    ({label: {"fetch": bytes, "write": bytes, "launches": n}}, note).
-    """
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--batch", str(args.batch),
-             "--method", args.method, "--dtype", args.dtype, "--steps", "12", "--warmup", "3", "--spots", str(args.spots),
-             "--sparse-columns", str(args.sparse_columns)]
-    for o in args.opt:
-        child += ["--opt", o]
-    env = dict(os.environ)
-    env["TMPDIR"] = "/tmp"
-    out = {k: {"fetch": None, "write": None, "launches": 0} for k in kernel_substrings}
-    names = {}
-    for counter, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-        d = tempfile.mkdtemp(prefix="hgs_pmc_", dir="/tmp")
-        try:
-            p = subprocess.run([exe, "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child,
-                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if p.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): " + p.stdout.decode(errors="replace")[-300:]
-            acc = {k: [0.0, 0] for k in kernel_substrings}
-            for path in files:
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if row.get("Counter_Name") != counter:
-                            continue
-                        kn = row.get("Kernel_Name", "")
-                        for label, sub in kernel_substrings.items():
-                            if sub in kn:
-                                acc[label][0] += float(row.get("Counter_Value", 0) or 0)
-                                acc[label][1] += 1
-                                names[label] = kn
-            for label, (tot, n) in acc.items():
-                if n:
-                    # rocprofv3 reports KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950 (x 2, guide)
-                    out[label][key] = tot / n * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
-                    out[label]["launches"] = n
-        except subprocess.TimeoutExpired:
-            return None, f"rocprofv3 --pmc {counter} timed out"
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    for label in out:
-        out[label]["kernel_name"] = names.get(label)
-    return out, ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this run (12 steps each); FETCH_SIZE x 2 "
-                 "(gfx950 half-count), WRITE_SIZE as reported; the fabric counters include Infinity-Cache hits")
-
-
-def _gather_ints(dist, torch, dev, value, world, group=None):
-    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
-    out = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    return [int(o.item()) for o in out]
-
-
-def apply_opts(engine, opts):
-    from slmsuite_amd import _lib as L
-    for o in opts:
-        name, val = o.split("=")
-        engine.set_option(getattr(L, "OPT_" + name.upper()), int(val))
-
-
-def self_launch(args):
-    """
-    ``python bench.py --gpus N`` (N > 1) outside a launcher: re-run this very command line under
-    ``python -m torch.distributed.run`` with one rank per GPU (the form the driver uses itself) and hand its exit code
-    back.  Fails loudly -- non-zero, nothing printed on stdout -- when the box has fewer than N devices.
-    """
-    import socket
-    import torch
-    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if n_dev < 1:
-        print(f"bench.py --gpus {args.gpus}: no GPU visible (the engine has no CPU fallback)", file=sys.stderr)
-        return 2
-    if n_dev < args.gpus and not args.share_devices:
-        print(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible; refusing to report a {args.gpus}-GPU figure "
-              f"from fewer devices", file=sys.stderr)
-        return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
-
-
 def main():
     args = parse()
     launched = "WORLD_SIZE" in os.environ
@@ -864,6 +688,13 @@ def main():
             roof = {"bound": "hbm", "kernel": kernel_ran or col_kernel_name(args, prob),
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                     "traffic": traffic, "traffic_note": tnote,
+                    # scalars of the nested objects below (a parser that keeps only flat fields still carries them):
+                    # the whole iteration on moved bytes -- the figure north_star's 50 % is about --, the row launch, and
+                    # SURVEY's canonical (un-pruned) count over the same time (a throughput equivalent, may exceed 1)
+                    "frac_iteration": (bm["col"] + bm["row"] + bm.get("other", 0)) * args.streams * iter_s / HBM_PEAK,
+                    "row_frac": bm["row"] / row_dur / HBM_PEAK,
+                    "row_launch_us": row_dur * 1e6,
+                    "canonical_equivalent_frac": bm["canon_iter"] * args.streams * iter_s / HBM_PEAK,
                     "traffic_over_model": None if traffic is None else traffic / bm["col"],
                     "frac_on_traffic": None if traffic is None else traffic / dur / HBM_PEAK,
                     "bytes_per_launch": bm["col"], "bytes_model": bm["col_model"],

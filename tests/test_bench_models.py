@@ -1,0 +1,85 @@
+"""
+The byte models bench.py computes ``roofline.achieved`` from (tools/benchlib/byte_models.py), on CPU: against the figures of
+the round-4 bench lines (profiles/r04/configs.jsonl), against the traffic the PMC counters measured for the same launches
+there, and against SURVEY 8(d)'s canonical counts.
+"""
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from benchlib import workloads as W                                    # noqa: E402
+from benchlib.byte_models import canonical_bytes, grid_bytes_models, tile_slots   # noqa: E402
+
+
+def _lines():
+    out = []
+    for line in open(os.path.join(ROOT, "profiles", "r04", "configs.jsonl")):
+        d = json.loads(line)
+        text = d["config"]["workload"]
+        key = text.split(":")[0]
+        r = d["roofline"]
+        if r.get("bytes_per_launch") is None or r.get("bound") != "hbm":
+            continue
+        method = re.search(r", (GS|WGS-[A-Za-z]+), fp", text).group(1)
+        out.append((key, method, d["dtype"], d["config"]["holograms_per_gpu"], d["config"]["stream_groups_per_gpu"], r))
+    return out
+
+
+def _model(key, method, dtype, batch, streams):
+    if key in W.SPOT_WORKLOADS:
+        shape, slm, grid, _ = W.SPOT_WORKLOADS[key]
+        return grid_bytes_models(shape, slm, dtype, batch, streams, method, True, grid[0] * grid[1], False, env={})
+    if key in W.VECTOR_WORKLOADS:
+        shape, slm, _ = W.VECTOR_WORKLOADS[key]
+        return grid_bytes_models(shape, slm, dtype, batch, streams, method, True, 10000, False, env={})
+    shape, slm = W.IMAGE_WORKLOADS[key]
+    if key == "cfg5mraf":
+        return grid_bytes_models(shape, slm, dtype, batch, streams, method, False, 2048 * 2048, True, signal_cols=2048, noise_cols=3072,
+                                 noise_pixels=3072 * 3072 - 2048 * 2048, env={})
+    return grid_bytes_models(shape, slm, dtype, batch, streams, method, False, shape[0] * shape[1], False, env={})
+
+
+@pytest.mark.parametrize("line", _lines(), ids=[f"{l[0]}-{l[1]}-{l[2]}-b{l[3]}s{l[4]}" for l in _lines()])
+def test_models_reproduce_the_recorded_lines_and_the_measured_traffic(line):
+    key, method, dtype, batch, streams, roof = line
+    m = _model(key, method, dtype, batch, streams)
+    assert m["col"] == roof["bytes_per_launch"], (m["col"], roof["bytes_per_launch"])
+    assert m["row"] == roof["row_kernel"]["bytes_per_launch"]
+    # what the counters saw (FETCH_SIZE x 2 + WRITE_SIZE, child passes of the same run): the model is what is moved.  fp64
+    # access widths are uncalibrated (MI355X_MICROARCH.md) and the 5 MB state of cfg 1 is partial lines: wider bands there
+    if roof.get("traffic"):
+        band = 0.10 if dtype == "f64" or key == "cfg1" else 0.04
+        assert abs(roof["traffic"] / m["col"] - 1) < band, roof["traffic"] / m["col"]
+    tr_row = roof["row_kernel"].get("traffic")
+    if tr_row:
+        assert abs(tr_row / m["row"] - 1) < (0.25 if key == "cfg3" else 0.10), tr_row / m["row"]
+
+
+def test_canonical_counts_are_surveys():
+    P, S = 4096 * 4096, 1152 * 1920
+    assert canonical_bytes(P, S, 4, True) == 1_024_327_680              # SURVEY 8(d), cfg 2 / 3 (WGS, f32)
+    assert canonical_bytes(P, S, 4, True, kim_fixed=True) == 1_091_436_544
+    assert canonical_bytes(8192 * 8192, S, 4, True) == 4_044_226_560
+    assert canonical_bytes(8192 * 8192, S, 8, True) == 8_088_453_120
+    assert canonical_bytes(512 * 512, 512 * 512, 4, False) == 15_728_640
+    m = grid_bytes_models((4096, 4096), (1152, 1920), "f32", 1, 1, "WGS-Leonardo", True, 1024, False, env={})
+    assert m["canon_iter"] == 1_024_327_680 and m["col"] + m["row"] == 285_278_208      # 285.3 MB moved per iteration
+    # the headline's own split: GH tile read + written, weights, target, changed weights
+    gh = 1152 * 4096 * 8
+    assert m["col"] == 2 * gh + 2 * P * 4 + 1024 * 16 * 4 and m["row"] == 2 * gh
+
+
+def test_slot_counts_of_the_shifted_tile_kernel():
+    assert tile_slots(4096, 1152) == 5 and tile_slots(8192, 1152) == 3 and tile_slots(2048, 1080) == 9
+    assert tile_slots(4096, 1024) == 4 and tile_slots(4096, 1500) == 6 and tile_slots(4096, 1800) == 8
+    for Ph in (2048, 4096, 8192):
+        for Sh in range(16, Ph, 37):
+            T, r0 = Ph // 16, (Ph - Sh) // 2
+            shift = r0 // 16 * 16
+            n = tile_slots(Ph, Sh)
+            assert n * T >= r0 - shift + Sh > (n - 1) * T          # the rows fit n slots and need all of them
