@@ -55,7 +55,7 @@ inline void dispatch_note(const DispatchSite* s, unsigned flags = 0) {
 #define HGS_FAMILY(tag, kname, plist) struct tag { static constexpr const char* name = kname; static constexpr const char* params = plist; }
 HGS_FAMILY(KRow, "row_kernel", "R,N,MODE,NS,PREF,SPLIT");
 HGS_FAMILY(KCol, "col_kernel", "R,N,MODE");
-HGS_FAMILY(KFused, "col_fused_kernel", "R,N,PHASE,STATS,RULE");
+HGS_FAMILY(KFused, "col_fused_kernel", "R,N,PHASE,STATS,RULE,NRS");
 HGS_FAMILY(KTile, "col_tile_kernel", "R,N,PHASE,NR,STATS,EXTRAS,RULE,LISTED");
 HGS_FAMILY(KTile2, "col_tile2_kernel", "R,N,PHASE,NR,RULE");
 HGS_FAMILY(KBlue, "bluestein_lines", "R,M");

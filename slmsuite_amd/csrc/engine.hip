@@ -233,6 +233,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_tile2 = 1;                     // developer A/B (HGS_TILE2=0 at create): half-width tile kernel off
     int env_tile2_blocks = 0;              // ... its workgroups per launch over the batch (HGS_TILE2_BLOCKS; 0 = 3 x / 2 x #CU)
     int opt_keep_g = 1;                    // developer A/B (HGS_KEEP_G=0 at create)
+    int opt_fused_shift = 1;               // developer A/B (HGS_FUSED_SHIFT=0 at create): float64 per-column kernel unshifted (16 slots)
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
     int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
@@ -399,6 +400,7 @@ template <typename R> struct Engine : EngineBase {
         const bool trace_init = env_int("HGS_TRACE_INIT", 0) != 0;
         opt_tile_rule = env_int("HGS_TILE_RULE", 1);
         opt_tile_nr4 = env_int("HGS_TILE_NR4", 1);
+        opt_fused_shift = env_int("HGS_FUSED_SHIFT", 1);
         opt_keep_g = env_int("HGS_KEEP_G", 1);
         opt_tile2 = env_int("HGS_TILE2", 1);
         env_tile2_blocks = env_int("HGS_TILE2_BLOCKS", 0);
@@ -434,9 +436,11 @@ template <typename R> struct Engine : EngineBase {
         row_xcd = (grp > 1 && row_blocks >= 8 * grp && env_int("HGS_ROW_XCD", 1)) ? 1 : 0;
         if (row_xcd) row_blocks = (row_blocks + 8 * grp - 1) / (8 * grp) * (8 * grp);
         // prefetching row kernel (one hologram; a batch keeps the one-row workgroups): 2 workgroups per CU
+        // (round 5: a batch walks too where every workgroup gets at least four rows -- 8 x 1152 rows over 2 x #CU workgroups
+        //  are 18 rows each, no partial round at all; HGS_ROW_PREF_BATCH=0 keeps its one-row workgroups)
         row_blocks_pref = 0;
-        if (sizeof(R) == 4 && g.Pw == 4096 && fpw == 1 && B == 1 && row_xcd) {
-            const int want = env_int("HGS_ROW_PREF_BLOCKS", 2 * n_cu);
+        if (sizeof(R) == 4 && g.Pw == 4096 && fpw == 1 && row_xcd && (B == 1 || env_int("HGS_ROW_PREF_BATCH", 0))) {
+            const int want = env_int("HGS_ROW_PREF_BLOCKS", 2 * n_cu) / B;
             row_blocks_pref = std::max(8 * grp, want / (8 * grp) * (8 * grp));
         }
         const int tiles = g.Pw / 4;
@@ -1404,6 +1408,7 @@ template <typename R> struct Engine : EngineBase {
         have_pff = false;
         have_prev = false;
         farfield_valid = false;
+        gh_state = -1;          // (a kept G is the un-extracted phasor of the last body: a reset hologram starts from its phase, like a new one)
         return reset_weights();
     }
     // n values at listed pixels, `0` everywhere else (SpotHologram targets: n_spots numbers instead of P)
@@ -1504,7 +1509,7 @@ template <typename R> struct Engine : EngineBase {
             //  walk turns into a third row for a quarter to a half of the workgroups -- 1152 rows 28.1 -> 26.3 us, 1280 rows
             //  29.1 -> 27.5 us, 1040 / 1088 / 1200 / 1248 rows 1.0 - 1.7 us ahead; level at 1024 rows, behind at 1312 and 1536)
             if (sizeof(R) == 4 && g.Pw == 4096 && mode == 2 && opt_row_pref && row_blocks_pref > 0 && !a.load_mask && !a.store_mask &&
-                g.Sh > 2 * row_blocks_pref && 2 * g.Sh <= 5 * row_blocks_pref) {
+                (B == 1 ? (g.Sh > 2 * row_blocks_pref && 2 * g.Sh <= 5 * row_blocks_pref) : g.Sh >= 4 * row_blocks_pref)) {
                 a.prefetch = 1;
                 a.n_row_blocks = blocks = row_blocks_pref;
             }
@@ -1649,6 +1654,11 @@ template <typename R> struct Engine : EngineBase {
         a.g = g; a.gh = gh; a.ff = ff; a.amp_ff = aff; a.pff = pff; a.w = w; a.t = t; a.wscale = wscale;
         a.wpartial = wpartial; a.fpartial = fpartial; a.tw = tw_col; a.scale = (R)(1.0 / std::sqrt((double)g.Ph));
         a.col_xmap = col_xmap;
+        // float64, 4096 / 8192 rows: col_fused_kernel in its shifted form (the SLM rows in the first fnr register slots)
+        if (sizeof(R) == 8 && g.Ph >= 4096 && opt_fused_shift) {
+            const int sh = (g.r0 / 16) * 16, Tc = g.Ph / 16, nr = (g.r0 - sh + g.Sh + Tc - 1) / Tc;
+            if (nr <= 6) { a.fshift = sh; a.fnr = nr; }
+        }
         return a;
     }
     int reduce(const double* partial, int n, double* out) {

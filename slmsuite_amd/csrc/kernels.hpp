@@ -59,6 +59,9 @@
 #ifndef HGS_F64_WT_PREFETCH
 #define HGS_F64_WT_PREFETCH 0   // 1: float64 8192-point fused kernel, one word of each weight / target line requested ahead of the forward
 #endif                          //    transform (L2 prefetch): 737 vs 713 us -- slower
+#ifndef HGS_F64_WT_EARLY
+#define HGS_F64_WT_EARLY 0      // float64 8192-point fused kernel, shifted form: weights / targets requested ahead of the (pruned) forward transform
+#endif
 #ifndef HGS_SPLIT_L2_PREFETCH
 #define HGS_SPLIT_L2_PREFETCH 0 // 1: single-pass MRAF tile kernel, the next tile's rows requested ahead of the first transform: 332.6 vs 330.4 us
 #endif
@@ -970,6 +973,9 @@ template <typename R> struct ColArgs {
     const int* col_list;   // [batch][Pw] compacted active columns
     const int* n_active;   // [batch]
     // fused kernels only: statistics of this iteration (hgs_iterate_stats)
+    int fnr;               // col_fused_kernel: register slots the shifted SLM rows occupy (0 = the unshifted kernel, NRS = 16)
+    int fshift;            // col_fused_kernel<..., NRS < 16> (float64, >= 4096 rows): circular shift of the transform input, a
+                           // multiple of 16 rows (shift theorem, as in col_tile_kernel): the SLM rows occupy slots 0 .. NRS - 1
     int do_stats;          // bit 0: accumulate the "computational" statistics; bit 1: store amp_ff
     double* spartial;      // [batch][gridDim.x][STAT_WAVES][STAT_N]
     const double* tsum;    // [batch] sum T^2
@@ -1120,9 +1126,16 @@ __global__ __launch_bounds__(ColCfg<N>::WG, (sizeof(R) == 8 ? 2 : N >= 8192 ? HG
 // RULE (as in col_tile_kernel): 0 = method, update switch, MRAF / Nogrette-sum / forward-only flags read from CParams;
 // 1 = plain WGS-Leonardo / WGS-Kim update compiled in; 2 = plain pass without a weight update.  "Plain" = none of the
 // extras.  The latency-bound launches (column lists, small grids: one wave per SIMD) pay every uniform branch in full.
-template <typename R, int N, int PHASE, bool STATS = false, int RULE = 0>
+// NRS < 16 (round 5; float64 at 4096 / 8192 rows, where every register and every LDS byte counts twice): the transform
+// input is shifted by a.fshift rows so that the SLM rows occupy the first NRS register slots (col_tile_kernel's shift
+// theorem form: a per-lane unit factor on the frequency side) -- NRS loads and stores per lane instead of 16 range-checked
+// ones, the leading butterfly layer of the forward transform and the trailing one of the inverse pruned to those slots,
+// at 8192 points the radix-2 step a copy and a twiddle and its pair exchange 2 NRS instead of 16 values per lane.
+template <typename R, int N, int PHASE, bool STATS = false, int RULE = 0, int NRS = 16>
 __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel(ColArgs<R> a) {
     using M = Math<R>;
+    constexpr bool SHIFTED = NRS < 16;
+    static_assert(!SHIFTED || N >= 4096, "col_fused_kernel: the shifted form needs the row-local transforms");
     constexpr int T = ColCfg<N>::T, CPAR = ColCfg<N>::CPAR, PASSES = ColCfg<N>::PASSES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo g = a.g;
@@ -1151,7 +1164,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const size_t P = (size_t)g.Ph * g.Pw;
     const R wsc = a.wscale[b];
     const R sc = sgn * a.scale;
-    const int r_lane = js - g.r0;  // SLM row of element m is r_lane + m*T
+    const int shift = SHIFTED ? a.fshift : 0;
+    const int r_lane = js + shift - g.r0;  // SLM row of element m is r_lane + m*T
+    // SHIFTED: shift-theorem factor of this lane (unit modulus) with the (-1)^k sign folded in
+    Cx<R> omu = mk<R>(sgn, 0);
+    if constexpr (SHIFTED) omu = a.tw[(j * shift) & (N - 1)] * sgn;
     const int ntiles = g.Pw / 4;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     // listed mode: pass q of this workgroup handles the CPAR list entries of group blockIdx.x + q*gridDim.x;
@@ -1239,7 +1256,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         col_of(q, ct, c4);
         if constexpr (GBUF) {
             const Buf bg = g_buf(q, ct, c4);
-            static_for<0, 16>([&](auto m_) { constexpr int m = m_; dst[m] = bg.template ld<Cx<R>>(g_voff + (unsigned)m * g_vstep, 0u); });
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = m_;
+                if constexpr (m < NRS) dst[m] = bg.template ld<Cx<R>>(g_voff + (unsigned)m * g_vstep, 0u); else dst[m] = mk<R>(0, 0);
+            });
             return;
         }
         const Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
@@ -1247,7 +1267,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             constexpr int m = m_;
             const int r = r_lane + m * T;
             dst[m] = mk<R>(0, 0);
-            if (r >= 0 && r < g.Sh && col_valid(q)) dst[m] = gh[(unsigned)r * 4u];
+            if constexpr (m < NRS) { if (r >= 0 && r < g.Sh && col_valid(q)) dst[m] = gh[(unsigned)r * 4u]; }
         });
     };
 
@@ -1266,10 +1286,10 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         HGS_T(fft.tr_n, 2);
-        static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
+        static_for<0, NRS>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
         // fp64: this column's weights / targets land under its forward transform (8192: after it -- the 64 registers
         // would not fit next to the transform's own)
-        if constexpr (LEAN && N < 8192) issue_wt(q);
+        if constexpr (LEAN && (N < 8192 || (SHIFTED && HGS_F64_WT_EARLY))) issue_wt(q);
         // 8192 points: the 64 registers of this column's weights / targets do not fit next to the forward transform, so they
         // are requested after it.  (Experiment, off: one word of each of the lane's two 128-byte lines requested BEFORE the
         // transform, so that the real loads are L2 hits -- the launch got 3 % slower, HGS_F64_WT_PREFETCH.)
@@ -1280,7 +1300,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if (do_upd || STATS || x_mraf) pf_t = reinterpret_cast<const int*>(a.t + cb + lane_pos<T>(j, 0))[0];
             }
         }
-        fft.fwd(v, lds, j);
+        if constexpr (SHIFTED) fft.template fwd_lead<NRS>(v, lds, j);       // slots NRS.. are zero (rows outside the SLM)
+        else fft.fwd(v, lds, j);
         if constexpr (LEAN && N >= 8192 && HGS_F64_WT_PREFETCH) asm volatile("" :: "v"(pf_w), "v"(pf_t));
         HGS_T(fft.tr_n, 3);
         // fp64: the 16 transformed values of a lane (64 VGPRs) wait in the idle LDS image while the constraint runs --
@@ -1290,7 +1311,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         Cx<R>* park = lds + j;
         if constexpr (LEAN) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; park[m * T] = v[m]; });
-            if constexpr (N >= 8192) issue_wt(q);
+            if constexpr (N >= 8192 && !(SHIFTED && HGS_F64_WT_EARLY)) issue_wt(q);
         }
 #if HGS_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1314,7 +1335,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if (x_nog && vcol) acc_w += (R)1;      // T == 0 -> fc = 1 (:1841)
                 return;
             }
-            const Cx<R> F = vm * sc;
+            Cx<R> F;
+            if constexpr (SHIFTED) F = cmul(vm, omu) * a.scale; else F = vm * sc;
             const R p2 = F.x * F.x + F.y * F.y;
             if (x_nog) {                                    // Nogrette: sum of fc = feedback / target over all pixels
                 if (vcol) acc_w += nogrette_fc<R>(M::sqrt(p2) * cp.inv_fnorm, tr[m]);
@@ -1361,7 +1383,8 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 }
                 if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
-            vm = mk<R>(wv * co * sgn, wv * si * sgn);
+            // inverse-transform input = (-1)^k * ff (SHIFTED: times the conjugate shift factor)
+            if constexpr (SHIFTED) vm = cmulc(mk<R>(co, si), omu) * wv; else vm = mk<R>(wv * co * sgn, wv * si * sgn);
             if (x_mraf) {                                   // mixed-region amplitude freedom (:1606-1653)
                 const R t = tr[m];
                 if (is_nan(t)) {
@@ -1369,8 +1392,12 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                         if (vcol) a.ffb[cb + idx] = cp.has_mraf_factor ? F * cp.mraf_factor : F;
                         vm = mk<R>(0, 0);
                     } else {
-                        const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
-                        vm = F * mf;
+                        if constexpr (SHIFTED) {
+                            vm = cmulc(cp.has_mraf_factor ? F * cp.mraf_factor : F, omu);
+                        } else {
+                            const R mf = cp.has_mraf_factor ? cp.mraf_factor * sgn : sgn;
+                            vm = F * mf;
+                        }
                     }
                 } else if (t == (R)0) {
                     vm = mk<R>(0, 0);
@@ -1415,13 +1442,14 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             __syncthreads();
         }
         if (!x_wonly) {
-            fft.inv_after_fwd(v, lds, j);
+            if constexpr (SHIFTED) fft.template inv_after_fwd_trail<NRS>(v, lds, j);     // slots NRS.. are not stored
+            else fft.inv_after_fwd(v, lds, j);
             if constexpr (GBUF) {
                 const Buf bg = g_buf(q, ct, c4);
-                static_for<0, 16>([&](auto m_) { constexpr int m = m_; bg.template st<Cx<R>>(v[m] * scs, g_voff + (unsigned)m * g_vstep, 0u); });
+                static_for<0, NRS>([&](auto m_) { constexpr int m = m_; bg.template st<Cx<R>>(v[m] * scs, g_voff + (unsigned)m * g_vstep, 0u); });
             } else {
                 Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + c4;
-                static_for<0, 16>([&](auto m_) {
+                static_for<0, NRS>([&](auto m_) {
                     constexpr int m = m_;
                     const int r = r_lane + m * T;
                     if (r >= 0 && r < g.Sh && vcol) gh[(unsigned)r * 4u] = v[m] * scs;

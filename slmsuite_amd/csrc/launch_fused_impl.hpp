@@ -29,22 +29,38 @@ constexpr bool kStats = HGS_STATS_TU != 0;
 constexpr bool kExtras = HGS_TILE_EXTRAS_TU != 0;
 
 #if !HGS_TILE_EXTRAS_TU
-template <typename R, int N, int PHASE>
+template <typename R, int N, int PHASE, int NRS = 16>
 static int launch_fused_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
     constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
-    auto k = col_fused_kernel<R, N, PHASE, kStats>;
+    auto k = col_fused_kernel<R, N, PHASE, kStats, 0, NRS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dispatch_note(dispatch_site<KFused, R, N, PHASE, kStats, 0>(), col_flags(grid, a));
+    dispatch_note(dispatch_site<KFused, R, N, PHASE, kStats, 0, NRS>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(ColCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }
 
 template <typename R, int N>
 static int launch_fused_n(int phase, dim3 grid, hipStream_t s, const ColArgs<R>& a) {
+    // float64 at 4096 / 8192 rows: the shifted form with the transforms pruned to the slots the SLM rows occupy (a.fnr)
+    if constexpr (sizeof(R) == 8 && N >= 4096 && !kStats) {
+        if (a.fnr > 0 && a.fnr <= 4) {
+            switch (phase) {
+                case 0: return launch_fused_one<R, N, 0, 4>(grid, s, a);
+                case 1: return launch_fused_one<R, N, 1, 4>(grid, s, a);
+                case 2: return launch_fused_one<R, N, 2, 4>(grid, s, a);
+            }
+        } else if (a.fnr > 0 && a.fnr <= 6) {
+            switch (phase) {
+                case 0: return launch_fused_one<R, N, 0, 6>(grid, s, a);
+                case 1: return launch_fused_one<R, N, 1, 6>(grid, s, a);
+                case 2: return launch_fused_one<R, N, 2, 6>(grid, s, a);
+            }
+        }
+    }
     switch (phase) {
         case 0: return launch_fused_one<R, N, 0>(grid, s, a);
         case 1: return launch_fused_one<R, N, 1>(grid, s, a);

@@ -12,7 +12,7 @@ static int launch_fused_rule1_one(dim3 grid, hipStream_t s, const ColArgs<float>
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dispatch_note(dispatch_site<KFused, float, N, PHASE, false, 1>(), col_flags(grid, a));
+    dispatch_note(dispatch_site<KFused, float, N, PHASE, false, 1, 16>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(ColCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }

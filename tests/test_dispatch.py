@@ -29,7 +29,7 @@ def test_record_names_template_arguments_and_clears():
     h.optimize("GS", maxiter=3, verbose=False)
     d = dispatch_of(h)
     recs = {r["name"]: r for r in d.records}
-    assert any(n.startswith("col_fused_kernel<R=float,N=256,PHASE=0,STATS=false,RULE=2>") for n in recs), d
+    assert any(n.startswith("col_fused_kernel<R=float,N=256,PHASE=0,STATS=false,RULE=2,NRS=16>") for n in recs), d
     # (the last row launch of a float32 call is MODE 3: it writes the phase and leaves G of the next body behind)
     assert d.count("row_kernel", R="float", N=256, MODE=0) == 1 and d.count("row_kernel", MODE=2) == 2 and d.count("row_kernel", MODE=3) == 1, d
     assert dispatch_of(h).records == []                         # reading clears
