@@ -54,9 +54,45 @@ constexpr int C_NC = 64;     // spots per cross-wave reduction round
 // order [1, x, y, x^2, xy, y^2] (coeff6[k][n], zero where a monomial is absent) so the evaluation is a
 // short Horner form with wave-uniform coefficients; DEG 0: arbitrary monomial list, including the
 // non-polynomial pseudo-term (-1, 0) (vortex plate).
+// DEG 3 (round 5): an arbitrary list of at most C_MTAB monomials (Zernike bases up to radial degree 4 -- what
+// wavefront_calibrate_zernike re-optimises, cameraslms.py:1840-1930) with the monomial VALUES of a lane's pixels formed once,
+// ahead of the spot loop (MonoTab), so that a spot costs one multiply-add per monomial and pixel instead of the exponent
+// loops and their loads: 16 spots x 10 terms on a 1152 x 1920 SLM, GS x 3: 2.46 -> see NOTEBOOK round 5.
+constexpr int C_MTAB = 16;
+template <typename R> struct MonoTab {
+    R v[C_PT][C_MTAB];
+    // the same products, in the same order, as SpotPoly<R, 0>::eval forms per spot
+    __device__ __forceinline__ void build(const CArgs<R>& a, const R (&x)[C_PT], const R (&y)[C_PT]) {
+        static_for<0, C_MTAB>([&](auto m_) {
+            constexpr int m = m_;
+            const int px = m < a.M ? a.mono[2 * m] : 0, py = m < a.M ? a.mono[2 * m + 1] : 0;
+#pragma unroll
+            for (int i = 0; i < C_PT; ++i) {
+                R t = 1;
+                if (px < 0) {
+                    t = Math<R>::atan2(y[i], x[i]);     // vortex plate pseudo-term (-1, 0)
+                } else {
+                    for (int k = 0; k < px; ++k) t *= x[i];
+                    for (int k = 0; k < py; ++k) t *= y[i];
+                }
+                v[i][m] = m < a.M ? t : (R)0;
+            }
+        });
+    }
+};
+
 template <typename R, int DEG> struct SpotPoly {
-    R c[6];
+    R c[DEG == 3 ? C_MTAB : 6];
     __device__ __forceinline__ void load(const CArgs<R>& a, int n) {
+        if constexpr (DEG == 3) {
+            static_for<0, C_MTAB>([&](auto m_) {
+                constexpr int m = m_;
+                R cm = m < a.M ? a.coeff[(size_t)m * a.N + n] : (R)0;
+                if (m < a.M && a.mono[2 * m] < 0 && !(cm > (R)0)) cm = 0;      // vortex plate: positive charges only (phase.py:1783-1790)
+                c[m] = cm;
+            });
+            return;
+        }
         if constexpr (DEG >= 1) {
             c[0] = a.coeff[n];
             c[1] = a.coeff[(size_t)a.N + n];
@@ -67,6 +103,12 @@ template <typename R, int DEG> struct SpotPoly {
             c[4] = a.coeff[(size_t)4 * a.N + n];
             c[5] = a.coeff[(size_t)5 * a.N + n];
         }
+    }
+    // DEG 3: pixel i of the lane's table
+    __device__ __forceinline__ R eval_tab(const MonoTab<R>& tab, int i) const {
+        R phi = 0;
+        static_for<0, C_MTAB>([&](auto m_) { constexpr int m = m_; phi += c[m] * tab.v[i][m]; });
+        return phi;
     }
     __device__ __forceinline__ R eval(const CArgs<R>& a, int n, R x, R y) const {
         if constexpr (DEG == 1) {
@@ -114,6 +156,8 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_n2f_par
             im[i] = am * s;
         }
     }
+    MonoTab<R> tab;
+    if constexpr (DEG == 3) tab.build(a, x, y);
     Cx<R>* out = a.partial + ((size_t)b * a.nblocks + blockIdx.x) * a.N;
     for (int n0 = 0; n0 < a.N; n0 += C_NC) {
         const int nc = min(C_NC, a.N - n0);
@@ -124,7 +168,8 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_n2f_par
 #pragma unroll
             for (int i = 0; i < C_PT; ++i) {
                 R c, s;
-                Trig<R>::cis(sp.eval(a, n0 + k, x[i], y[i]), &c, &s);
+                if constexpr (DEG == 3) Trig<R>::cis(sp.eval_tab(tab, i), &c, &s);
+                else Trig<R>::cis(sp.eval(a, n0 + k, x[i], y[i]), &c, &s);
                 sr += re[i] * c + im[i] * s;       // nf * exp(-i phi)
                 si += im[i] * c - re[i] * s;
             }
@@ -220,6 +265,8 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_f2n(CAr
         if (p < a.S) { x[i] = a.xg[p]; y[i] = a.yg[p]; }
     }
     const Cx<R>* ff = a.ff + (size_t)b * a.N;
+    MonoTab<R> tab;
+    if constexpr (DEG == 3) tab.build(a, x, y);
     for (int n = 0; n < a.N; ++n) {
         const Cx<R> f = ff[n];
         SpotPoly<R, DEG> sp;
@@ -227,7 +274,8 @@ template <typename R, int DEG> __global__ __launch_bounds__(C_WG) void c_f2n(CAr
 #pragma unroll
         for (int i = 0; i < C_PT; ++i) {
             R c, s;
-            Trig<R>::cis(sp.eval(a, n, x[i], y[i]), &c, &s);
+            if constexpr (DEG == 3) Trig<R>::cis(sp.eval_tab(tab, i), &c, &s);
+            else Trig<R>::cis(sp.eval(a, n, x[i], y[i]), &c, &s);
             re[i] += f.x * c - f.y * s;            // ff * exp(+i phi)
             im[i] += f.x * s + f.y * c;
         }

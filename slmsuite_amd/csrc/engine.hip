@@ -232,6 +232,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_prev_phase = 0;
     int opt_tile2 = 1;                     // developer A/B (HGS_TILE2=0 at create): half-width tile kernel off
     int env_tile2_blocks = 0;              // ... its workgroups per launch over the batch (HGS_TILE2_BLOCKS; 0 = 3 x / 2 x #CU)
+    int opt_mono_tab = 1;                  // developer A/B (HGS_MONO_TAB=0 at create): per-pixel compressed kernels evaluate every monomial per spot
     int opt_keep_g = 1;                    // developer A/B (HGS_KEEP_G=0 at create)
     int opt_fused_shift = 1;               // developer A/B (HGS_FUSED_SHIFT=0 at create): float64 per-column kernel unshifted (16 slots)
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
@@ -670,6 +671,7 @@ template <typename R> struct Engine : EngineBase {
     int init_compressed(const hgs_config& c) {
         if (c.n_spots < 1 || c.n_monomials < 1 || c.slm_h < 1 || c.slm_w < 1 || c.batch < 1)
             return fail(HGS_ERR_ARG, "compressed engine needs n_spots, n_monomials, slm shape and batch >= 1");
+        opt_mono_tab = env_int("HGS_MONO_TAB", 1);
         g.Sh = c.slm_h; g.Sw = c.slm_w; g.r0 = g.c0 = 0;
         g.Ph = c.n_spots; g.Pw = 1;      // farfield-sized arrays are N-vectors; the transposes degenerate
         g.batch = B = c.batch;
@@ -998,6 +1000,7 @@ template <typename R> struct Engine : EngineBase {
             if (use_run()) { if (int e = run_n2f(a)) return e; }
             else if (c_degree <= 1) { dispatch_note(dispatch_site<KCn2fPix, R, 1>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 1>), grid, dim3(C_WG), 0, stream, a); }
             else if (c_degree == 2) { dispatch_note(dispatch_site<KCn2fPix, R, 2>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 2>), grid, dim3(C_WG), 0, stream, a); }
+            else if (cfg.n_monomials <= C_MTAB && opt_mono_tab) { dispatch_note(dispatch_site<KCn2fPix, R, 3>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 3>), grid, dim3(C_WG), 0, stream, a); }
             else { dispatch_note(dispatch_site<KCn2fPix, R, 0>(), bflag()); hipLaunchKernelGGL((c_n2f_partial<R, 0>), grid, dim3(C_WG), 0, stream, a); }
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(c_n2f_reduce<R>, dim3(nred, B), dim3(C_RED_SPOTS * C_RED_SLICES), 0, stream, a, cnorm);
@@ -1026,6 +1029,7 @@ template <typename R> struct Engine : EngineBase {
             if (use_run()) return run_f2n(a);
             if (c_degree <= 1) { dispatch_note(dispatch_site<KCf2nPix, R, 1>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a); }
             else if (c_degree == 2) { dispatch_note(dispatch_site<KCf2nPix, R, 2>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a); }
+            else if (cfg.n_monomials <= C_MTAB && opt_mono_tab) { dispatch_note(dispatch_site<KCf2nPix, R, 3>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 3>), grid, dim3(C_WG), 0, stream, a); }
             else { dispatch_note(dispatch_site<KCf2nPix, R, 0>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a); }
             HIPCHK(hipGetLastError());
             return 0;
@@ -1720,6 +1724,7 @@ template <typename R> struct Engine : EngineBase {
                 if (use_run()) return run_f2n(a);
                 if (c_degree <= 1) { dispatch_note(dispatch_site<KCf2nPix, R, 1>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 1>), grid, dim3(C_WG), 0, stream, a); }
                 else if (c_degree == 2) { dispatch_note(dispatch_site<KCf2nPix, R, 2>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 2>), grid, dim3(C_WG), 0, stream, a); }
+                else if (cfg.n_monomials <= C_MTAB && opt_mono_tab) { dispatch_note(dispatch_site<KCf2nPix, R, 3>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 3>), grid, dim3(C_WG), 0, stream, a); }
                 else { dispatch_note(dispatch_site<KCf2nPix, R, 0>(), bflag()); hipLaunchKernelGGL((c_f2n<R, 0>), grid, dim3(C_WG), 0, stream, a); }
                 HIPCHK(hipGetLastError());
                 return 0;
@@ -2101,9 +2106,17 @@ template <typename R> struct Engine : EngineBase {
                 if (sp && n_noise_max * 2 > n_active_max) split64 = false;
             }
             if (split64 && !ffb_zeroed) {
-                if (!ffb) { if (dalloc(&ffb, (size_t)B * g.Ph * g.Pw)) return HGS_ERR_DEVICE; }
-                HIPCHK(hipMemsetAsync(ffb, 0, (size_t)B * g.Ph * g.Pw * sizeof(C), stream));
-                ffb_zeroed = true;
+                // (a farfield-sized buffer more: 268 MB per float64 hologram at 4096^2.  Where the device cannot give it the
+                //  update runs in two passes as it did before round 4 -- slower, same results -- instead of failing the call)
+                if (!ffb) {
+                    void* p = nullptr;
+                    if (hipMalloc(&p, (size_t)B * g.Ph * g.Pw * sizeof(C)) != hipSuccess) { (void)hipGetLastError(); split64 = false; }
+                    else ffb = static_cast<C*>(p);
+                }
+                if (split64) {
+                    HIPCHK(hipMemsetAsync(ffb, 0, (size_t)B * g.Ph * g.Pw * sizeof(C), stream));
+                    ffb_zeroed = true;
+                }
             }
             const bool split_any = split || split64;
             if (split_any && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }

@@ -139,6 +139,9 @@ def _kernel_phase64(h, orc):
     y = np.asarray(h._yg, dtype=np.float64).ravel()
     phi = np.zeros((wts.shape[1], x.size))
     for m, (px, py) in enumerate(terms):
+        if px < 0:       # vortex plate pseudo-term (-1, 0): positive charges only (phase.py:1783-1790)
+            phi += np.where(wts[m] > 0, wts[m], 0.0)[:, None] * np.arctan2(y, x)[None, :]
+            continue
         phi += wts[m][:, None] * (x ** int(px) * y ** int(py))[None, :]
     return phi
 
@@ -205,3 +208,52 @@ def test_run_kernels_against_float64_sums(basis, slm_shape):
            per_pixel_ff=errs[0][0], per_pixel_phase=errs[0][1])
     assert errs[1][0] < 2e-6 and errs[1][1] < 1e-5
     assert errs[0][0] < 2e-5 and errs[0][1] < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("ansi", [[2, 1, 4, 3, 5, 7, 8, 6, 9, 12], [2, 1, 4, -1]])
+def test_monomial_table_kernels_against_float64_sums(ansi, dtype, monkeypatch):
+    """
+    Bases beyond degree 2 (and the vortex pseudo-term) run the per-pixel kernels; with at most 16 monomials they form the
+    monomial values of a lane's pixels once, ahead of the spot loop (c_n2f_partial / c_f2n DEG = 3, MonoTab), instead of
+    walking the exponent list for every spot and pixel (DEG = 0, HGS_MONO_TAB=0 at hgs_create) -- the basis
+    wavefront_calibrate_zernike re-optimises (cameraslms.py:1840-1930): 16 spots x 10 terms.  Both forms against float64
+    direct sums and against each other (the same products in the same order: they may differ by contraction only).
+    """
+    from oracle import hgs_oracle as orc
+    slm_shape = (70, 93)
+    fs = SimpleFourierSLM(SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78))
+    N = 21
+    z = np.zeros((len(ansi), N))
+    z[:2] = 60 * (synth.uniform01(71, (2, N), 0) - 0.5)
+    z[2:] = 1.5 * (synth.uniform01(72, (len(ansi) - 2, N), 0) - 0.5)          # (vortex row: charges of both signs, negative ones are ignored)
+    amp = 0.5 + synth.uniform01(73, (N,), 0)
+    phase0 = synth.seed_phase(70, slm_shape).astype(dtype)
+    S = slm_shape[0] * slm_shape[1]
+    out, errs = {}, {}
+    for tab in ("1", "0"):
+        monkeypatch.setenv("HGS_MONO_TAB", tab)
+        h = CompressedSpotHologram(z.copy(), basis=np.array(ansi), spot_amp=amp, cameraslm=fs, dtype=dtype)
+        h.reset_phase(phase0)
+        h.optimize("WGS-Leonardo", maxiter=3, verbose=False)
+        d = dispatch_of(h)
+        deg = 3 if tab == "1" else 0
+        assert d.count("c_n2f_partial", DEG=deg) >= 3 and d.count("c_f2n", DEG=deg) >= 3 and d.families() == {"c_n2f_partial", "c_f2n"}, d
+        out[tab] = (h.phase.copy(), np.array(h.weights, copy=True), np.array(h.farfield, copy=True))
+        h.phase = phase0
+        e = h._get_engine()
+        phi = _kernel_phase64(h, orc)
+        e.nearfield2farfield()
+        ff = e.get(L.FARFIELD)[0].astype(np.complex128)
+        nf = float(h.amp) * np.exp(1j * phase0.astype(np.float64).ravel()) if np.isscalar(h.amp) else \
+            np.asarray(h.amp, dtype=np.float64).ravel() * np.exp(1j * phase0.astype(np.float64).ravel())
+        ref = np.sum(nf[None, :] * np.exp(-1j * phi), axis=1)
+        ref /= np.sqrt(np.sum(np.abs(ref) ** 2))
+        errs[tab] = rel_l2(ff, ref)
+        h._release_engine()
+    between = dict(phase=phase_rel_l2(out["1"][0], out["0"][0]), weights=rel_l2(out["1"][1], out["0"][1]), ff=rel_l2(out["1"][2], out["0"][2]))
+    report(f"compressed monomial-table kernels {ansi} {np.dtype(dtype).name}", table_ff=errs["1"], list_ff=errs["0"], **between)
+    tol = 3e-5 if dtype == np.float32 else 1e-10
+    assert errs["1"] < tol and errs["0"] < tol, errs
+    assert max(between.values()) < (2e-5 if dtype == np.float32 else 1e-11), between

@@ -1,36 +1,28 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python - > gpurun_out/b_pair_parity.log 2>&1 <<'PY'
-import os, sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import numpy as np, torch
-from conftest import dispatch_of, phase_rel_l2, rel_l2
-from slmsuite_amd import _lib as L, synth
-from slmsuite_amd.holography.algorithms import SpotHologram
-out = {}
-for slm in [(1152, 1920), (1000, 1000), (1400, 1920)]:
-    for pair in ("1", "0"):
-        os.environ["HGS_PAIR"] = pair
-        h = SpotHologram.make_rectangular_array((4096, 4096), (32, 32), (64, 64), basis="knm", slm_shape=slm, phase=synth.seed_phase(2, slm), engine_options={L.OPT_SPARSE_COLUMNS: 0})
-        h.optimize("WGS-Leonardo", maxiter=6, verbose=False)
-        d = dispatch_of(h)
-        out[pair] = (h.phase.copy(), h.weights.copy(), h.amp_ff.copy())
-        print(slm, "pair", pair, [(r["name"], r["count"]) for r in d.records if "col_" in r["name"]])
-        h._release_engine()
-    a, b = out["1"], out["0"]
-    print(slm, "phase", phase_rel_l2(a[0], b[0]), "weights", rel_l2(a[1], b[1]), "amp_ff", rel_l2(a[2], b[2]))
+python -m pytest tests/test_compressed.py tests/test_dispatch.py tests/test_full_configs.py -m gpu -q --tb=short -p no:cacheprovider -k "compressed or monomial or cfg4 or zern" > gpurun_out/d_pytest.log 2>&1; tail -8 gpurun_out/d_pytest.log
+python - > gpurun_out/d_wavefront_profile.log 2>&1 <<'PY'
+import sys, json, os, time, cProfile, pstats
+sys.path.insert(0, ".")
+import torch
+import numpy as np
+from slmsuite_amd import synth
+from slmsuite_amd.hardware import SimpleFourierSLM, SimpleSLM
+from slmsuite_amd.holography.algorithms import CompressedSpotHologram
+slm_shape = (1152, 1920)
+fs = SimpleFourierSLM(SimpleSLM(slm_shape, pitch_um=(8, 8), wav_um=0.78))
+basis = np.array([2, 1, 4, 3, 5, 7, 8, 6, 9, 12]); N = 16
+z = np.zeros((len(basis), N)); z[:2] = 600 * (synth.uniform01(41, (2, N), 0) - 0.5); z[2:] = 1.0 * (synth.uniform01(42, (len(basis) - 2, N), 0) - 0.5)
+h = CompressedSpotHologram(z.copy(), basis=basis, cameraslm=fs); h.reset_phase(synth.seed_phase(40, slm_shape))
+h.optimize("GS", maxiter=3, verbose=False); _ = h.get_phase()
+def rounds(n):
+    for rnd in range(n):
+        z[2 + rnd % 8, :] += 0.05
+        h.spot_zernike = z.copy()
+        h.optimize("GS", maxiter=3, verbose=False)
+        _ = h.get_phase()
+rounds(4)
+t = time.perf_counter(); rounds(40); print("ms per round", 1e3 * (time.perf_counter() - t) / 40)
+pr = cProfile.Profile(); pr.enable(); rounds(40); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
 PY
-cat gpurun_out/b_pair_parity.log
-for p in 0 1 0 1; do HGS_PAIR=$p python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']
-        print('pair=$p it/s %8.0f  col_us %6.2f row_us %6.2f frac %.3f iter %.3f %s'%(d['value'],r['launch_us'],r['row_kernel']['launch_us'],r['frac'],r['frac_iteration'],r['kernel'][:60]))
-"; done 2>&1 | tee gpurun_out/b_ab_pair.log
-for blk in 256 384 768 1024; do HGS_PAIR_BLOCKS=$blk python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']
-        print('pair blocks=$blk it/s %8.0f  col_us %6.2f row_us %6.2f'%(d['value'],r['launch_us'],r['row_kernel']['launch_us']))
-"; done 2>&1 | tee -a gpurun_out/b_ab_pair.log
+head -70 gpurun_out/d_wavefront_profile.log | cut -c1-160
