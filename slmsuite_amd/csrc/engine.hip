@@ -238,6 +238,7 @@ template <typename R> struct Engine : EngineBase {
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
     int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
     int opt_row_shift = 1;                 // developer A/B (HGS_ROW_SHIFT=0 at create): shifted row kernel off
+    int opt_row_shift64 = 1;               // ... in float64 (HGS_ROW_SHIFT64=0 at create; round 5)
     int opt_row_pref = 1;                  // developer A/B (HGS_ROW_PREF=0 at create): prefetching row kernel off
     int opt_mraf_split = 1;                // developer A/B (HGS_MRAF_SPLIT=0 at create): MRAF weight updates in two column passes
     bool row_split = false;                // the next row kernel joins gh and gh2 (single-pass MRAF)
@@ -412,6 +413,7 @@ template <typename R> struct Engine : EngineBase {
         opt_gh2_mask = env_int("HGS_GH2_MASK", 1);
         opt_tile_list = env_int("HGS_TILE_LIST", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
+        opt_row_shift64 = env_int("HGS_ROW_SHIFT64", 1);
         auto t_prev = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!trace_init) return;
@@ -1477,7 +1479,7 @@ template <typename R> struct Engine : EngineBase {
         {   // shifted form of the row kernel: fp32, one-row workgroups, the SLM columns within eight register slots
             const int T = g.Pw / 16;
             const int s0 = g.c0 / T, s1 = (g.c0 + g.Sw - 1) / T;
-            a.shifted = (sizeof(R) == 4 && g.Pw >= 4096 && s1 - s0 + 1 <= 8 && opt_row_shift) ? 1 : 0;
+            a.shifted = ((sizeof(R) == 4 || opt_row_shift64) && g.Pw >= 4096 && s1 - s0 + 1 <= 8 && opt_row_shift) ? 1 : 0;
             a.m0 = s0;
         }
         return a;

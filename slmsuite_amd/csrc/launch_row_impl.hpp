@@ -54,6 +54,17 @@ static int launch_row_n(int mode, dim3 grid, hipStream_t s, const RowArgs<R>& a)
             }
         }
     }
+#else
+    // float64 (round 5): the same shifted form at 4096 / 8192 columns (no MODE 3: the engine keeps MODE 1 in float64)
+    if constexpr (N >= 4096) {
+        if (a.shifted) {
+            switch (mode) {
+                case 0: return launch_row_one<R, N, 0, 8>(grid, s, a);
+                case 1: return launch_row_one<R, N, 1, 8>(grid, s, a);
+                case 2: return launch_row_one<R, N, 2, 8>(grid, s, a);
+            }
+        }
+    }
 #endif
     switch (mode) {
         case 0: return launch_row_one<R, N, 0>(grid, s, a);
@@ -83,20 +94,25 @@ template <> int launch_row<HGS_REAL>(int N, int mode, dim3 grid, hipStream_t s, 
 #ifndef HGS_REAL_IS_FLOAT
 // float64 single-pass MRAF (col_fused_kernel with CParams::split + col_kernel<LOAD | INV> into gh2): the row kernel that joins
 // the two parts, H = gh * wscale + gh2 (a.gh2 and a.gh2_mask set); rows of 4096 / 8192 (the split form has one-row workgroups)
-template <int N, int MODE>
+template <int N, int MODE, int NS = 16>
 static int launch_row_split64_one(dim3 grid, hipStream_t s, const RowArgs<double>& a) {
     constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<double>);
-    auto k = row_kernel<double, N, MODE, 16, false, true>;
+    auto k = row_kernel<double, N, MODE, NS, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    dispatch_note(dispatch_site<KRow, double, N, MODE, 16, false, true>(), row_flags(grid, a));
+    dispatch_note(dispatch_site<KRow, double, N, MODE, NS, false, true>(), row_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(RowCfg<N>::WG), lds, s, a);
     return (int)hipGetLastError();
 }
+template <int N>
+static int launch_row_split64_n(int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a) {
+    if (a.shifted) return mode == 1 ? launch_row_split64_one<N, 1, 8>(grid, s, a) : launch_row_split64_one<N, 2, 8>(grid, s, a);
+    return mode == 1 ? launch_row_split64_one<N, 1>(grid, s, a) : launch_row_split64_one<N, 2>(grid, s, a);
+}
 int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a) {
     if (mode != 1 && mode != 2) return (int)hipErrorInvalidValue;
-    if (N == 4096) return mode == 1 ? launch_row_split64_one<4096, 1>(grid, s, a) : launch_row_split64_one<4096, 2>(grid, s, a);
-    if (N == 8192) return mode == 1 ? launch_row_split64_one<8192, 1>(grid, s, a) : launch_row_split64_one<8192, 2>(grid, s, a);
+    if (N == 4096) return launch_row_split64_n<4096>(mode, grid, s, a);
+    if (N == 8192) return launch_row_split64_n<8192>(mode, grid, s, a);
     return (int)hipErrorInvalidValue;
 }
 #endif

@@ -309,3 +309,39 @@ def test_float64_column_kernel_shifted_form(n, slm, nrs, kind, monkeypatch):
         assert max(worst.values()) < 1e-9, worst
     # dense launches and column lists of the shifted kernel agree as they always did
     assert phase_rel_l2(out["1", 0][0], out["1", 1][0]) < 1e-9
+
+
+@pytest.mark.parametrize("n,slm", [(4096, (1152, 1920)), (8192, (1152, 1920)), (4096, (600, 2300))])
+def test_float64_row_kernel_shifted_form(n, slm, monkeypatch):
+    """
+    float64 rows of 4096 / 8192 columns whose SLM columns fit eight of the sixteen register slots run the shifted row kernel
+    (row_kernel<double, N, MODE, 8>: no phasor, predicate or butterfly input for the eight empty slots), as float32 has since
+    round 3.  Against the 16-slot form (HGS_ROW_SHIFT64=0 at hgs_create), spots (WGS-Kim: MODE 0 / 2 / 1 launches) and
+    single-pass MRAF (the row kernel that joins the two parts): the same numbers up to the rounding of the shift factors.
+    """
+    out = {}
+    for sh in ("1", "0"):
+        monkeypatch.setenv("HGS_ROW_SHIFT64", sh)
+        res = []
+        h = SpotHologram.make_rectangular_array((n, n), (6, 6), (n // 16, n // 32), basis="knm", slm_shape=slm,
+                                                phase=synth.seed_phase(11, slm, dtype=np.float64), dtype=np.float64, engine_options={L.OPT_SPARSE_COLUMNS: 0})
+        h.optimize("WGS-Kim", maxiter=4, verbose=False, fix_phase_iteration=2)
+        d = dispatch_of(h)
+        fits = (n // 2 + slm[1] // 2 - 1) // (n // 16) - (n // 2 - slm[1] // 2) // (n // 16) + 1 <= 8
+        ns = 8 if (sh == "1" and fits) else 16
+        assert d.count("row_kernel", R="double", NS=ns) >= 4 and d.count("row_kernel", R="double") == d.count("row_kernel", NS=ns), d
+        res.append((h.phase.copy(), h.amp_ff.copy()))
+        h._release_engine()
+        if n == 4096:
+            h = Hologram(_mraf_target64(n), phase=synth.seed_phase(12, slm, dtype=np.float64), slm_shape=slm, dtype=np.float64,
+                         engine_options={L.OPT_SPARSE_COLUMNS: 0})
+            h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.5)
+            d = dispatch_of(h)
+            assert d.count("row_kernel", R="double", SPLIT=True, NS=ns) >= 2, d
+            res.append((h.phase.copy(), h.amp_ff.copy()))
+            h._release_engine()
+        out[sh] = res
+    for a, b in zip(out["1"], out["0"]):
+        worst = dict(phase=phase_rel_l2(a[0], b[0]), amp_ff=rel_l2(a[1], b[1]))
+        report(f"float64 shifted row kernel vs 16-slot form: n={n} slm={slm}", **worst)
+        assert max(worst.values()) < 1e-9, worst
