@@ -669,11 +669,11 @@ def main():
             if want_pmc:
                 # which fused column kernel ran is the engine's choice (tile-resident, per column, sparse list):
                 # count both and keep the one that was launched
-                subs = {"col_tile": "col_tile_kernel", "col_fused": "col_fused_kernel",
+                subs = {"col_tile": "col_tile_kernel", "col_tile2": "col_tile2_kernel", "col_fused": "col_fused_kernel",
                         "row": "row_kernel<" + ("float" if args.dtype == "f32" else "double") + f", {prob.shape[1]}, 2"}   # (<R, N, MODE 2[, NS]>)
                 res, tnote = pmc_traffic(args, subs)
                 if res is not None:
-                    res["col"] = max((res["col_tile"], res["col_fused"]), key=lambda r: r["launches"])
+                    res["col"] = max((res["col_tile"], res["col_tile2"], res["col_fused"]), key=lambda r: r["launches"])
                 if res is not None and res["col"]["fetch"] is not None and res["col"]["write"] is not None:
                     traffic = (res["col"]["fetch"] + res["col"]["write"]) * per
                     tr_row = None if res["row"]["fetch"] is None else res["row"]["fetch"] + res["row"]["write"]
@@ -885,6 +885,11 @@ def col_kernel_name(args, prob):
     r0 = (Ph - prob.slm[0]) // 2
     slots = (r0 + prob.slm[0] - 1) // T - r0 // T + 1
     tile_off = any(o.upper().replace(" ", "") == "TILE_KERNEL=0" for o in args.opt)
+    # plain passes (Leonardo / Kim update or none) that neither store nor read the farfield phase run the half-width tile kernel
+    # at 4096 rows (three workgroups per CU) and at 2048 rows
+    plain = args.method in ("GS", "WGS-Leonardo") and not getattr(prob, "mraf", False) and args.workload != "cfg5mraf"
+    if args.dtype == "f32" and plain and not tile_off and ((Ph == 4096 and slots <= 6) or (Ph == 2048 and slots <= 10)):
+        return f"col_tile2_kernel<float, {Ph}, ...> (half-width tile-resident fused column kernel)"
     if args.dtype == "f32" and Ph >= 4096 and slots <= 6 and not tile_off:
         return f"col_tile_kernel<float, {Ph}, ...> (tile-resident fused column kernel)"
     return f"col_fused_kernel<{'float' if args.dtype == 'f32' else 'double'}, {Ph}, ...> (per-column fused kernel)"

@@ -42,7 +42,8 @@ def test_record_names_template_arguments_and_clears():
 @pytest.mark.parametrize("n, dtype, family, extra", [
     (512, np.float32, "col_fused_kernel", dict(R="float", N=512)),
     (2048, np.float32, "col_tile2_kernel", dict(R="float", N=2048, NR=8)),     # half-width tile-resident kernel (520 SLM rows: within eight slots of 128)
-    (4096, np.float32, "col_tile_kernel", dict(R="float", N=4096, NR=5, LISTED=0)),     # 1032 SLM rows from row 1532: five slots of 256
+    (4096, np.float32, "col_tile2_kernel", dict(R="float", N=4096, NR=5)),     # 1032 SLM rows from row 1532: five slots of 256; plain passes without a stored
+                                                                                 # farfield phase run the half-width tile kernel (three workgroups per CU) since round 5
     (1024, np.float64, "col_fused_kernel", dict(R="double", N=1024, RULE=0)),
     (4096, np.float64, "col_fused_kernel", dict(R="double", N=4096, RULE=0)),      # the tile-resident kernel is fp32 only
 ])
@@ -68,13 +69,15 @@ def test_tall_slm_leaves_the_tile_kernel():
     h2 = Hologram(_image(n), phase=synth.seed_phase(2, (1500, 1920)), slm_shape=(1500, 1920))       # 6 slots: still tile-resident
     h2.optimize("WGS-Leonardo", maxiter=2, verbose=False)
     d = dispatch_of(h2)
-    assert d.count("col_tile_kernel", N=4096, NR=6) == 2 and d.count("col_fused_kernel") == 0, d
+    assert d.count("col_tile2_kernel", N=4096, NR=6) == 2 and d.count("col_fused_kernel") + d.count("col_tile_kernel") == 0, d
 
 
 @pytest.mark.parametrize("method", ["WGS-Nogrette", "WGS-Wu", "WGS-tanh", "WGS-Kim", "GS"])
 def test_rule_specialisation_follows_the_method(method):
     """RULE 1 is compiled for the Leonardo / Kim power rule only, RULE 2 for passes without an update; the other updates run
-    the generic kernel (RULE 0), WGS-Nogrette with one more forward-only pass (EXTRAS unit) that sums feedback / target."""
+    the generic kernel (RULE 0), WGS-Nogrette with one more forward-only pass (EXTRAS unit) that sums feedback / target.
+    (Plain passes that neither store nor read the farfield phase take the half-width tile kernel: all of GS, body 0 of the
+    Wu / tanh / Nogrette / Kim runs; WGS-Kim's later bodies store the phase, so they stay on col_tile_kernel.)"""
     n, slm = 4096, (1152, 1920)
     h = Hologram(_image(n), phase=synth.seed_phase(5, slm), slm_shape=slm)
     h.optimize(method, maxiter=3, verbose=False)
@@ -84,10 +87,11 @@ def test_rule_specialisation_follows_the_method(method):
             "WGS-Nogrette": {(2, False): 1, (0, False): 2, (0, True): 2}}[method]
     got = {}
     for r in d.records:
-        if r["kernel"] == "col_tile_kernel":
-            key = (int(r["args"]["RULE"]), r["args"]["EXTRAS"] == "true")
+        if r["kernel"] in ("col_tile_kernel", "col_tile2_kernel"):
+            key = (int(r["args"]["RULE"]), r["args"].get("EXTRAS") == "true")
             got[key] = got.get(key, 0) + r["count"]
     assert got == want, d
+    assert d.count("col_tile2_kernel") > 0 and (d.count("col_tile_kernel") > 0) == (method != "GS"), d      # (body 0 of every run is a plain pass)
 
 
 def test_stepwise_option_and_callbacks_run_the_three_operators():

@@ -27,7 +27,8 @@ def assert_cfg2_column_path(h, path, update=True):
     The three policies of PATHS must reach three different kernels -- they agree to the last bit on the cfg 2 grid, so the
     numbers alone would not notice a dispatcher that routed one policy to another's kernel.
       default           col_fused_kernel over the active-column list (rule compiled in), masked row kernel
-      dense             col_tile_kernel, dense schedule compiled in (LISTED = 0), prefetching shifted row kernel
+      dense             col_tile2_kernel (plain passes without a stored farfield phase: half-width tile, three workgroups per CU)
+                        or col_tile_kernel with the dense schedule compiled in (LISTED = 0; WGS-Kim), prefetching shifted row kernel
       dense-per-column  col_fused_kernel, every column, no list
     """
     d = dispatch_of(h)
@@ -38,7 +39,8 @@ def assert_cfg2_column_path(h, path, update=True):
         assert d.count("row_kernel", flags=["load_mask", "store_mask"], MODE=2) > 0 or d.count("row_kernel", MODE=2) == 0, d
         assert d.count("row_kernel", PREF=True) == 0, d
     elif path == "dense":
-        assert d.count("col_tile_kernel", without=["list"], R="float", N=4096, NR=5, RULE=rule, LISTED=0, STATS=False, EXTRAS=False) > 0, d
+        assert d.count("col_tile_kernel", without=["list"], R="float", N=4096, NR=5, RULE=rule, LISTED=0, STATS=False, EXTRAS=False) + \
+            d.count("col_tile2_kernel", flags=["xmap"], without=["list", "batch"], R="float", N=4096, NR=5, RULE=rule) > 0, d
         assert d.count("col_fused_kernel") == 0 and d.count("col_tile_kernel", flags=["list"]) == 0, d
         n2 = d.count("row_kernel", MODE=2)
         assert n2 == 0 or d.count("row_kernel", MODE=2, NS=8, PREF=True, SPLIT=False, without=["load_mask", "store_mask"]) == n2, d
@@ -67,7 +69,7 @@ def test_cfg2_leonardo_every_column_path_matches_reference(path):
     h = cfg2_hologram(2, path)
     h.optimize("WGS-Leonardo", maxiter=50, verbose=False)
     d = assert_cfg2_column_path(h, path)
-    assert d.count("col_fused_kernel" if path != "dense" else "col_tile_kernel", RULE=1) == 49, d     # body 0 has no update
+    assert d.count("col_fused_kernel" if path != "dense" else "col_tile2_kernel", RULE=1) == 49, d     # body 0 has no update
     ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
     amp_ff = h.amp_ff
     errs = dict(spot_amp=rel_l2(amp_ff[ky, kx], gold["spot_ampff"]),

@@ -639,7 +639,7 @@ def test_sparse_column_path_matches_dense_path(method, kw):
         if sparse:
             assert d.count("col_fused_kernel", flags=["list"], STATS=False, RULE=rule) == 2, d
         else:
-            assert d.count("col_tile_kernel", without=["list"], STATS=False, RULE=rule, LISTED=0) == 2, d
+            assert d.count("col_tile_kernel", without=["list"], STATS=False, RULE=rule, LISTED=0) + d.count("col_tile2_kernel", without=["list"], RULE=rule) == 2, d
         return h
 
     a, b = run(True), run(False)

@@ -450,10 +450,10 @@ def test_tile_rounded_column_list_equals_the_dense_launch(n, slm, method, kw, mo
                 assert d.count("col_tile_kernel", flags=["list"], RULE=4) == 1 and d.count("row_kernel", SPLIT=True, flags=["load_mask"]) == 1, d
             assert d.count("row_kernel", MODE=2, flags=["load_mask", "store_mask"]) == 1, d
         elif name == "dense":
-            assert d.count("col_tile_kernel", without=["list"], N=n) >= 2 and d.count("col_tile_kernel", flags=["list"]) == 0, d
+            assert d.count("col_tile_kernel", without=["list"], N=n) + d.count("col_tile2_kernel", without=["list"], N=n) >= 2 and d.count("col_tile_kernel", flags=["list"]) == 0, d
             assert d.count("col_fused_kernel") == 0 and d.count("row_kernel", flags=["load_mask"]) == 0, d
             if "mraf_factor" not in kw:
-                assert d.count("col_tile_kernel", LISTED=0) == 2, d
+                assert d.count("col_tile_kernel", LISTED=0) + d.count("col_tile2_kernel") == 2, d
         else:
             assert d.count("col_fused_kernel", flags=["list"], N=n) >= 2 and d.count("col_tile_kernel") == 0, d
         two = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
