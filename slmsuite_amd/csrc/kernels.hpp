@@ -1961,8 +1961,13 @@ template <int N> struct Tile2Cfg {
     static constexpr int CPAR = T >= 256 ? 1 : 256 / T;       // lane groups per workgroup (2 at 2048)
     static constexpr int WG = T * CPAR;
 };
+// 4096 rows: the column of the half tile that is NOT being transformed waits in LDS (lane-private slots, six per lane: 12 KB),
+// not in registers -- with both columns resident the NR = 5 / 6 update instances were 4 / 13 registers over the 168 that three
+// workgroups per CU allow (tools/resusage.sh: 20 / 56 bytes of scratch in the headline kernel)
+template <int N> constexpr bool tile2_parks() { return N >= 4096; }
 template <typename R, int N> constexpr size_t col_tile2_lds_bytes() {
-    return (size_t)Tile2Cfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
+    return (size_t)Tile2Cfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double) +
+           (tile2_parks<N>() ? (size_t)6 * Tile2Cfg<N>::T * sizeof(Cx<R>) : 0);
 }
 
 #ifndef HGS_TILE2_CONS_GROUP
@@ -2004,7 +2009,9 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
     // the half tile, one array per column and component: selected by the (uniform) column of the pass with v_cndmask -- a
     // run-time index into [NR][2] arrays put them on the stack (96 bytes of scratch), unrolling the two passes made the
     // scheduler interleave them (23 .. 187 spilled registers)
-    R g0x[NR], g0y[NR], g1x[NR], g1y[NR];
+    constexpr bool PARK = tile2_parks<N>();
+    R g0x[PARK ? 1 : NR], g0y[PARK ? 1 : NR], g1x[PARK ? 1 : NR], g1y[PARK ? 1 : NR];
+    Cx<R>* park = reinterpret_cast<Cx<R>*>(scratch + SCRATCH_DOUBLES) + j;     // PARK: slot m of this lane at park[m * T]
     R wr[16], tr[16];
     const R* wbase = a.w + (size_t)b * P;
     const R* tbase = a.t + (size_t)b * P;
@@ -2031,7 +2038,12 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
             const int r = r_lane + m * T;
             float4 q = make_float4(0, 0, 0, 0);
             if (r >= 0 && r < g.Sh) q = *reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
-            g0x[m] = q.x; g0y[m] = q.y; g1x[m] = q.z; g1y[m] = q.w;
+            if constexpr (PARK) {           // column 0 straight into the transform registers, column 1 waits in LDS
+                v[m] = mk<R>(q.x * sgs, q.y * sgs);
+                park[m * T] = mk<R>(q.z, q.w);
+            } else {
+                g0x[m] = q.x; g0y[m] = q.y; g1x[m] = q.z; g1y[m] = q.w;
+            }
         }
         const int col0 = ct * 4 + 2 * half;
         if (first) {
@@ -2044,8 +2056,10 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m < NR) {
-                    const R xr = c ? g1x[m < NR ? m : 0] : g0x[m < NR ? m : 0], xi = c ? g1y[m < NR ? m : 0] : g0y[m < NR ? m : 0];
-                    v[m] = mk<R>(xr * sgs, xi * sgs);
+                    if constexpr (!PARK) {
+                        const R xr = c ? g1x[m < NR ? m : 0] : g0x[m < NR ? m : 0], xi = c ? g1y[m < NR ? m : 0] : g0y[m < NR ? m : 0];
+                        v[m] = mk<R>(xr * sgs, xi * sgs);
+                    }                                    // (PARK: slots 0 .. NR-1 hold this column already)
                 } else {
                     v[m] = mk<R>(0, 0);
                 }
@@ -2105,18 +2119,42 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, do_upd, j, wr, tr);
             }
             fft.template inv_after_fwd_trail<NR>(v, lds, j);
+            if constexpr (PARK) {
+                if (c == 0) {
+                    // column 0 done: its result takes column 1's place in the lane's slots, column 1 moves into the registers
 #pragma unroll
-            for (int m = 0; m < NR; ++m) {
-                const Cx<R> h = v[m] * (sgs * a.scale);
-                g0x[m] = c ? g0x[m] : h.x; g0y[m] = c ? g0y[m] : h.y;
-                g1x[m] = c ? h.x : g1x[m]; g1y[m] = c ? h.y : g1y[m];
+                    for (int m = 0; m < NR; ++m) {
+                        const Cx<R> h = v[m] * (sgs * a.scale);
+                        const Cx<R> nx = park[m * T];
+                        park[m * T] = h;
+                        v[m] = nx * sgs;
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NR; ++m) {
+                        const int r = r_lane + m * T;
+                        const Cx<R> h1 = v[m] * (sgs * a.scale);
+                        const Cx<R> h0 = park[m * T];
+                        if (r >= 0 && r < g.Sh)
+                            *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = make_float4(h0.x, h0.y, h1.x, h1.y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const Cx<R> h = v[m] * (sgs * a.scale);
+                    g0x[m] = c ? g0x[m] : h.x; g0y[m] = c ? g0y[m] : h.y;
+                    g1x[m] = c ? h.x : g1x[m]; g1y[m] = c ? h.y : g1y[m];
+                }
             }
         }
+        if constexpr (!PARK) {
 #pragma unroll
-        for (int m = 0; m < NR; ++m) {
-            const int r = r_lane + m * T;
-            if (r >= 0 && r < g.Sh)
-                *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = make_float4(g0x[m], g0y[m], g1x[m], g1y[m]);
+            for (int m = 0; m < NR; ++m) {
+                const int r = r_lane + m * T;
+                if (r >= 0 && r < g.Sh)
+                    *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = make_float4(g0x[m], g0y[m], g1x[m], g1y[m]);
+            }
         }
     }
     if constexpr (do_upd) {

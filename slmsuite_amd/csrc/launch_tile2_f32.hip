@@ -19,8 +19,13 @@ static int launch_tile2_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, i
 template <int N, int RULE, int NR>
 static int launch_tile2_n(int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int shift, int half_xmap) {
     if (phase == 0) return launch_tile2_one<N, 0, RULE, NR>(grid, s, a, shift, half_xmap);
+    // 4096 rows: the engine sends only passes that neither store nor read the farfield phase here (the phase-storing / -reading
+    // update instances do not fit the 168 registers of three workgroups per CU, tools/resusage.sh) -- they are not compiled
+    if constexpr (N >= 4096) return (int)hipErrorInvalidValue;
+    else {
     if (phase == 1) return launch_tile2_one<N, 1, RULE, NR>(grid, s, a, shift, half_xmap);
     return launch_tile2_one<N, 2, RULE, NR>(grid, s, a, shift, half_xmap);
+    }
 }
 template <int N, int NR>
 static int launch_tile2_r(int phase, int rule, dim3 grid, hipStream_t s, const ColArgs<float>& a, int shift, int half_xmap) {

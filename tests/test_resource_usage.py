@@ -14,11 +14,16 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "slmsuite_amd", "csrc")
-UNITS = ["launch_tile_rule_f32.hip", "launch_tile_list_f32.hip", "launch_row_f32.hip", "launch_fused_rule1_f32.hip",
+UNITS = ["launch_tile_rule_f32.hip", "launch_tile_list_f32.hip", "launch_tile2_f32.hip", "launch_row_f32.hip", "launch_fused_rule1_f32.hip",
          "launch_fused_rule2_f32.hip", "launch_tile_split_f32.hip"]
 
 # instantiations that keep a few spilled registers, by (kernel, substring of the template arguments)
 KNOWN = {
+    # half-width tile kernel at 2048 rows with ten occupied slots (SLMs of 1153 .. 1280 rows on a 2048 pad) and a stored / read
+    # farfield phase (WGS-Kim): 2 / 8 registers over the 256 of two workgroups per CU.  (At 4096 rows -- the headline kernel
+    # since round 5 -- the idle column of the half tile waits in LDS and every reachable instance is clean.)
+    ("col_tile2_kernel", "float, 2048, 1, 10, 1"): 2,
+    ("col_tile2_kernel", "float, 2048, 2, 10, 1"): 8,
     # unshifted 8192-wide rows (an SLM wider than 4096 columns on an 8192 pad): 8 VGPRs over the 128 that let two
     # 512-lane workgroups share a CU; one workgroup per CU costs 25 % of the launch, the spills do not
     ("row_kernel", "float, 8192, 2, 16, false, false"): 8,
@@ -75,7 +80,7 @@ def test_hot_kernels_do_not_spill():
         for name, scratch, spilled in rows:
             text = pretty[name].replace("hgs::", "")
             m = re.match(r"void (\w+)<(.*)>\(", text)
-            if not m or m.group(1) not in ("row_kernel", "col_tile_kernel", "col_fused_kernel"):
+            if not m or m.group(1) not in ("row_kernel", "col_tile_kernel", "col_tile2_kernel", "col_fused_kernel"):
                 continue
             key = (m.group(1), m.group(2))
             seen.add(key)
@@ -86,7 +91,8 @@ def test_hot_kernels_do_not_spill():
     assert len(seen) > 100, len(seen)            # the units really were the ones with the hot instantiations
     # the named kernels of VERDICT round 4: the phase-storing rule kernels and the narrow phase-extracting row kernel
     for key in (("col_tile_kernel", "float, 4096, 1, 6, false, false, 1, 0"), ("col_tile_kernel", "float, 8192, 1, 6, false, false, 1, 0"),
-                ("col_tile_kernel", "float, 4096, 1, 5, false, false, 1, 0"), ("row_kernel", "float, 128, 1, 16, false, false")):
+                ("col_tile_kernel", "float, 4096, 1, 5, false, false, 1, 0"), ("row_kernel", "float, 128, 1, 16, false, false"),
+                ("col_tile2_kernel", "float, 4096, 0, 5, 1"), ("col_tile2_kernel", "float, 4096, 0, 6, 1")):       # the headline kernel (round 5)
         assert key in seen and key not in KNOWN, key
     stale = [k for k in KNOWN if k not in seen]
     assert not stale, stale
