@@ -4,11 +4,9 @@ import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('$1 it/s %8.0f  col_us %6.2f row_us %6.2f frac %.3f iter %.3f'%(d['value'],r['launch_us'],r['row_kernel']['launch_us'],r['frac'],r.get('frac_iteration') or 0))
+        print('$1 it/s %8.0f  col_us %6.2f row_us %6.2f frac %.3f'%(d['value'],r['launch_us'],r['row_kernel']['launch_us'],r['frac']))
 "; }
-python -m pytest tests/test_full_configs.py tests/test_dispatch.py tests/test_gpu_round5.py -m gpu -q --tb=short -p no:cacheprovider -k "cfg2 or cfg3 or dispatch or batch or dense or callback" 2>&1 | tail -5
-for v in nopark main nopark main; do lib=slmsuite_amd/libhgs_$v.so; [ $v = main ] && lib=slmsuite_amd/libhgs.so
-  HGS_LIB=$PWD/$lib python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 $v"
-  HGS_LIB=$PWD/$lib python bench.py --workload cfg3 --steps 100 --warmup 10 --streams 1 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg3 $v"
-  HGS_LIB=$PWD/$lib python bench.py --workload cfg2dense --steps 100 --warmup 10 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2dense $v"
-done 2>&1 | tee gpurun_out/j_ab_tile2_park.log
+for v in 0 1 0 1; do HGS_ROW_RPF=$v python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 rpf=$v"; done 2>&1 | tee gpurun_out/k_ab_rpf_single.log
+for blk in 640 704 832 896 1024; do HGS_ROW_RPF=1 HGS_ROW_RPF_BLOCKS=$blk python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 rpf blocks=$blk"; done 2>&1 | tee -a gpurun_out/k_ab_rpf_single.log
+for kb in 48 34 48 34; do HGS_ROW_DENSE_LDS_KB=$kb python bench.py --workload cfg3 --steps 100 --warmup 10 --streams 1 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg3 row lds_kb=$kb"; done 2>&1 | tee gpurun_out/k_ab_row4.log
+for kb in 48 34; do HGS_ROW_PREF=0 HGS_ROW_DENSE_LDS_KB=$kb python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 nopref row lds_kb=$kb"; done 2>&1 | tee -a gpurun_out/k_ab_row4.log
