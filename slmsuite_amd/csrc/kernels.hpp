@@ -1964,10 +1964,11 @@ template <int N> struct Tile2Cfg {
 // 4096 rows: the column of the half tile that is NOT being transformed waits in LDS (lane-private slots, six per lane: 12 KB),
 // not in registers -- with both columns resident the NR = 5 / 6 update instances were 4 / 13 registers over the 168 that three
 // workgroups per CU allow (tools/resusage.sh: 20 / 56 bytes of scratch in the headline kernel)
-template <int N> constexpr bool tile2_parks() { return N >= 4096; }
-template <typename R, int N> constexpr size_t col_tile2_lds_bytes() {
+// (PARK is a template argument: a batch of eight, whose 1.4 GB do not fit the Infinity Cache, is 3 - 5 % FASTER with both
+//  columns in registers and the 4 spilled ones -- 354 against 372 us per column launch -- so batches keep that form)
+template <typename R, int N, bool PARK = false> constexpr size_t col_tile2_lds_bytes() {
     return (size_t)Tile2Cfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double) +
-           (tile2_parks<N>() ? (size_t)6 * Tile2Cfg<N>::T * sizeof(Cx<R>) : 0);
+           (PARK ? (size_t)6 * Tile2Cfg<N>::T * sizeof(Cx<R>) : 0);
 }
 
 #ifndef HGS_TILE2_CONS_GROUP
@@ -1975,8 +1976,9 @@ template <typename R, int N> constexpr size_t col_tile2_lds_bytes() {
 #endif
 // (4096 rows: three waves per SIMD = three workgroups per CU, the point of the kernel; 2048 rows: two -- the general
 //  transform keeps 20 stage twiddles and up to ten tile slots, at three it spilled 14 .. 103 VGPRs)
-template <typename R, int N, int PHASE, int NR, int RULE>
+template <typename R, int N, int PHASE, int NR, int RULE, bool PARK = false>
 __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile2_kernel(ColArgs<R> a, int shift, int half_xmap) {
+    static_assert(!PARK || Tile2Cfg<N>::CPAR == 1, "col_tile2_kernel: the parked form is for one lane group per workgroup");
     constexpr int TILE2_CONS_GROUP = HGS_TILE2_CONS_GROUP;
     using M = Math<R>;
     static_assert(sizeof(R) == 4 && (N == 2048 || N == 4096) && (RULE == 1 || RULE == 2), "col_tile2_kernel: fp32, 2048 / 4096 rows, plain rules");
@@ -2009,7 +2011,6 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
     // the half tile, one array per column and component: selected by the (uniform) column of the pass with v_cndmask -- a
     // run-time index into [NR][2] arrays put them on the stack (96 bytes of scratch), unrolling the two passes made the
     // scheduler interleave them (23 .. 187 spilled registers)
-    constexpr bool PARK = tile2_parks<N>();
     R g0x[PARK ? 1 : NR], g0y[PARK ? 1 : NR], g1x[PARK ? 1 : NR], g1y[PARK ? 1 : NR];
     Cx<R>* park = reinterpret_cast<Cx<R>*>(scratch + SCRATCH_DOUBLES) + j;     // PARK: slot m of this lane at park[m * T]
     R wr[16], tr[16];

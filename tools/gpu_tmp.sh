@@ -1,12 +1,13 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-line() { python -c "
+python -m pytest tests/test_full_configs.py tests/test_dispatch.py tests/test_distributed_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "cfg2 or cfg3 or dispatch or batch or dense or distributed" 2>&1 | tail -4
+rm -rf gpurun_out/prof_r05_cfg3 gpurun_out/prof_r05_cfg3_2streams
+prof() { n=$1; shift; bash tools/profile.sh r05_$n "$@" > gpurun_out/prof_$n.log 2>&1; }
+prof cfg3 --workload cfg3 --streams 1; prof cfg3_2streams --workload cfg3
+for i in 1 2; do python bench.py --workload cfg3 --steps 100 --warmup 10 2>/dev/null | grep '^{' > gpurun_out/l_cfg3_$i.json; python -c "
+import json; d=json.load(open('gpurun_out/l_cfg3_$i.json')); r=d['roofline']; print('cfg3', d['value'], r['launch_us'], r['row_kernel']['launch_us'], r['frac'], r.get('traffic'))"; done
+python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']
-        print('$1 it/s %8.0f  col_us %6.2f row_us %6.2f frac %.3f'%(d['value'],r['launch_us'],r['row_kernel']['launch_us'],r['frac']))
-"; }
-for v in 0 1 0 1; do HGS_ROW_RPF=$v python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 rpf=$v"; done 2>&1 | tee gpurun_out/k_ab_rpf_single.log
-for blk in 640 704 832 896 1024; do HGS_ROW_RPF=1 HGS_ROW_RPF_BLOCKS=$blk python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 rpf blocks=$blk"; done 2>&1 | tee -a gpurun_out/k_ab_rpf_single.log
-for kb in 48 34 48 34; do HGS_ROW_DENSE_LDS_KB=$kb python bench.py --workload cfg3 --steps 100 --warmup 10 --streams 1 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg3 row lds_kb=$kb"; done 2>&1 | tee gpurun_out/k_ab_row4.log
-for kb in 48 34; do HGS_ROW_PREF=0 HGS_ROW_DENSE_LDS_KB=$kb python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 nopref row lds_kb=$kb"; done 2>&1 | tee -a gpurun_out/k_ab_row4.log
+        d=json.loads(l); r=d['roofline']; print('cfg2', d['value'], r['launch_us'], r['row_kernel']['launch_us'], r['frac'])"
+sed -n 5,8p gpurun_out/prof_r05_cfg3/summary.md
