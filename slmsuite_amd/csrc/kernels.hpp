@@ -59,6 +59,9 @@
 #ifndef HGS_F64_WT_PREFETCH
 #define HGS_F64_WT_PREFETCH 0   // 1: float64 8192-point fused kernel, one word of each weight / target line requested ahead of the forward
 #endif                          //    transform (L2 prefetch): 737 vs 713 us -- slower
+#ifndef HGS_PF_AHEAD
+#define HGS_PF_AHEAD 1          // per-column kernel, fp32, fixed farfield phase: the stored phase fetched a column ahead with the weights
+#endif
 #ifndef HGS_F64_WT_EARLY
 #define HGS_F64_WT_EARLY 0      // float64 8192-point fused kernel, shifted form: weights / targets requested ahead of the (pruned) forward transform
 #endif
@@ -1207,6 +1210,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
 
     Cx<R> v[16], gn[LEAN ? 1 : 16];
     R wr[16], tr[16];
+    // PHASE 2 (fixed farfield phase, the steady state of WGS-Kim), fp32: the stored phase of a column arrives with its weights
+    // and targets, a column ahead (16 more registers, 189 -> ~205 of 256), instead of being fetched pixel by pixel inside the
+    // constraint -- on a column list (engine default) that fetch sat on the ~12 us chain of the launch (round 5)
+    constexpr bool PF_AHEAD = PHASE == 2 && !LEAN && HGS_PF_AHEAD && HGS_LANE_MAJOR;
+    float4 pfq0 = make_float4(0, 0, 0, 0), pfq1 = pfq0, pfq2 = pfq0, pfq3 = pfq0;      // (four 16-byte registers, not an array: R[16] left 12 bytes on the stack)
 
     auto col_of = [&](int q, int& ct, int& c4) {
         if (listed) {
@@ -1234,12 +1242,17 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         const bool need_t = do_upd || STATS || x_mraf;
         if (col_valid(q)) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = wc[lane_pos<T>(j, m)]; });
+            if constexpr (PF_AHEAD) {        // (a lane's sixteen values are 64 contiguous bytes: lane_pos<T>(j, m) = 16 j + m)
+                const float4* pc = reinterpret_cast<const float4*>(a.pff + cb + lane_pos<T>(j, 0));
+                pfq0 = pc[0]; pfq1 = pc[1]; pfq2 = pc[2]; pfq3 = pc[3];
+            }
             if (need_t) static_for<0, 16>([&](auto m_) { constexpr int m = m_; tr[m] = tc[lane_pos<T>(j, m)]; });
             // (defined on every path: left unset here, the RULE 2 instances kept one of them in scratch -- 12 bytes, a
             //  scratch round trip per column)
             else static_for<0, 16>([&](auto m_) { constexpr int m = m_; tr[m] = (R)0; });
         } else {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = (R)0; tr[m] = (R)0; });
+            if constexpr (PF_AHEAD) pfq0 = pfq1 = pfq2 = pfq3 = make_float4(0, 0, 0, 0);
         }
     };
     // rows outside the SLM (and whole columns past the end of a list) through the range check of a buffer resource
@@ -1371,7 +1384,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             }
             R co, si;
             if constexpr (PHASE == 2) {
-                M::sincos_phase(pfc[idx], &si, &co);
+                if constexpr (PF_AHEAD) {
+                    const float4 qv = (m / 4 == 0) ? pfq0 : (m / 4 == 1) ? pfq1 : (m / 4 == 2) ? pfq2 : pfq3;
+                    M::sincos_phase((R)((m % 4 == 0) ? qv.x : (m % 4 == 1) ? qv.y : (m % 4 == 2) ? qv.z : qv.w), &si, &co);
+                }
+                else M::sincos_phase(pfc[idx], &si, &co);
             } else {
                 if (sizeof(R) == 4 || p2 > (R)0) {         // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
                     const R inv = rsqrt_full(p2);

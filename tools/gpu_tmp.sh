@@ -1,13 +1,14 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python -m pytest tests/test_full_configs.py tests/test_dispatch.py tests/test_distributed_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "cfg2 or cfg3 or dispatch or batch or dense or distributed" 2>&1 | tail -4
-rm -rf gpurun_out/prof_r05_cfg3 gpurun_out/prof_r05_cfg3_2streams
-prof() { n=$1; shift; bash tools/profile.sh r05_$n "$@" > gpurun_out/prof_$n.log 2>&1; }
-prof cfg3 --workload cfg3 --streams 1; prof cfg3_2streams --workload cfg3
-for i in 1 2; do python bench.py --workload cfg3 --steps 100 --warmup 10 2>/dev/null | grep '^{' > gpurun_out/l_cfg3_$i.json; python -c "
-import json; d=json.load(open('gpurun_out/l_cfg3_$i.json')); r=d['roofline']; print('cfg3', d['value'], r['launch_us'], r['row_kernel']['launch_us'], r['frac'], r.get('traffic'))"; done
-python bench.py --steps 200 --warmup 20 --cpu-iters 0 --pmc 0 2>/dev/null | python -c "
+python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "kim or Kim or fixed or fuzz or dispatch" 2>&1 | tail -4
+line() { python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; print('cfg2', d['value'], r['launch_us'], r['row_kernel']['launch_us'], r['frac'])"
-sed -n 5,8p gpurun_out/prof_r05_cfg3/summary.md
+        d=json.loads(l); r=d['roofline']; e=d.get('engine_default_path') or {}
+        print('$1 it/s %8.0f col_us %6.2f row_us %6.2f | default it/s %8.0f col %5.2f row %5.2f'%(d['value'],r['launch_us'],r['row_kernel']['launch_us'],e.get('value',0),e.get('col_kernel_us') or 0,e.get('row_kernel_us') or 0))
+"; }
+for v in nopf main nopf main; do lib=slmsuite_amd/libhgs_$v.so; [ $v = main ] && lib=slmsuite_amd/libhgs.so
+  HGS_LIB=$PWD/$lib python bench.py --method WGS-Kim --steps 200 --warmup 40 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg2 Kim $v"
+  HGS_LIB=$PWD/$lib python bench.py --workload hd --method WGS-Kim --steps 200 --warmup 40 --cpu-iters 0 --pmc 0 2>/dev/null | line "hd Kim $v"
+  HGS_LIB=$PWD/$lib python bench.py --workload cfg1 --method WGS-Kim --steps 400 --warmup 40 --cpu-iters 0 --pmc 0 2>/dev/null | line "cfg1 Kim $v"
+done 2>&1 | tee gpurun_out/m_ab_pf_ahead.log
