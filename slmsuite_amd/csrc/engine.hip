@@ -231,6 +231,7 @@ template <typename R> struct Engine : EngineBase {
     bool have_prev = false;
     int opt_prev_phase = 0;
     int opt_tile2 = 1;                     // developer A/B (HGS_TILE2=0 at create): half-width tile kernel off
+    int opt_tile2_phase2 = 1;              // ... its phase-reading form at 4096 rows, one hologram (HGS_TILE2_PHASE2=0 at create: col_tile_kernel)
     int opt_tile2_min_batch = 1;           // ... smallest batch that runs it at 4096 rows (HGS_TILE2_MIN_BATCH)
     int env_tile2_blocks = 0;              // ... its workgroups per launch over the batch (HGS_TILE2_BLOCKS; 0 = 3 x / 2 x #CU)
     int opt_mono_tab = 1;                  // developer A/B (HGS_MONO_TAB=0 at create): per-pixel compressed kernels evaluate every monomial per spot
@@ -407,6 +408,7 @@ template <typename R> struct Engine : EngineBase {
         opt_keep_g = env_int("HGS_KEEP_G", 1);
         opt_tile2 = env_int("HGS_TILE2", 1);
         opt_tile2_min_batch = env_int("HGS_TILE2_MIN_BATCH", 1);
+        opt_tile2_phase2 = env_int("HGS_TILE2_PHASE2", 1);
         env_tile2_blocks = env_int("HGS_TILE2_BLOCKS", 0);
         opt_tile_shift16 = env_int("HGS_TILE_SHIFT16", 1);
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
@@ -1065,7 +1067,7 @@ template <typename R> struct Engine : EngineBase {
         if (a.cp.do_update && a.cp.method != HGS_WGS_LEONARDO && a.cp.method != HGS_WGS_KIM) return 0;
         const int nr = tile_slots();
         if (g.Ph == 4096) {
-            if (B < opt_tile2_min_batch || phase_mode != 0 || !tile_path || !tile2_has(4096, nr)) return 0;
+            if (B < opt_tile2_min_batch || (phase_mode != 0 && !(phase_mode == 2 && opt_tile2_phase2 && B == 1)) || !tile_path || !tile2_has(4096, nr)) return 0;
             const int per = (env_tile2_blocks > 0 ? env_tile2_blocks : 3 * n_cu) / B;
             return std::max(16, per / 16 * 16);
         }

@@ -2087,11 +2087,26 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
             R* wc = a.w + cb;
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
             bool w_changed = false;
-            R pf[PHASE != 0 ? 16 : 1];
-            if constexpr (PHASE == 2)
-                static_for<0, 16>([&](auto m_) { constexpr int m = m_; pf[m] = pfc[lane_pos<T>(j, m)]; });
+            R pf[PHASE == 1 ? 16 : 1];
+            // PHASE 2: the lane's sixteen stored phases (64 contiguous bytes) in two 16-byte registers that are refilled as they
+            // are used up -- pixels 0-3 / 8-11 from qa, 4-7 / 12-15 from qb -- instead of sixteen live values (the update
+            // instances were 8 .. 12 registers over the 168 of three workgroups per CU)
+            constexpr bool PFQ = PHASE == 2 && HGS_LANE_MAJOR;
+            const float4* pq = PFQ ? reinterpret_cast<const float4*>(pfc + lane_pos<T>(j, 0)) : nullptr;
+            float4 qa = make_float4(0, 0, 0, 0), qb = qa;
+            R pf2[(PHASE == 2 && !PFQ) ? 16 : 1];
+            if constexpr (PFQ) { qa = pq[0]; qb = pq[1]; }
+            else if constexpr (PHASE == 2) static_for<0, 16>([&](auto m_) { constexpr int m = m_; pf2[m] = pfc[lane_pos<T>(j, m)]; });
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = m_;
+                if constexpr (PFQ && m == 4) qa = pq[2];            // (pixels 0-3 are through)
+                if constexpr (PFQ && m == 8) qb = pq[3];
+                R pfm = 0;
+                if constexpr (PFQ) {
+                    const float4 qv = ((m / 4) & 1) ? qb : qa;
+                    // (pixels 4-7 read qb = pq[1], 8-11 qa = pq[2], 12-15 qb = pq[3])
+                    pfm = (m % 4 == 0) ? qv.x : (m % 4 == 1) ? qv.y : (m % 4 == 2) ? qv.z : qv.w;
+                } else if constexpr (PHASE == 2) pfm = pf2[m];
                 // wave-uniform skip where weight and target are zero (see col_tile_kernel)
                 if (PHASE != 1 && HGS_SPARSE_SKIP && __builtin_amdgcn_ballot_w64(wr[m] != (R)0 || tr[m] != (R)0) == 0) {
                     v[m] = mk<R>(0, 0);
@@ -2114,7 +2129,7 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                 Cx<R> ph;
                 if constexpr (PHASE == 2) {
                     R sn, cs;
-                    M::sincos_phase(pf[m], &sn, &cs);
+                    M::sincos_phase(pfm, &sn, &cs);
                     ph = mk<R>(cs, sn);
                 } else {
                     const R inv = rsqrt_full(p2);

@@ -23,8 +23,13 @@ static int launch_tile2_n(int phase, dim3 grid, hipStream_t s, const ColArgs<flo
     if (phase == 0) return launch_tile2_one<N, 0, RULE, NR>(grid, s, a, shift, half_xmap);
     // 4096 rows: the engine sends only passes that neither store nor read the farfield phase here (the phase-storing / -reading
     // update instances do not fit the 168 registers of three workgroups per CU, tools/resusage.sh) -- they are not compiled
-    if constexpr (N >= 4096) return (int)hipErrorInvalidValue;
-    else {
+    if constexpr (N >= 4096) {
+        // ... except the phase-READING form (WGS-Kim with its phase fixed) for ONE hologram: its update instances run 4 / 8 / 12
+        // registers over (parked form) and are still faster than col_tile_kernel's two workgroups per CU -- dense image target
+        // 87.5 -> 76.8 us, spot array 53.5 -> 52.1 us; a batch (register form, 18 .. 35 spilled) loses 15 % and is not sent here
+        if (phase == 2 && grid.y == 1) return launch_tile2_one<N, 2, RULE, NR, true>(grid, s, a, shift, half_xmap);
+        return (int)hipErrorInvalidValue;
+    } else {
     if (phase == 1) return launch_tile2_one<N, 1, RULE, NR>(grid, s, a, shift, half_xmap);
     return launch_tile2_one<N, 2, RULE, NR>(grid, s, a, shift, half_xmap);
     }

@@ -141,8 +141,9 @@ def test_cfg2_kim_every_column_path_matches_reference(path):
     h.optimize("WGS-Kim", maxiter=30, verbose=False)
     d = assert_cfg2_column_path(h, path)
     fam = "col_tile_kernel" if path == "dense" else "col_fused_kernel"
-    # PHASE: 1 = the phase is stored (every free body of WGS-Kim with an update), 2 = the stored phase is used (fixed)
-    assert d.count(fam, PHASE=1) > 0 and d.count(fam, PHASE=2) > 0, d
+    # PHASE: 1 = the phase is stored (every free body of WGS-Kim with an update), 2 = the stored phase is used (fixed) -- on
+    # the dense path the half-width tile kernel since round 5 (three workgroups per CU; its phase-STORING form does not fit)
+    assert d.count(fam, PHASE=1) > 0 and d.count("col_tile2_kernel" if path == "dense" else fam, PHASE=2) > 0, d
     assert [bool(x) for x in h.stats["flags"]["fixed_phase"]] == [bool(x) for x in gold["fixed_history"]]
     ky, kx = h.spot_knm_rounded[1], h.spot_knm_rounded[0]
     errs = dict(spot_amp=rel_l2(h.amp_ff[ky, kx], gold["spot_ampff"]),

@@ -19,11 +19,14 @@ UNITS = ["launch_tile_rule_f32.hip", "launch_tile_list_f32.hip", "launch_tile2_f
 
 # instantiations that keep a few spilled registers, by (kernel, substring of the template arguments)
 KNOWN = {
-    # half-width tile kernel at 2048 rows with ten occupied slots (SLMs of 1153 .. 1280 rows on a 2048 pad) and a stored / read
-    # farfield phase (WGS-Kim): 2 / 8 registers over the 256 of two workgroups per CU.  (At 4096 rows -- the headline kernel
+    # half-width tile kernel at 2048 rows with ten occupied slots (SLMs of 1153 .. 1280 rows on a 2048 pad) and a stored
+    # farfield phase (WGS-Kim before its phase is fixed): 2 registers over the 256 of two workgroups per CU.  (At 4096 rows -- the headline kernel
     # since round 5 -- the idle column of the half tile waits in LDS and every reachable instance is clean.)
     ("col_tile2_kernel", "float, 2048, 1, 10, 1, false"): 2,
-    ("col_tile2_kernel", "float, 2048, 2, 10, 1, false"): 8,
+    # the phase-READING update instances at 4096 rows (WGS-Kim with its phase fixed, one hologram, parked form): 2 / 6 registers
+    # over with five / six occupied slots, and still ahead of col_tile_kernel's two workgroups per CU (dense image 87.5 -> 76.8 us)
+    ("col_tile2_kernel", "float, 4096, 2, 5, 1, true"): 2,
+    ("col_tile2_kernel", "float, 4096, 2, 6, 1, true"): 6,
     # ... and the BATCH form at 4096 rows (both columns of the half tile in registers): 4 / 13 registers over the 168 of three
     # workgroups per CU with five / six occupied slots -- kept because a batch of eight is 3 - 5 % faster with them than with
     # the parked form (354 against 372 us per column launch at cfg 3); single holograms run the parked instances, which are clean
