@@ -2008,6 +2008,13 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
     Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem) + grp * lds_elems<N>();
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<Cx<R>*>(smem) + CPAR * lds_elems<N>());
 
+#if HGS_TRACE
+    {   // (a workgroup of this kernel records fewer than 128 events per wave: clear the rest)
+        unsigned long long* tz = reinterpret_cast<unsigned long long*>(smem + HGS_TRACE_OFF);
+        for (int i = tid; i < ((int)blockDim.x >> 6) * 128; i += blockDim.x) tz[i] = 0ull;
+        __syncthreads();
+    }
+#endif
     using Sel = FftSel<R, N, true>;
     typename Sel::type fft;
     fft.init(a.tw, j);
@@ -2048,9 +2055,14 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
         half = (int)blockIdx.x & 1; ct0 = (int)blockIdx.x >> 1; ct_step = G / 2;
     }
     bool first = true;
+    // (Experiment, removed: the rows of the workgroup's NEXT half tile requested while the second column of the current one is
+    //  transformed back -- tools/microbench/trace_tile2 shows 6.3 k of a workgroup's ~32 k cycles per half tile waiting for its
+    //  rows, which the other two workgroups of the CU cover -- costs 20 registers that stay live across the rolled column loop:
+    //  17 / 31 spilled at five / six slots.)
 #pragma unroll 1
     for (int ct = ct0; ct < ntiles; ct += ct_step) {
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + 2 * half;
+        HGS_T(fft.tr_n, 1);
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
@@ -2063,6 +2075,10 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                 g0x[m] = q.x; g0y[m] = q.y; g1x[m] = q.z; g1y[m] = q.w;
             }
         }
+#if HGS_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        HGS_T(fft.tr_n, 2);
         const int col0 = ct * 4 + 2 * half;
         if (first) {
             issue_wt_loads<R, T>(wbase + (size_t)col0 * g.Ph, tbase + (size_t)col0 * g.Ph, do_upd, j, wr, tr);
@@ -2083,6 +2099,11 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                 }
             }
             fft.template fwd_lead<(NR < 4 ? 4 : NR)>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
+            HGS_T(fft.tr_n, 3);
+#if HGS_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HGS_T(fft.tr_n, 4);
 
             R* wc = a.w + cb;
             R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
@@ -2151,7 +2172,9 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                 if (c == 0 || ct + ct_step < ntiles)
                     issue_wt_loads<R, T>(wbase + (size_t)ncol * g.Ph, tbase + (size_t)ncol * g.Ph, do_upd, j, wr, tr);
             }
+            HGS_T(fft.tr_n, 5);
             fft.template inv_after_fwd_trail<NR>(v, lds, j);
+            HGS_T(fft.tr_n, 6);
             if constexpr (PARK) {
                 if (c == 0) {
                     // column 0 done: its result takes column 1's place in the lane's slots, column 1 moves into the registers
@@ -2190,10 +2213,20 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
             }
         }
     }
+    HGS_T(fft.tr_n, 7);
     if constexpr (do_upd) {
         const double s = block_sum((double)acc_w, scratch);
         if (tid == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
     }
+#if HGS_TRACE
+    __syncthreads();
+    {   // dump this workgroup's events (128 per wave): fpartial doubles as the destination in the microbenchmark
+        const int nev = ((int)blockDim.x >> 6) * 128;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fpartial) + (size_t)blockIdx.x * nev;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + HGS_TRACE_OFF);
+        for (int i = tid; i < nev; i += blockDim.x) dst[i] = src[i];
+    }
+#endif
 }
 
 // =====================================================================================================
