@@ -2066,6 +2066,10 @@ template <typename R> struct Engine : EngineBase {
             // single-pass MRAF: which columns hold a NaN target (the noise part exists only there) -- a fact about the
             // target, scanned once per upload; the dense launches themselves still walk every column
             if (int e = refresh_sparse()) return e;
+        } else if (sizeof(R) == 4 && g.Ph == 4096 && B == 1 && opt_tile2) {
+            // dense launches of one hologram at 4096 rows: how many columns hold anything picks the instance of the half-width
+            // tile kernel (ColArgs::few_active) -- a fact about the target, scanned once per upload
+            if (int e = refresh_sparse()) return e;
         }
         // "computational_spot" statistics on the sparse path: amp_ff is produced on the spot columns dilated
         // by the integration window (col_kernel FWD|STORE over that list) before the fused kernel runs
@@ -2200,6 +2204,7 @@ template <typename R> struct Engine : EngineBase {
                         // half-width tile-resident kernel: batches at 4096 rows (three workgroups per CU), dense launches at
                         // 2048 rows (col_tile2_kernel); plain passes only
                         wpartial_n = t2;
+                        a.few_active = (!sparse_dirty && n_active_min > 0 && n_active_max * 4 <= g.Pw) ? 1 : 0;
                         LCHK(tile2_launch(g.Ph, phase_mode, a.cp.do_update ? 1 : 2, m1 - m0 + 1, dim3(t2, B), stream, a, m0,
                                           (g.Ph >= 4096 && t2 % 16 == 0) ? 1 : 0));
                     } else if (tile_path) {

@@ -976,6 +976,7 @@ template <typename R> struct ColArgs {
     const int* col_list;   // [batch][Pw] compacted active columns
     const int* n_active;   // [batch]
     // fused kernels only: statistics of this iteration (hgs_iterate_stats)
+    int few_active;        // at most a quarter of the farfield columns hold a non-zero weight or target (col_tile2_kernel NXF)
     int fnr;               // col_fused_kernel: register slots the shifted SLM rows occupy (0 = the unshifted kernel, NRS = 16)
     int fshift;            // col_fused_kernel<..., NRS < 16> (float64, >= 4096 rows): circular shift of the transform input, a
                            // multiple of 16 rows (shift theorem, as in col_tile_kernel): the SLM rows occupy slots 0 .. NRS - 1
@@ -1993,8 +1994,9 @@ template <typename R, int N, bool PARK = false> constexpr size_t col_tile2_lds_b
 #endif
 // (4096 rows: three waves per SIMD = three workgroups per CU, the point of the kernel; 2048 rows: two -- the general
 //  transform keeps 20 stage twiddles and up to ten tile slots, at three it spilled 14 .. 103 VGPRs)
-template <typename R, int N, int PHASE, int NR, int RULE, bool PARK = false>
+template <typename R, int N, int PHASE, int NR, int RULE, bool PARK = false, bool NXF = false>
 __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile2_kernel(ColArgs<R> a, int shift, int half_xmap) {
+    static_assert(!NXF || (PARK && PHASE == 0 && NR <= 5), "col_tile2_kernel: NXF is for the plain parked instances with at most five slots");
     static_assert(!PARK || Tile2Cfg<N>::CPAR == 1, "col_tile2_kernel: the parked form is for one lane group per workgroup");
     constexpr int TILE2_CONS_GROUP = HGS_TILE2_CONS_GROUP;
     using M = Math<R>;
@@ -2055,6 +2057,14 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
         half = (int)blockIdx.x & 1; ct0 = (int)blockIdx.x >> 1; ct_step = G / 2;
     }
     bool first = true;
+    // PARK: the rows of the workgroup's NEXT half tile are requested BEFORE the stores of the current one (vmcnt retires in order:
+    // behind the stores, the wait for the new rows also waited for the stores to be acknowledged -- tools/microbench/trace_tile2:
+    // 6.3 k cycles per half tile); they travel in the registers the finished tile has just freed
+    // (NXF, a template argument: plain instances with at most five slots -- the phase-reading ones and six slots have no 20
+    //  registers to lend -- and targets with few active columns: spot array 45.6 -> 44.8 us, but a dense image, whose constraint
+    //  runs in every wave and wants the registers, 65.1 -> 67.1 us)
+    float4 nq[NXF ? NR : 1];
+    bool have_nq = false;
     // (Experiment, removed: the rows of the workgroup's NEXT half tile requested while the second column of the current one is
     //  transformed back -- tools/microbench/trace_tile2 shows 6.3 k of a workgroup's ~32 k cycles per half tile waiting for its
     //  rows, which the other two workgroups of the CU cover -- costs 20 registers that stay live across the rolled column loop:
@@ -2067,6 +2077,8 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
             float4 q = make_float4(0, 0, 0, 0);
+            if (NXF && have_nq) q = nq[NXF ? m : 0];
+            else
             if (r >= 0 && r < g.Sh) q = *reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
             if constexpr (PARK) {           // column 0 straight into the transform registers, column 1 waits in LDS
                 v[m] = mk<R>(q.x * sgs, q.y * sgs);
@@ -2185,16 +2197,7 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                         park[m * T] = h;
                         v[m] = nx * sgs;
                     }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < NR; ++m) {
-                        const int r = r_lane + m * T;
-                        const Cx<R> h1 = v[m] * (sgs * a.scale);
-                        const Cx<R> h0 = park[m * T];
-                        if (r >= 0 && r < g.Sh)
-                            *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = make_float4(h0.x, h0.y, h1.x, h1.y);
-                    }
-                }
+                }           // (c == 1: the second column's result stays in v for the code after the loop)
             } else {
 #pragma unroll
                 for (int m = 0; m < NR; ++m) {
@@ -2210,6 +2213,29 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                 const int r = r_lane + m * T;
                 if (r >= 0 && r < g.Sh)
                     *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = make_float4(g0x[m], g0y[m], g1x[m], g1y[m]);
+            }
+        } else {
+            float4 outq[NR];
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const Cx<R> h1 = v[m] * (sgs * a.scale);
+                const Cx<R> h0 = park[m * T];
+                outq[m] = make_float4(h0.x, h0.y, h1.x, h1.y);
+            }
+            have_nq = NXF && ct + ct_step < ntiles;
+            if (NXF && have_nq) {
+                const Cx<R>* ghn = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)(ct + ct_step) * g.Sh * 4 + 2 * half;
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const int r = r_lane + m * T;
+                    nq[NXF ? m : 0] = make_float4(0, 0, 0, 0);
+                    if (r >= 0 && r < g.Sh) nq[NXF ? m : 0] = *reinterpret_cast<const float4*>(ghn + (unsigned)r * 4u);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const int r = r_lane + m * T;
+                if (r >= 0 && r < g.Sh) *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = outq[m];
             }
         }
     }

@@ -4,22 +4,28 @@
 
 namespace hgs {
 
-template <int N, int PHASE, int RULE, int NR, bool PARK = false>
+template <int N, int PHASE, int RULE, int NR, bool PARK = false, bool NXF = false>
 static int launch_tile2_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int shift, int half_xmap) {
     constexpr size_t lds = col_tile2_lds_bytes<float, N, PARK>();
-    auto k = col_tile2_kernel<float, N, PHASE, NR, RULE, PARK>;
+    auto k = col_tile2_kernel<float, N, PHASE, NR, RULE, PARK, NXF>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dispatch_note(dispatch_site<KTile2, float, N, PHASE, NR, RULE, PARK>(), col_flags(grid, a) | (half_xmap ? DF_XMAP : 0u));
+    dispatch_note(dispatch_site<KTile2, float, N, PHASE, NR, RULE, PARK, NXF>(), col_flags(grid, a) | (half_xmap ? DF_XMAP : 0u));
     hipLaunchKernelGGL(k, grid, dim3(Tile2Cfg<N>::WG), lds, s, a, shift, half_xmap);
     return (int)hipGetLastError();
 }
 template <int N, int RULE, int NR>
 static int launch_tile2_n(int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int shift, int half_xmap) {
     // 4096 rows, one hologram: the idle column of the half tile parked in LDS (no scratch); batches: both columns in registers
-    if constexpr (N >= 4096) { if (phase == 0 && grid.y == 1) return launch_tile2_one<N, 0, RULE, NR, true>(grid, s, a, shift, half_xmap); }
+    if constexpr (N >= 4096) {
+        if (phase == 0 && grid.y == 1) {
+            // few active columns (a spot array with every column forced): the next half tile's rows requested ahead of the stores
+            if constexpr (NR <= 5) { if (a.few_active) return launch_tile2_one<N, 0, RULE, NR, true, true>(grid, s, a, shift, half_xmap); }
+            return launch_tile2_one<N, 0, RULE, NR, true>(grid, s, a, shift, half_xmap);
+        }
+    }
     if (phase == 0) return launch_tile2_one<N, 0, RULE, NR>(grid, s, a, shift, half_xmap);
     // 4096 rows: the engine sends only passes that neither store nor read the farfield phase here (the phase-storing / -reading
     // update instances do not fit the 168 registers of three workgroups per CU, tools/resusage.sh) -- they are not compiled

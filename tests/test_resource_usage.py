@@ -22,16 +22,16 @@ KNOWN = {
     # half-width tile kernel at 2048 rows with ten occupied slots (SLMs of 1153 .. 1280 rows on a 2048 pad) and a stored
     # farfield phase (WGS-Kim before its phase is fixed): 2 registers over the 256 of two workgroups per CU.  (At 4096 rows -- the headline kernel
     # since round 5 -- the idle column of the half tile waits in LDS and every reachable instance is clean.)
-    ("col_tile2_kernel", "float, 2048, 1, 10, 1, false"): 2,
+    ("col_tile2_kernel", "float, 2048, 1, 10, 1, false, false"): 2,
     # the phase-READING update instances at 4096 rows (WGS-Kim with its phase fixed, one hologram, parked form): 2 / 6 registers
     # over with five / six occupied slots, and still ahead of col_tile_kernel's two workgroups per CU (dense image 87.5 -> 76.8 us)
-    ("col_tile2_kernel", "float, 4096, 2, 5, 1, true"): 2,
-    ("col_tile2_kernel", "float, 4096, 2, 6, 1, true"): 6,
+    ("col_tile2_kernel", "float, 4096, 2, 5, 1, true, false"): 2,
+    ("col_tile2_kernel", "float, 4096, 2, 6, 1, true, false"): 6,
     # ... and the BATCH form at 4096 rows (both columns of the half tile in registers): 4 / 13 registers over the 168 of three
     # workgroups per CU with five / six occupied slots -- kept because a batch of eight is 3 - 5 % faster with them than with
     # the parked form (354 against 372 us per column launch at cfg 3); single holograms run the parked instances, which are clean
-    ("col_tile2_kernel", "float, 4096, 0, 5, 1, false"): 4,
-    ("col_tile2_kernel", "float, 4096, 0, 6, 1, false"): 13,
+    ("col_tile2_kernel", "float, 4096, 0, 5, 1, false, false"): 4,
+    ("col_tile2_kernel", "float, 4096, 0, 6, 1, false, false"): 13,
     # unshifted 8192-wide rows (an SLM wider than 4096 columns on an 8192 pad): 8 VGPRs over the 128 that let two
     # 512-lane workgroups share a CU; one workgroup per CU costs 25 % of the launch, the spills do not
     ("row_kernel", "float, 8192, 2, 16, false, false"): 8,
@@ -100,7 +100,8 @@ def test_hot_kernels_do_not_spill():
     # the named kernels of VERDICT round 4: the phase-storing rule kernels and the narrow phase-extracting row kernel
     for key in (("col_tile_kernel", "float, 4096, 1, 6, false, false, 1, 0"), ("col_tile_kernel", "float, 8192, 1, 6, false, false, 1, 0"),
                 ("col_tile_kernel", "float, 4096, 1, 5, false, false, 1, 0"), ("row_kernel", "float, 128, 1, 16, false, false"),
-                ("col_tile2_kernel", "float, 4096, 0, 5, 1, true"), ("col_tile2_kernel", "float, 4096, 0, 6, 1, true")):       # the headline kernel (round 5)
+                ("col_tile2_kernel", "float, 4096, 0, 5, 1, true, true"), ("col_tile2_kernel", "float, 4096, 0, 5, 1, true, false"),
+                ("col_tile2_kernel", "float, 4096, 0, 6, 1, true, false")):       # the headline kernel (round 5)
         assert key in seen and key not in KNOWN, key
     stale = [k for k in KNOWN if k not in seen]
     assert not stale, stale
