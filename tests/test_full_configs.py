@@ -431,7 +431,7 @@ def test_cfg4_configured_run_reaches_its_end_state():
     # the two arithmetics part no faster than one of them parts from itself under a one-ulp change of the input (x 20:
     # the perturbation is one rounding, the paths differ by a few per operator)
     # (measured: 1.7e-5 between the arithmetics, 6.7e-7 for the one-ulp change, 1.4e-3 for the 12 + 2 call split)
-    assert e_paths["spot_amp"] < 50 * max(e_ulp["spot_amp"], 1e-6), (e_paths, e_ulp)
+    assert e_paths["spot_amp"] < 35 * max(e_ulp["spot_amp"], 1e-6), (e_paths, e_ulp)      # (26 x in rounds 4 and 5; the factor was 50 until round 5)
     assert err_end < 2e-5
     assert u200 > u12, (u12, u200)
     h._release_engine()
