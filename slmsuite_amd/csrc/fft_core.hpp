@@ -413,9 +413,24 @@ template <int N> constexpr int lds_elems() { return N == 8192 ? 2 * (16 * 272 + 
 //                   many transforms per workgroup (the column kernels).
 // RESIDENT = false: they are fetched from the (L1/L2-resident) table right before each use, which
 //                   frees ~24 VGPRs -- for kernels that are occupancy-bound (the row kernels).
+#ifndef HGS_WAVE_LOCAL_BARRIER
+#define HGS_WAVE_LOCAL_BARRIER 1
+#endif
 template <typename R, int N, bool RESIDENT = true> struct WgFft {
     static constexpr int E = 16;
     static constexpr int T = N / 16;
+    // the rendezvous between the write and the read side of an exchange.  Up to 1024 points a transform is owned by ONE wave (or
+    // part of one: T <= 64 lanes, its own LDS image), so nothing crosses waves and a workgroup barrier only couples the
+    // independent transforms of the workgroup to each other (round 5: eight s_barrier per fused pass of the small grids --
+    // the reference's own 512^2 / 1024^2 cases -- gone; LDS operations of one wave execute in issue order)
+    static __device__ __forceinline__ void xbar() {
+        if constexpr (T <= 64 && HGS_WAVE_LOCAL_BARRIER) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    }
     static constexpr int NTW = RESIDENT ? (tw_count<N>() > 0 ? tw_count<N>() : 1) : 1;
     Cx<R> tw[NTW];
     const Cx<R>* table_ = nullptr;
@@ -545,14 +560,14 @@ template <typename R, int N, bool RESIDENT = true> struct WgFft {
             }
         });
         if constexpr (s != Sched<N>::S - 1 && !HGS_ABL_XCHG) {
-            __syncthreads();
+            xbar();
             if constexpr (T % 16 == 0) {
                 const Cx<R>* p = lds + lds_pad(j);
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = p[m * (T + T / 16)]; });
             } else {
                 static_for<0, 16>([&](auto m_) { constexpr int m = m_; v[m] = lds[lds_pad(j + m * T)]; });
             }
-            if constexpr (!DB) __syncthreads();
+            if constexpr (!DB) xbar();
         }
     }
 
