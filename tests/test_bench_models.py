@@ -16,9 +16,9 @@ from benchlib import workloads as W                                    # noqa: E
 from benchlib.byte_models import canonical_bytes, grid_bytes_models, tile_slots   # noqa: E402
 
 
-def _lines():
+def _lines(rnd="r04"):
     out = []
-    for line in open(os.path.join(ROOT, "profiles", "r04", "configs.jsonl")):
+    for line in open(os.path.join(ROOT, "profiles", rnd, "configs.jsonl")):
         d = json.loads(line)
         text = d["config"]["workload"]
         key = text.split(":")[0]
@@ -58,6 +58,20 @@ def test_models_reproduce_the_recorded_lines_and_the_measured_traffic(line):
     tr_row = roof["row_kernel"].get("traffic")
     if tr_row:
         assert abs(tr_row / m["row"] - 1) < (0.25 if key == "cfg3" else 0.10), tr_row / m["row"]
+
+
+@pytest.mark.parametrize("line", _lines("r05"), ids=[f"r05-{l[0]}-{l[1]}-{l[2]}-b{l[3]}s{l[4]}" for l in _lines("r05")])
+def test_models_reproduce_round_5_lines_and_traffic(line):
+    """The same models against the lines of round 5 (profiles/r05/configs.jsonl): other kernels moved the same bytes -- the
+    half-width tile kernel at 4096 / 2048 rows (whose PMC traffic bench.py finds since round 5), the shifted float64 kernel."""
+    key, method, dtype, batch, streams, roof = line
+    m = _model(key, method, dtype, batch, streams)
+    assert m["col"] == roof["bytes_per_launch"], (m["col"], roof["bytes_per_launch"])
+    assert m["row"] == roof["row_kernel"]["bytes_per_launch"]
+    if roof.get("traffic"):
+        # (cfg 3: the two halves of a tile meet in one L2 less reliably when 1.4 GB stream through it: 1.07 measured)
+        band = 0.10 if dtype == "f64" or key in ("cfg1", "cfg3") else 0.05
+        assert abs(roof["traffic"] / m["col"] - 1) < band, roof["traffic"] / m["col"]
 
 
 def test_canonical_counts_are_surveys():
