@@ -210,9 +210,10 @@ int hgs_sync(hgs_engine* e);
  *   a two-term recurrence instead of evaluating the polynomial, sin and cos per pixel; 0 forces the per-pixel kernels.
  * Options are per engine and take effect at the next call; nothing is read from the environment after
  * hgs_create (which reads the developer overrides once: the grid sizes HGS_ROW_BLOCKS / HGS_COL_BLOCKS / HGS_TILE_BLOCKS /
- * HGS_ROW_PREF_BLOCKS, and the A/B switches HGS_ROW_XCD, HGS_COL_XMAP, HGS_ROW_SHIFT, HGS_ROW_PREF, HGS_TILE_RULE, HGS_MRAF_SPLIT, HGS_TILE_LIST,
- * HGS_TILE_SHIFT16, HGS_TILE_NR4, HGS_KEEP_G, HGS_FUSED_SHIFT -- all default to the
- * tuned path).
+ * HGS_TILE2_BLOCKS / HGS_ROW_PREF_BLOCKS, and the A/B switches HGS_ROW_XCD, HGS_COL_XMAP, HGS_ROW_SHIFT, HGS_ROW_SHIFT64, HGS_ROW_PREF,
+ * HGS_ROW_PREF_BATCH, HGS_TILE_RULE, HGS_MRAF_SPLIT, HGS_MRAF_SPLIT64, HGS_GH2_MASK, HGS_TILE_LIST, HGS_TILE_SHIFT16, HGS_TILE_NR4,
+ * HGS_TILE2, HGS_TILE2_MIN_BATCH, HGS_TILE2_PHASE2, HGS_KEEP_G, HGS_FUSED_SHIFT, HGS_MONO_TAB -- all default to the tuned path;
+ * HGS_TRACE_INIT=1 prints where hgs_create spends its time).
  * HGS_OPT_ROCTX (default 0): roctx ranges (hgs_iterate, hgs_nearfield2farfield, hgs_farfield_constraint,
  *   hgs_farfield2nearfield) for rocprofv3 --marker-trace; the roctx library is dlopen'ed on first use.
  * HGS_OPT_KEEP_PREV_PHASE (default 0): a fused hgs_iterate / hgs_iterate_stats call of ONE iteration that rewrites the
