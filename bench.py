@@ -134,6 +134,10 @@ def parse():
     ap.add_argument("--pmc", type=int, default=None, help="1: measure roofline.traffic with rocprofv3 PMC child passes "
                                                           "(default: on for one rank, off otherwise)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    # test infrastructure (tests/test_host_logic.py): the rank protocol -- self-launch, barriers, the solo pass of rank 0, the
+    # gather and the fields derived from them -- on a box without a GPU, against a stand-in that sleeps instead of
+    # launching kernels.  The line says so in `metric` and `stub_engine`; nothing it reports is a measurement.
+    ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--opt", action="append", default=[], help="engine option NAME=VALUE (hgs_set_option), e.g. "
                                                                "TILE_KERNEL=0")
     a = ap.parse_args()
@@ -141,6 +145,8 @@ def parse():
         ap.error("--gpus must be >= 1")
     if a.share_devices and a.backend != "gloo":
         ap.error("--share-devices needs --backend gloo (RCCL refuses two ranks on one device)")
+    if a.stub_engine and not (a.backend == "gloo" and a.share_devices and a.no_roofline_pass):
+        ap.error("--stub-engine is the CPU self-test of the rank protocol: --backend gloo --share-devices --no-roofline-pass")
     if a.workload is None:
         a.workload = "cfg2" if a.gpus == 1 else "cfg3"
     if a.steps is None:
@@ -162,6 +168,37 @@ def parse():
 # ---------------------------------------------------------------------------------------------------
 # problems: each exposes warm(n), run(n) -> milliseconds (HIP events on the engine stream), engine
 # ---------------------------------------------------------------------------------------------------
+class StubProblem:
+    """--stub-engine: the interface of the problems below with nothing behind it (a step is a sleep, the phase masks are a
+    host tensor that names the rank).  For the CPU test of the rank protocol only."""
+    STEP_S = 2e-4
+
+    class _Engine:
+        def sync(self): pass
+        def version(self): return "stub (no device, no kernels)"
+        def set_option(self, *a): pass
+
+    def __init__(self, args, rank, local_rank):
+        self.args, self.rank = args, rank
+        self.engine = self._Engine()
+        self.shape, self.slm = (64, 64), (16, 24)
+        self.desc = "STUB ENGINE"
+        self.mraf = False
+
+    def warm(self, n):
+        pass
+
+    def run(self, n):
+        time.sleep(self.STEP_S * n * self.args.batch)
+        return self.STEP_S * n * self.args.batch * 1e3
+
+    def phases_device(self, torch, device):
+        return torch.full((self.args.batch,) + self.slm, float(self.rank), dtype=torch.float32)
+
+    def close(self):
+        pass
+
+
 class GridProblem:
     """DFT-grid workloads through HologramBatch (one engine, --batch holograms in grid.y)."""
 
@@ -473,9 +510,11 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the line would report the wrong "
                          f"number of GPUs (launch {args.gpus} ranks, or let bench.py launch them itself)")
     import torch
-    if not torch.cuda.is_available():
+    stub = args.stub_engine
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    n_dev = torch.cuda.device_count()
+    n_dev = 1 if stub else torch.cuda.device_count()
+    cuda_sync = (lambda: None) if stub else torch.cuda.synchronize
     if args.share_devices:
         local_rank %= n_dev
     elif local_rank >= n_dev:
@@ -488,7 +527,8 @@ def main():
         import torch.distributed as dist
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)         # --force-dist outside a launcher: a one-rank group
-        torch.cuda.set_device(local_rank)
+        if not stub:
+            torch.cuda.set_device(local_rank)
         # The process group the timed regions see is gloo: the barriers of the protocol are host rendezvous (every rank has
         # synchronised its engine streams before it arrives) and the scalars of the max-over-ranks are host numbers.  RCCL
         # carries what north_star gives it -- the gather of the phase masks -- and its communicator is created only then:
@@ -505,7 +545,7 @@ def main():
 
     compressed = args.workload in COMPRESSED_WORKLOADS
     refbench = args.workload == "refbench"
-    prob = (CompressedProblem if compressed else RefBenchProblem if refbench else GridProblem)(args, rank, local_rank)
+    prob = (StubProblem if stub else CompressedProblem if compressed else RefBenchProblem if refbench else GridProblem)(args, rank, local_rank)
     apply_opts(prob.engine, args.opt)
     # targets with empty farfield columns (spot arrays; the zero frame outside an MRAF noise box): the engine would
     # skip those columns, the byte model of the roofline counts all of them - time the dense kernels, report the
@@ -524,11 +564,12 @@ def main():
         prob.close()
         return
     # timed region, --reps times: EXACTLY K steps between barrier + synchronize, the slowest rank counts
-    def timed_region(pb):
+    # (alone: this rank by itself -- no barrier, nobody else's time -- while the others wait, see single_rank_same_job)
+    def timed_region(pb, alone=False):
         def sync_all():
             pb.engine.sync()
-            torch.cuda.synchronize()
-            if dist is not None:
+            cuda_sync()
+            if dist is not None and not alone:
                 dist.barrier(group=ctl)
         ws, evs, rws = [], [], []
         for _ in range(args.reps):
@@ -537,7 +578,7 @@ def main():
             ms_ev = pb.run(args.steps)
             sync_all()
             mine = time.perf_counter() - t0
-            if dist is not None:        # the slowest rank counts
+            if dist is not None and not alone:        # the slowest rank counts
                 tmax = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
                 every = [torch.zeros_like(tmax) for _ in range(world)]
                 dist.all_gather(every, tmax, group=ctl)
@@ -549,13 +590,25 @@ def main():
         mid_ = sorted(range(args.reps), key=lambda i: ws[i])[len(ws) // 2]
         return ws, evs, rws, mid_
 
+    # Several ranks: first rank 0 ALONE on its own shard -- the very job it runs in the all-rank regions, the other ranks idle
+    # at a barrier -- so that this one line carries its own scaling figure: `scaling_efficiency` = value / (N x that rate).
+    # (The N = 1 line of the same bench is another workload by default -- cfg 2, one hologram -- and another process.)
+    solo = None
+    if world > 1 and dist is not None and not args.no_extra_pass:
+        if rank == 0:
+            ws_, _, _, m_ = timed_region(prob, alone=True)
+            solo = {"value": args.batch * args.steps / ws_[m_], "unit": "iterations/s", "ms_per_step": ws_[m_] * 1e3 / args.steps,
+                    "what": "rank 0 alone on its shard of the job (same holograms, steps and repetitions; the other ranks wait at a "
+                            "barrier), timed before the all-rank regions"}
+        dist.barrier(group=ctl)
+
     walls, events, rank_walls, mid = timed_region(prob)
     wall, ms_events = walls[mid], events[mid]
 
     # several ranks on the default workload (cfg 3: eight holograms per GPU): the one-hologram-per-GPU rate as well, i.e.
     # the N = 1 default workload (cfg 2) on every rank, so that a scaling figure on EQUAL per-GPU work can be formed
     one_per_gpu = None
-    if world > 1 and args.workload == "cfg3" and args.batch != 1 and not args.no_extra_pass:
+    if world > 1 and args.workload == "cfg3" and args.batch != 1 and not args.no_extra_pass and not stub:
         a1 = argparse.Namespace(**vars(args))
         a1.workload, a1.batch, a1.streams = "cfg2", 1, 1
         p1 = GridProblem(a1, rank, local_rank)
@@ -754,6 +807,12 @@ def main():
             line["per_rank_its"] = [args.batch * args.steps / t for t in med]
         if one_per_gpu is not None:
             line["one_hologram_per_gpu"] = one_per_gpu
+        if solo is not None:
+            line["single_rank_same_job"] = solo
+            line["scaling_efficiency"] = value / (world * solo["value"])
+        if stub:
+            line["metric"] = "STUB ENGINE -- rank-protocol self-test, not a measurement"
+            line["stub_engine"] = True
         if args.share_devices:
             line["launcher_self_test"] = (f"{world} ranks share {n_dev} device(s) over {args.backend}: exercises the launcher and the "
                                           "collectives, NOT a scaling measurement")
@@ -803,7 +862,7 @@ def main():
                         data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
                     except TypeError:          # (older torch: no device_id argument)
                         data_group = dist.new_group(backend="nccl")
-                torch.cuda.synchronize()
+                cuda_sync()
                 dist.barrier(group=ctl)
                 t1 = time.perf_counter()
                 ph = prob.phases_device(torch, local_rank)
@@ -811,7 +870,7 @@ def main():
                     ph = ph.cpu()
                 out = [torch.empty_like(ph) for _ in range(world)]
                 dist.all_gather(out, ph, group=data_group)
-                torch.cuda.synchronize()
+                cuda_sync()
                 gather_ms = (time.perf_counter() - t1) * 1e3
                 # every rank must now hold every rank's masks: finite, and its own shard back unchanged
                 ok = all(bool(torch.isfinite(o).all().item()) for o in out) and bool(torch.equal(out[rank], ph))
@@ -833,6 +892,16 @@ def main():
                 line["process_group"] = group_info      # read back from the group: backend ("nccl" = RCCL), ranks, device per rank
                 line["rccl_ranks"] = group_info["ranks"] if group_info["backend"] == "nccl" else 0
             line["gathered"] = gathered
+            if gather_ms is not None:
+                # "cfg3 reports aggregate it/s = sum over GPUs of (holograms x iterations) / wall-time, including the
+                # final RCCL gather".  `value` is the rate of the K-step regions; here the gather is charged once to the region
+                # (K steps) and once to the job as BASELINE configures it (50 iterations per hologram).
+                its = world * args.batch
+                line["value_including_gather"] = {
+                    "value": its * args.steps / (wall + gather_ms * 1e-3), "unit": "iterations/s",
+                    "what": f"{args.steps} steps per hologram + one all-gather of the phase masks",
+                    "job_of_50_iterations": its * 50 / (50 * wall / args.steps + gather_ms * 1e-3),
+                    "gather_ms": gather_ms}
     if rank == 0:
         print(json.dumps(line), flush=True)
     prob.close()

@@ -202,7 +202,8 @@ int hgs_sync(hgs_engine* e);
  *   transformed separately and joined by the row kernel once ||w'|| is known), two passes elsewhere.
  * HGS_OPT_FORCE_STEPWISE (default 0): hgs_iterate / hgs_iterate_stats loop the three general operators
  *   (materialised farfield) even where a fused kernel exists -- the reference's own op sequence; used by tests.
- * HGS_OPT_TILE_KERNEL (default 1): use the tile-resident fused column kernel where it applies (fp32, pad_h >= 4096).
+ * HGS_OPT_TILE_KERNEL (default 1): use the tile-resident fused column kernels where they apply (fp32: col_tile_kernel at
+ *   pad_h >= 4096, the half-width col_tile2_kernel at pad_h = 4096 and 2048); 0 forces the per-column kernel at every size.
  * HGS_OPT_SEPARABLE (default 1), HGS_OPT_SEPARABLE_MIN_SPOTS (default 96): kind 1, run the two transforms as
  *   complex GEMMs on the matrix cores when the basis and the grid factorise; 0 forces the direct kernels.
  * HGS_OPT_RUN_KERNELS (default 1): kind 1, fp32, regular pixel grid and a phase polynomial of degree <= 2 (any basis of
@@ -214,6 +215,11 @@ int hgs_sync(hgs_engine* e);
  * HGS_ROW_PREF_BATCH, HGS_TILE_RULE, HGS_MRAF_SPLIT, HGS_MRAF_SPLIT64, HGS_GH2_MASK, HGS_TILE_LIST, HGS_TILE_SHIFT16, HGS_TILE_NR4,
  * HGS_TILE2, HGS_TILE2_MIN_BATCH, HGS_TILE2_PHASE2, HGS_KEEP_G, HGS_FUSED_SHIFT, HGS_MONO_TAB -- all default to the tuned path;
  * HGS_TRACE_INIT=1 prints where hgs_create spends its time).
+ *   HGS_KEEP_G (default 1): the last row launch of a float32 hgs_iterate call leaves G of the next body behind, and the next
+ *   call -- or hgs_nearfield2farfield -- on an unchanged phase starts from it.  That G is the loop's own un-rounded phasor
+ *   amp * nf / |nf|, not exp(i * HGS_PHASE) of the rounded, stored phase: the trailing transform is consistent with the loop
+ *   (a loop cut into calls walks bit for bit like one call) rather than bit-identical with a fresh engine given the
+ *   downloaded phase; the two agree to float32 rounding (tests/test_gpu_round6.py, 2e-6 on the farfield).
  * HGS_OPT_ROCTX (default 0): roctx ranges (hgs_iterate, hgs_nearfield2farfield, hgs_farfield_constraint,
  *   hgs_farfield2nearfield) for rocprofv3 --marker-trace; the roctx library is dlopen'ed on first use.
  * HGS_OPT_KEEP_PREV_PHASE (default 0): a fused hgs_iterate / hgs_iterate_stats call of ONE iteration that rewrites the

@@ -1062,18 +1062,22 @@ template <typename R> struct Engine : EngineBase {
     //              per hologram so that the two halves of a tile run on one XCD together;
     //   2048 rows: SLM rows within ten slots -- 2 x #CU workgroups of two lane groups, one tile each at a time.
     int tile2_grid(bool sp, bool tile_path, const ColArgs<R>& a, int phase_mode) const {
-        if (sizeof(R) != 4 || !opt_tile2 || sp || a.do_stats || !opt_tile_rule) return 0;
+        // (HGS_OPT_TILE_KERNEL = 0 forces the per-column kernel at every size: the tests' A/B reference)
+        if (sizeof(R) != 4 || !opt_tile2 || !opt_tile || sp || a.do_stats || !opt_tile_rule) return 0;
         if (a.cp.mraf || a.cp.nog_pass || a.cp.weights_only || a.cp.nog != nullptr) return 0;
         if (a.cp.do_update && a.cp.method != HGS_WGS_LEONARDO && a.cp.method != HGS_WGS_KIM) return 0;
         const int nr = tile_slots();
+        // the developer override HGS_TILE2_BLOCKS never exceeds what wpartial / the statistics partials are sized for
+        // (B * max(col_blocks, tile_blocks, 3 * #CU) entries) nor the number of half tiles there are
+        const int want = env_tile2_blocks > 0 ? std::min(env_tile2_blocks, 3 * n_cu) : 0;
         if (g.Ph == 4096) {
             if (B < opt_tile2_min_batch || (phase_mode != 0 && !(phase_mode == 2 && opt_tile2_phase2 && B == 1)) || !tile_path || !tile2_has(4096, nr)) return 0;
-            const int per = (env_tile2_blocks > 0 ? env_tile2_blocks : 3 * n_cu) / B;
-            return std::max(16, per / 16 * 16);
+            const int per = (want > 0 ? want : 3 * n_cu) / B;
+            return std::min(std::max(16, per / 16 * 16), std::max(16, g.Pw / 2 / 16 * 16));
         }
         if (g.Ph == 2048) {
             if (!tile2_has(2048, nr)) return 0;
-            return std::max(1, std::min(g.Pw / 4, (env_tile2_blocks > 0 ? env_tile2_blocks : 2 * n_cu) / B));
+            return std::max(1, std::min(g.Pw / 4, (want > 0 ? want : 2 * n_cu) / B));
         }
         return 0;
     }

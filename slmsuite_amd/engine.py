@@ -73,6 +73,16 @@ class Engine:
         L.check(self.lib.hgs_get_array(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
+    def try_get(self, which):
+        """``get`` that returns None where the engine holds no such array yet (HGS_ERR_STATE) instead of raising."""
+        out = np.empty((self.batch,) + (self.slm_shape if which == L.PHASE else self.shape),
+                       dtype=self.ctype if which in (L.FARFIELD, L.ZERO_WEIGHTS) else self.dtype)
+        code = self.lib.hgs_get_array(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
+        if code == L.HGS_ERR_STATE:
+            return None
+        L.check(code)
+        return out
+
     def get_prev_phase(self):
         """HGS_PHASE_PREV (HGS_OPT_KEEP_PREV_PHASE): the phase the last one-iteration fused call started from, or None when
         the engine holds none (the general operators ran -- HGS_PHASE_FF itself is up to date then -- or nothing ran yet)."""

@@ -764,6 +764,19 @@ class Hologram:
         phase the body started from instead (HGS_OPT_KEEP_PREV_PHASE) and its farfield phase is formed here on demand.
         """
         state = self._midloop
+        # A phase the callback has just assigned is NOT what these arrays describe: the reference formed them before it
+        # called the callback (:1465-1477), and the body overwrites such a phase anyway (optimize_gs discards the pending
+        # upload after the callback).  Hold the upload back, so that the result does not depend on whether -- or in which
+        # order -- the callback looked at the farfield.
+        held = "phase" in self._upload
+        self._upload.discard("phase")
+        try:
+            self._midloop_materialise_held(name, state)
+        finally:
+            if held:
+                self._upload.add("phase")
+
+    def _midloop_materialise_held(self, name, state):
         e = self._get_engine()
         if self.__dict__.get("_populate_pending"):
             # first invocation of this call and nobody has looked at the previous call's results yet: its trailing transform
@@ -779,6 +792,8 @@ class Hologram:
                 state["ff"] = True
         elif not state.get("pff"):
             state["pff"] = True
+            if "phase_ff" in self._upload:                     # assigned by this callback: that is what it reads back
+                return
             prev = e.get_prev_phase() if state["bodies"] > 0 else None
             if prev is not None:
                 side = self._side_engine(self.shape)
@@ -790,6 +805,16 @@ class Hologram:
                 self._host["phase_ff"] = pf
                 self._stale.discard("phase_ff")
                 self._upload.discard("phase_ff")
+            elif state["bodies"] > 0:
+                # the body ran the general operators (Bluestein shapes, compressed engines, MRAF with zero_weights, spot
+                # feedback on a dense target): they store HGS_PHASE_FF itself, so the engine's copy is the one to show -- as
+                # the host-driven loop marked it after every constraint step.  An engine that holds none (a body that
+                # never formed it) leaves the host copy as it is.
+                held = e.try_get(L.PHASE_FF)
+                if held is not None:
+                    self._host["phase_ff"] = held[0]
+                    self._stale.discard("phase_ff")
+                    self._upload.discard("phase_ff")
 
     def _device_loop_ok(self, callback):
         """

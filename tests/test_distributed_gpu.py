@@ -98,6 +98,12 @@ def test_bench_launches_its_own_ranks():
     assert d["gather_ms"] > 0 and d["value"] > 0
     assert d["one_hologram_per_gpu"]["value"] > 0
     assert "launcher_self_test" in d
+    # the line carries its own scaling figure (rank 0 alone on its shard, timed first) and the aggregate with the gather
+    solo = d["single_rank_same_job"]
+    assert solo["value"] > 0 and abs(d["scaling_efficiency"] - d["value"] / (2 * solo["value"])) < 1e-12
+    assert 0.3 < d["scaling_efficiency"] < 0.75        # two ranks on ONE device: about half each (a self-test, not a scaling figure)
+    g = d["value_including_gather"]
+    assert 0 < g["value"] < g["job_of_50_iterations"] < d["value"] and g["gather_ms"] == d["gather_ms"]
 
 
 def test_bench_one_rank_rccl_group():

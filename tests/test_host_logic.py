@@ -490,6 +490,45 @@ def test_bench_gpus_n_rejects_a_mismatched_launch():
     assert not any(line.startswith("{") for line in r.stdout.splitlines())
 
 
+def test_bench_n_ranks_line_is_self_contained():
+    """
+    The N > 1 line has to carry its own scaling figure (the N = 1 default is another workload in another process) and the
+    aggregate SURVEY 8(d) defines for cfg 3, "including the final RCCL gather".  The rank protocol of ``bench.py --gpus 2`` on
+    this box -- self-launch under torch.distributed.run, gloo, the two ranks sharing "the device" -- against the stand-in
+    engine (``--stub-engine``: a step is a sleep of 0.2 ms per hologram): rank 0 runs its shard alone first
+    (``single_rank_same_job``) while rank 1 waits, ``scaling_efficiency`` = value / (N x that), and
+    ``value_including_gather`` charges the gather to the K-step region and to the configured 50-iteration job.
+    """
+    import json
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-devices", "--no-roofline-pass", "--stub-engine",
+                    "--steps", "10", "--warmup", "1", "--reps", "5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["stub_engine"] is True and "STUB" in d["metric"]              # cannot be mistaken for a measurement
+    assert d["n_gpus"] == 2 and d["config"]["holograms_per_gpu"] == 8
+    solo = d["single_rank_same_job"]
+    step = 8 * 2e-4                                                        # the stand-in's seconds per step of a rank
+    assert 0.5 / step * 8 < solo["value"] <= 8 / step * 1.001, solo        # one rank: <= 8 holograms per 1.6 ms
+    assert abs(d["scaling_efficiency"] - d["value"] / (2 * solo["value"])) < 1e-12
+    assert 0.5 < d["scaling_efficiency"] <= 1.1, d["scaling_efficiency"]   # two sleeping ranks do not slow each other down
+    g = d["value_including_gather"]
+    assert d["gather_ms"] > 0 and g["gather_ms"] == d["gather_ms"]
+    wall = d["ms_per_step"] * 1e-3 * d["steps"]
+    assert abs(g["value"] - 16 * d["steps"] / (wall + d["gather_ms"] * 1e-3)) < 1e-6 * g["value"]
+    assert abs(g["job_of_50_iterations"] - 16 * 50 / (50 * d["ms_per_step"] * 1e-3 + d["gather_ms"] * 1e-3)) < 1e-6 * g["value"]
+    assert g["value"] < g["job_of_50_iterations"] < d["value"]             # the gather weighs less on the longer job
+    assert d["gathered"]["masks"] == 16 and d["gathered"]["verified_on_every_rank"] is True
+
+
+def test_bench_stub_engine_is_only_the_rank_self_test():
+    """``--stub-engine`` outside the gloo / shared-device self-test form is an argument error: no line, non-zero exit."""
+    r = _run_bench(["--stub-engine", "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0 and "self-test" in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
 def test_update_flags_precedence_and_verbose_print(capsys):
     """_update_flags (_hologram.py:1370-1424): method defaults only where no value exists yet (flags persist between calls),
     keyword flags over both, stat_groups / feedback checked against FEEDBACK_OPTIONS right before they are stored (a rejected

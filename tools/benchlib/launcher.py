@@ -27,6 +27,8 @@ def self_launch(args, bench_path):
     import socket
     import torch
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if getattr(args, "stub_engine", False):       # the CPU self-test of the rank protocol: no device behind the ranks
+        n_dev = max(n_dev, 1)
     if n_dev < 1:
         print(f"bench.py --gpus {args.gpus}: no GPU visible (the engine has no CPU fallback)", file=sys.stderr)
         return 2

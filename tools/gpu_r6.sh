@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-6 GPU batches: tools/gpu_r6.sh STEP [-- STEP ...]   (the steps of tools/gpu_r5.sh plus:)
+#   base                  bench lines of the workloads this round works on -> gpurun_out/r6_base.jsonl
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+line() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']; e=d.get('engine_default_path') or {}
+        print('%-70s it/s %8.0f  col_us %6.1f (frac %.3f) row_us %6.1f | default it/s %8.0f'%(d['config']['workload'][:70],d['value'],r['launch_us'],r['frac'],(r.get('row_kernel') or {}).get('launch_us',0),e.get('value',0)))
+"; }
+run6() {
+  case "$1" in
+    base) OUT=gpurun_out/r6_base.jsonl; : > $OUT
+      b() { timeout 600 python bench.py --cpu-iters 0 --pmc 0 "$@" 2>gpurun_out/r6_base.err | grep '^{' | tee -a $OUT | line; }
+      b --steps 20 --warmup 5
+      b --steps 200 --warmup 20
+      b --workload cfg2dense --steps 100 --warmup 12
+      b --workload cfg2dense --steps 100 --warmup 12 --method WGS-Kim
+      b --workload cfg5mraf --steps 40 --warmup 5
+      b --workload cfg5mraf --steps 20 --warmup 3 --dtype f64
+      b --workload cfg5pad --steps 50 --warmup 5
+      b --workload hd --steps 100 --warmup 10
+      b --workload cfg3 --steps 100 --warmup 10 ;;
+    *) bash tools/gpu_r5.sh "$@" ;;
+  esac
+}
+args=()
+for a in "$@"; do
+  if [ "$a" == "--" ]; then run6 "${args[@]}"; args=(); else args+=("$a"); fi
+done
+[ ${#args[@]} -gt 0 ] && run6 "${args[@]}"
+exit 0
