@@ -774,11 +774,12 @@ def main():
                               "1 - 2 us to a launch (the rocprofv3 --kernel-trace average of the same kernel, profiles/, is "
                               "the sharper figure)" + ("; this pass runs the stream groups one after the other, so that a launch's "
                               "event interval holds that launch only" if args.streams > 1 else "")}
-        if roof is not None and prof is not None and bm.get("other") and prof.get("col_inv", {}).get("launches", 0) > 0:
-            inv_dur = prof["col_inv"]["ms"] * 1e-3 / prof["col_inv"]["launches"]
-            roof["noise_inverse_launch"] = {"kernel": "col_kernel<double, N, LOAD | INV> over the columns that hold a NaN target",
-                                            "launch_us": inv_dur * 1e6, "bytes_per_launch": bm["other"],
-                                            "frac": bm["other"] / inv_dur / HBM_PEAK}
+        ok_ = bm.get("other_kind", "col_inv")
+        if roof is not None and prof is not None and bm.get("other") and prof.get(ok_, {}).get("launches", 0) > 0:
+            inv_dur = prof[ok_]["ms"] * 1e-3 / prof[ok_]["launches"]
+            roof["noise_inverse_launch" if ok_ == "col_inv" else "presum_launch"] = {
+                "kernel": bm.get("other_name"), "launch_us": inv_dur * 1e6, "bytes_per_launch": bm["other"],
+                "frac": bm["other"] / inv_dur / HBM_PEAK}
         if roof is not None and roof.get("traffic_over_model") is not None and abs(roof["traffic_over_model"] - 1) > 0.05:
             roof["traffic_explanation"] = traffic_explanation(args, prob, roof)
         cpu = cpu_baseline(args) if world == 1 else None

@@ -58,6 +58,7 @@ HGS_FAMILY(KCol, "col_kernel", "R,N,MODE");
 HGS_FAMILY(KFused, "col_fused_kernel", "R,N,PHASE,STATS,RULE,NRS");
 HGS_FAMILY(KTile, "col_tile_kernel", "R,N,PHASE,NR,STATS,EXTRAS,RULE,LISTED");
 HGS_FAMILY(KTile2, "col_tile2_kernel", "R,N,PHASE,NR,RULE,PARK,NXF");
+HGS_FAMILY(KPresum, "col_presum_kernel", "R,N,NR");
 HGS_FAMILY(KBlue, "bluestein_lines", "R,M");
 HGS_FAMILY(KCn2fRun, "c_n2f_run", "R,DEG");
 HGS_FAMILY(KCf2nRun, "c_f2n_run", "R,DEG");

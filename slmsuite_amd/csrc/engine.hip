@@ -185,6 +185,7 @@ template <typename R> struct Engine : EngineBase {
     C* tw_row = nullptr;
     C* tw_col = nullptr;
     double* wpartial = nullptr;
+    double* dpartial = nullptr;  // partials of col_presum_kernel (single-inverse MRAF), sized like wpartial
     double* fpartial = nullptr;
     double* epartial = nullptr;  // elementwise partials
     double* sums = nullptr;      // [3][B]: fsum, nogsum, wsum
@@ -197,6 +198,7 @@ template <typename R> struct Engine : EngineBase {
     R* nog_dev = nullptr;             // [B] -1/mean(fc) of the fused WGS-Nogrette pass
     // sparse targets (spot arrays): columns that hold a non-zero weight or target
     unsigned char* col_active = nullptr;   // [B][Pw]
+    unsigned short* sig_rows = nullptr;    // [B][Pw] register slots of a column that hold signal pixels (scan_active_cols; col_presum_kernel)
     int* col_list = nullptr;               // [B][Pw] compacted
     int* n_active_dev = nullptr;           // [B]
     unsigned short* lane_mask = nullptr;   // [B][Pw/16] row-kernel view of col_active
@@ -236,6 +238,8 @@ template <typename R> struct Engine : EngineBase {
     int env_tile2_blocks = 0;              // ... its workgroups per launch over the batch (HGS_TILE2_BLOCKS; 0 = 3 x / 2 x #CU)
     int opt_mono_tab = 1;                  // developer A/B (HGS_MONO_TAB=0 at create): per-pixel compressed kernels evaluate every monomial per spot
     int opt_keep_g = 1;                    // developer A/B (HGS_KEEP_G=0 at create)
+    int opt_mraf_presum = 1;               // developer A/B (HGS_MRAF_PRESUM=0 at create: the two-inverse split form on every update)
+    int env_presum_blocks = 0, opt_presum_rows = 1;    // developer A/B (HGS_PRESUM_BLOCKS, HGS_PRESUM_ROWS at create)
     int opt_fused_shift = 1;               // developer A/B (HGS_FUSED_SHIFT=0 at create): float64 per-column kernel unshifted (16 slots)
     int opt_tile_nr4 = 1;                  // developer A/B (HGS_TILE_NR4=0 at create): slot-count instances of the rule kernels off (NR = 6 only)
     int opt_tile_shift16 = 1;              // developer A/B (HGS_TILE_SHIFT16=0 at create): the tile kernel shifts by whole register slots
@@ -312,6 +316,10 @@ template <typename R> struct Engine : EngineBase {
     double amp_scalar = 0, amp_norm2 = 1.0;
     bool has_amp = false, has_kern = false, have_pff = false, farfield_valid = false;
     bool w_pending = false;  // weights stored un-normalised, wscale holds 1/||w||
+    // ... and wscale^2 * sum w^2 = 1 to rounding: the stored weights were last written by an update pass of the fused loop and
+    // wscale was folded from THAT pass' partial sums (no NaN left among them).  What the single-inverse MRAF pass builds on
+    // (||w'||^2 = 1 + D); every other writer of the weights or of wscale goes through fill_wscale_one and clears it.
+    bool w_unit = false;
     bool has_target = false, has_spots = false;
     int row_blocks = 0, col_blocks = 0, ew_blocks = 0, n_cu = 256, row_xcd = 0, tile_blocks = 0, wpartial_n = 0, col_xmap = 0, list_xmap = 0;
     // profiling
@@ -324,8 +332,8 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
-        void* ptrs[] = {phase_prev, ffb, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial,
-                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
+        void* ptrs[] = {phase_prev, ffb, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial, dpartial,
+                        fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, sig_rows, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
         for (auto& d : blue_tab) for (auto& dir : d) for (C* t3 : dir) if (t3) hipFree(t3);
@@ -414,6 +422,9 @@ template <typename R> struct Engine : EngineBase {
         opt_row_pref = env_int("HGS_ROW_PREF", 1);
         opt_mraf_split = env_int("HGS_MRAF_SPLIT", 1);
         opt_mraf_split64 = env_int("HGS_MRAF_SPLIT64", 1);
+        opt_mraf_presum = env_int("HGS_MRAF_PRESUM", 1);
+        opt_presum_rows = env_int("HGS_PRESUM_ROWS", 1);
+        env_presum_blocks = env_int("HGS_PRESUM_BLOCKS", 0);
         opt_gh2_mask = env_int("HGS_GH2_MASK", 1);
         opt_tile_list = env_int("HGS_TILE_LIST", 1);
         opt_row_shift = env_int("HGS_ROW_SHIFT", 1);
@@ -1094,6 +1105,10 @@ template <typename R> struct Engine : EngineBase {
         return a.do_stats ? launch_tile_split_stats(N, phase, nr, rule_ok, grid, s, a, m0) : launch_tile_split(N, phase, nr, rule_ok, grid, s, a, m0);
     }
     static int tile_split(int, int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
+    static int presum_launch(int N, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) { return launch_presum(N, nr, grid, s, a, m0); }
+    static int presum_launch(int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
+    static int tile_presum(int N, int phase, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) { return launch_tile_presum(N, phase, nr, grid, s, a, m0); }
+    static int tile_presum(int, int, int, dim3, hipStream_t, const ColArgs<double>&, int) { return (int)hipErrorInvalidValue; }
     static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a) { return launch_row_split(N, mode, grid, s, a); }
     static int row_split_launch(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a) { return launch_row_split(N, mode, grid, s, a); }
 
@@ -1101,6 +1116,7 @@ template <typename R> struct Engine : EngineBase {
         hipLaunchKernelGGL(set_scalar<R>, dim3((B + 63) / 64), dim3(64), 0, stream, wscale, B, (R)1);
         HIPCHK(hipGetLastError());
         w_pending = false;
+        w_unit = false;
         return 0;
     }
 
@@ -1587,12 +1603,13 @@ template <typename R> struct Engine : EngineBase {
         if (gh_state > 0) gh_state = -1;       // (a G stored on the old column lists; one of every column stays good)
         if (!col_active) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_active), (size_t)B * g.Pw));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&sig_rows), (size_t)B * g.Pw * sizeof(unsigned short)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list), (size_t)B * g.Pw * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_active_dev), (size_t)B * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
         }
         hipLaunchKernelGGL(scan_active_cols<R>, dim3(g.Pw, B), dim3(256), 0, stream, (const R*)w, (const R*)t, g.Ph, g.Pw,
-                           col_active);
+                           col_active, g.lane_T > 0 ? sig_rows : (unsigned short*)nullptr);
         HIPCHK(hipGetLastError());
         // Where the tile-resident kernel can run the column pass and the active columns fill their 4-column tiles at least
         // half (images, MRAF noise boxes -- not spot arrays, whose columns sit alone in their tiles), the active set is
@@ -1965,6 +1982,7 @@ template <typename R> struct Engine : EngineBase {
             return (st->feedback == HGS_FB_SPOT_WINDOW && q.do_update) || (groups & 2);
         };
         farfield_valid = false;
+        w_unit = false;           // (spot_update writes the weights itself)
         Plan p = plan_iteration(st, hist ? hist : nullptr);
         if (int e = keep_prev_phase(p, n)) return e;
         if (!gh_holds(windows_needed(p) ? 2 : 1)) { if (int e = run_row(0, false, 0, windows_needed(p) ? 2 : 1)) return e; }
@@ -2133,7 +2151,22 @@ template <typename R> struct Engine : EngineBase {
                 }
             }
             const bool split_any = split || split64;
-            if (split_any && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
+            // ... and with ONE inverse per column where ||w'|| can be had BEFORE the field is rebuilt (round 6): the weights that
+            // enter this update are normalised (w_unit), so ||w'||^2 = 1 + D, D = sum over the signal pixels of w'^2 - w^2, which a
+            // forward-only pre-pass over the columns that hold signal pixels forms (col_presum_kernel; a quarter of the columns
+            // at cfg 5).  The main pass (col_tile_kernel RULE 5) rebuilds with the final scale: no second inverse in the noise
+            // columns, no noise part parked in LDS, nothing for the row kernel to join.  WGS-Leonardo / WGS-Kim without in-pass
+            // statistics; the first update after new weights or a new target (and every other rule) takes the split form.
+            const bool presum = split && opt_mraf_presum && w_unit && !stat_ctx && sizeof(R) == 4 &&
+                                (st->method == HGS_WGS_LEONARDO || st->method == HGS_WGS_KIM);
+            // (the pre-pass' grid: one workgroup per CU slot it can hold)
+            const int presum_blocks = std::max(1, std::min(g.Pw / 4, (env_presum_blocks > 0 ? std::min(env_presum_blocks, 3 * n_cu)
+                                                                         : (g.Ph >= 8192 ? 1 : 2) * n_cu) / B));
+            if (presum) {
+                if (int e = refresh_sparse()) return e;         // the column flags (clean unless the weights / target moved)
+                if (!dpartial) { if (dalloc(&dpartial, (size_t)B * std::max(std::max(col_blocks, tile_blocks), n_cu * 3))) return HGS_ERR_DEVICE; }
+            }
+            if (split_any && !presum && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
             // one more forward-only pass that just accumulates it
             const bool nog = st->method == HGS_WGS_NOGRETTE && p.do_update;
@@ -2145,6 +2178,18 @@ template <typename R> struct Engine : EngineBase {
                     a.col_list = col_list_d;
                     a.n_active = n_active_d_dev;
                     LCHK(launch_col<R>(g.Ph, C_FWD | C_STORE, dim3(list_blocks(n_active_d_max), B), stream, a));
+                    return 0;
+                });
+                if (r) return r;
+            }
+            if (presum) {                 // the pre-pass (its own profile slot: a forward-only column launch)
+                r = timed(HGS_K_COL_FWD, [&]() -> int {
+                    ColArgs<R> pa = col_args();
+                    pa.cp = cparams(st, p);
+                    pa.col_flags = col_active;
+                    pa.sig_rows = (g.lane_T > 0 && opt_presum_rows) ? sig_rows : nullptr;
+                    pa.wpartial = dpartial;
+                    LCHK(presum_launch(g.Ph, m1 - m0 + 1, dim3(presum_blocks, B), stream, pa, m0));
                     return 0;
                 });
                 if (r) return r;
@@ -2197,6 +2242,12 @@ template <typename R> struct Engine : EngineBase {
                         wpartial_n = blocks;
                         if (a.do_stats) LCHK(launch_fused_stats<R>(g.Ph, phase_mode, dim3(blocks, B), stream, a));
                         else LCHK(fused_launch(phase_mode, dim3(blocks, B), a));
+                    } else if (presum && pass == 0) {
+                        wpartial_n = tile_grid;
+                        a.dpartial = dpartial;
+                        a.n_dpartial = presum_blocks;
+                        if (sp) a.col_flags = col_active;
+                        LCHK(tile_presum(g.Ph, phase_mode, m1 - m0 + 1, dim3(tile_grid, B), stream, a, m0));
                     } else if (split && pass == 0) {
                         wpartial_n = tile_grid;
                         a.gh2 = gh2;
@@ -2236,7 +2287,9 @@ template <typename R> struct Engine : EngineBase {
                                            sp ? (const int*)n_active_dev : (const int*)nullptr, g.Ph, g.Pw, nog_dev, B);
                         HIPCHK(hipGetLastError());
                     }
-                    if (two_pass && pass == 0) {
+                    // (the single-inverse pass needs wscale only from the NEXT column launch on: the row launch below folds the
+                    //  partials, as after a plain update -- one 4.7 us launch less per iteration)
+                    if (two_pass && pass == 0 && !presum) {
                         hipLaunchKernelGGL(reduce_to_scale<R>, dim3(B), dim3(256), 0, stream, (const double*)wpartial, wpartial_n,
                                            sums + 2 * B, wscale);
                         HIPCHK(hipGetLastError());
@@ -2259,7 +2312,7 @@ template <typename R> struct Engine : EngineBase {
             }
             if (stat_ctx) { if (int e = fused_stats_finish(i)) return e; }
             if (p.store_phase) have_pff = true;
-            if (p.do_update) w_pending = true;
+            if (p.do_update) { w_pending = true; w_unit = true; }       // (wscale: from this pass' partials, here or in the row launch below)
             if (stat_ctx) { if (int e = eff_gate_after(st, nullptr, stat_ctx->dev_out + ((size_t)i * 2 + st->efficiency_group) * B * 4)) return e; }
             st->iter++;
             Plan pn{0, 0, 0};
@@ -2271,7 +2324,7 @@ template <typename R> struct Engine : EngineBase {
             // so that whatever comes next (another call, the transform that ends optimize()) can start from it on every path
             const int last_mode = (opt_keep_g && sizeof(R) == 4 && !row_split) ? 3 : 1;
             const bool last = i + 1 == n;
-            if (int e = run_row(last ? last_mode : 2, p.do_update != 0 && !two_pass, sp ? 1 : 0, (last && last_mode == 3) ? 0 : (sp ? store_sparse : 0)))
+            if (int e = run_row(last ? last_mode : 2, p.do_update != 0 && (!two_pass || presum), sp ? 1 : 0, (last && last_mode == 3) ? 0 : (sp ? store_sparse : 0)))
                 return e;
             p = pn;
         }

@@ -976,6 +976,10 @@ template <typename R> struct ColArgs {
     const int* col_list;   // [batch][Pw] compacted active columns
     const int* n_active;   // [batch]
     // fused kernels only: statistics of this iteration (hgs_iterate_stats)
+    const unsigned short* sig_rows;   // col_presum_kernel: [batch][Pw] which register slots of a column hold signal pixels (column scan), or nullptr
+    const double* dpartial;   // col_tile_kernel RULE 5 (MRAF with a weight update, ONE inverse per column): per-workgroup partials
+    int n_dpartial;           // of D = sum w'^2 - sum w^2 over the signal pixels, left by col_presum_kernel (written there through
+                              // wpartial's neighbour, see engine.hip); 1 / ||w'|| = 1 / sqrt(1 + D) is known BEFORE the field is rebuilt
     int few_active;        // at most a quarter of the farfield columns hold a non-zero weight or target (col_tile2_kernel NXF)
     int fnr;               // col_fused_kernel: register slots the shifted SLM rows occupy (0 = the unshifted kernel, NRS = 16)
     int fshift;            // col_fused_kernel<..., NRS < 16> (float64, >= 4096 rows): circular shift of the transform input, a
@@ -1568,6 +1572,12 @@ template <typename R, int N> constexpr size_t col_tile_split_lds_bytes() {
 // transform is linear.  The signal part A = w' e^{i phi} (un-normalised) and the noise part B = mraf_factor F are transformed
 // separately (B only for columns that hold noise pixels), stored to gh / gh2, and the row kernel (SPLIT) forms A / ||w'|| + B.
 // One forward transform, one read of the column's weights and target and one of GH less than the two-pass form.
+// 5 = MRAF with the WGS-Leonardo / WGS-Kim update and ONE inverse per column (round 6): the weights that enter an update are
+// normalised (wscale folds the previous ||w||), so ||w'||^2 = 1 + D with D = sum over the SIGNAL pixels (finite non-zero
+// target: everywhere else the factor is 1) of w'^2 - w^2 -- and col_presum_kernel has formed D from a forward-only pass over
+// the columns that hold signal pixels (a quarter of them at cfg 5) before this launch.  The field is rebuilt with the final
+// scale: no second inverse in the columns that hold noise, no parked noise part in LDS (the next tile is staged again), no
+// second array for the row kernel to join.
 // LISTED: -1 = the tile schedule is decided at run time (a.col_list), 0 / 1 = compiled in (the hot dense launches lose
 // 0.4 us of 51.5 with the run-time form).
 template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0, int LISTED = -1>
@@ -1584,8 +1594,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
     constexpr bool TPREF = N >= 8192;
     constexpr bool SPLIT = RULE == 3 || RULE == 4;     // 4: ... with the WGS-Leonardo / WGS-Kim update compiled in, MRAF on, no
-    constexpr bool FIXED = RULE == 4;                  //    Nogrette sum, not forward-only (the cfg 5 launch)
-    static_assert(!SPLIT || EXTRAS, "col_tile_kernel: RULE 3 / 4 are EXTRAS forms");
+    constexpr bool FIXED = RULE == 4 || RULE == 5;     //    Nogrette sum, not forward-only (the cfg 5 launch)
+    constexpr bool PRESUM = RULE == 5;                 // 5: the same rule, the field rebuilt with the pre-summed 1 / ||w'||
+    static_assert(!(SPLIT || PRESUM) || EXTRAS, "col_tile_kernel: RULE 3 / 4 / 5 are EXTRAS forms");
     using Sel = FftSel<R, N, true, TPREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
@@ -1628,6 +1639,18 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     }
     const R* wbase = a.w + (size_t)b * P;
     const R* tbase = a.t + (size_t)b * P;
+    // PRESUM: every workgroup folds the pre-pass' partials itself (a few hundred doubles, fixed order: all workgroups get
+    // the same bits) instead of waiting for one more launch
+    R snew = 1;
+    if constexpr (PRESUM) {
+        double d = 0;
+        for (int i = j; i < a.n_dpartial; i += T) d += a.dpartial[(size_t)b * a.n_dpartial + i];
+        d = block_sum(d, scratch);
+        if (j == 0) scratch[0] = 1.0 / ::sqrt(1.0 + d);
+        __syncthreads();
+        snew = (R)scratch[0];
+        __syncthreads();
+    }
 
     // TPREF: staging image of the workgroup's next tile, wave-private 1 KiB blocks [slot][half][wave][lane * 16 bytes];
     // used when the SLM rows fit the first TILE_PREF_SLOTS register slots (uniform)
@@ -1754,7 +1777,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // all-zero signal part, one without a NaN target an all-zero noise part -- known before the column is touched
             int cflags = -1;
             if constexpr (FIXED) { if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c]; }
-            const bool has_sig = cflags < 0 || (cflags & 2) != 0;
+            // (PRESUM: one inverse carries both parts -- skipped only where the column holds neither)
+            const bool has_sig = cflags < 0 || (cflags & (PRESUM ? 6 : 2)) != 0;
             fft.template fwd_lead<NR>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
 
             R* wc = a.w + cb;
@@ -1824,7 +1848,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                     if constexpr (PHASE == 1) pf[m] = M::atan2(F.y, F.x);
                 }
                 // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
-                v[m] = cmulc(ph, om) * wv;
+                // (PRESUM: with the new weights' final normalisation -- the stored weight stays un-normalised as on every path)
+                if constexpr (PRESUM) v[m] = cmulc(ph, om) * (wv * snew);
+                else v[m] = cmulc(ph, om) * wv;
                 if (EXTRAS && (FIXED || cp.mraf)) {                              // mixed-region amplitude freedom (:1606-1653)
                     const R t = tr[m];
                     Cx<R> nz = mk<R>(0, 0);
@@ -1961,6 +1987,145 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 #endif
 }
 
+#ifndef HGS_PRESUM_ABL
+#define HGS_PRESUM_ABL 0     // ablation builds (tools/build_variant.sh): 1 = the pre-pass loads no weights, 2 = neither weights nor targets
+#endif
+template <typename R, int T>
+__device__ __forceinline__ void presum_abl_loads(const R* __restrict__ wc, const R* __restrict__ tc, bool, int j, R (&wr)[16], R (&tr)[16]) {
+    static_for<0, 16>([&](auto m_) {
+        constexpr int m = m_;
+        wr[m] = (R)1e-4;
+        tr[m] = HGS_PRESUM_ABL >= 2 ? ((m >= 6 && m < 10) ? (R)0.5 : (R)0) : tc[lane_pos<T>(j, m)];
+    });
+}
+// =====================================================================================================
+// Pre-pass of col_tile_kernel RULE 5 (MRAF with the WGS-Leonardo / WGS-Kim update, _hologram.py:1606-1653 after
+// _update_weights :1786-1879): D = sum over the signal pixels of w'^2 - w^2, w = the normalised weight that enters the
+// update, w' = w * fc the un-normalised new one -- exactly as the main pass will form it (same transform, same rule, same
+// fix-ups), so that it can rebuild the field with 1 / ||w'|| = 1 / sqrt(1 + D).  Forward transforms only, over the tiles that
+// hold a column with a finite non-zero target (bit 1 of the column scan; a.col_flags is required), the rule only where a
+// wave meets such a pixel; nothing is written but one partial per workgroup (a.wpartial -- the caller points it at the
+// buffer the main pass reads through ColArgs::dpartial).  Pixels outside the signal region contribute exactly 0 (fc = 1).
+// =====================================================================================================
+template <typename R, int N> constexpr size_t col_presum_lds_bytes() { return lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double); }
+template <typename R, int N, int NR>
+__global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_presum_kernel(ColArgs<R> a, int shift) {
+    constexpr int T = N / 16;
+    static_assert(T >= 256 && sizeof(R) == 4, "col_presum_kernel: fp32, one column per workgroup pass");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo g = a.g;
+    const int j = threadIdx.x;
+    const int b = blockIdx.y;
+    Cx<R>* lds = reinterpret_cast<Cx<R>*>(smem);
+    double* scratch = reinterpret_cast<double*>(lds + lds_elems<N>());
+    using Sel = FftSel<R, N, true, false>;
+    typename Sel::type fft;
+    fft.init(a.tw, j);
+    const CParams<R> cp = a.cp;
+    const int js = Sel::space_lane(j);
+    const R sgn = (j & 1) ? (R)-1 : (R)1;
+    const R sgs = (js & 1) ? (R)-1 : (R)1;
+    const size_t P = (size_t)g.Ph * g.Pw;
+    const R wsc = a.wscale[b];
+    Cx<R> om = a.tw[(j * shift) & (N - 1)];
+    om = om * (sgn * a.scale);
+    const int r_lane = js + shift - g.r0;
+    const unsigned char* flags = a.col_flags + (size_t)b * g.Pw;
+    double acc = 0;
+    Cx<R> v[16];
+    R gtx[NR][4], gty[NR][4];
+    R wr[16], tr[16], wn[16], tn[16];
+    // the signal columns of this workgroup's tiles (ct = blockIdx.x + k gridDim.x), in order: (tile, column) -> the next one.
+    // Uniform scalar walk over the scan bits; a workgroup owns a handful of tiles.
+    const int ntile = g.Pw / 4;
+    auto next_signal = [&](int& ct, int& c) -> bool {          // advances (ct, c); false at the end
+        for (;;) {
+            if (++c >= 4) { c = 0; ct += (int)gridDim.x; }
+            if (ct >= ntile) return false;
+            if ((flags[ct * 4 + c] & 2) != 0) return true;
+        }
+    };
+    int ct = blockIdx.x, c = -1;
+    bool have = next_signal(ct, c);
+    // weights and targets of column (ct, c) into wn / tn: only the 16-byte quarters of a lane's 64 bytes whose register slots
+    // hold signal pixels somewhere in the column (sig_rows, uniform) -- at cfg 5 two of the four (the image occupies rows
+    // 3072 .. 5119 = slots 6 .. 9); everything else reads as "no target"
+    auto issue_next = [&]() {
+        const size_t cb = (size_t)b * P + (size_t)(ct * 4 + c) * g.Ph;
+#if HGS_PRESUM_ABL
+        presum_abl_loads<R, T>(a.w + cb, a.t + cb, true, j, wn, tn);
+#else
+        const unsigned sl = a.sig_rows != nullptr ? a.sig_rows[(size_t)b * g.Pw + ct * 4 + c] : 0xffffu;
+        const float4* wq = reinterpret_cast<const float4*>(a.w + cb + lane_pos<T>(j, 0));
+        const float4* tq = reinterpret_cast<const float4*>(a.t + cb + lane_pos<T>(j, 0));
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = q_;
+            float4 wv = make_float4(0, 0, 0, 0), tv = wv;
+            if ((sl >> (4 * q)) & 0xfu) { wv = wq[q]; tv = tq[q]; }
+            wn[4 * q] = wv.x; wn[4 * q + 1] = wv.y; wn[4 * q + 2] = wv.z; wn[4 * q + 3] = wv.w;
+            tn[4 * q] = tv.x; tn[4 * q + 1] = tv.y; tn[4 * q + 2] = tv.z; tn[4 * q + 3] = tv.w;
+        });
+#endif
+    };
+    if (have) issue_next();
+    int ct_loaded = -1;
+#pragma unroll 1
+    while (have) {
+        if (ct != ct_loaded) {
+            const Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const int r = r_lane + m * T;
+                float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+                if (r >= 0 && r < g.Sh) {
+                    const float4* q = reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
+                    lo = q[0];
+                    hi = q[1];
+                }
+                gtx[m][0] = lo.x; gty[m][0] = lo.y; gtx[m][1] = lo.z; gty[m][1] = lo.w;
+                gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
+            }
+            ct_loaded = ct;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < NR) v[m] = mk<R>(gtx[m < NR ? m : 0][c] * sgs, gty[m < NR ? m : 0][c] * sgs);
+            else v[m] = mk<R>(0, 0);
+            wr[m] = wn[m];
+            tr[m] = tn[m];
+        }
+        // the NEXT signal column's weights and targets land under this column's transform (without this every column
+        // waited a full memory round trip for them: 44 us per launch at cfg 5 against 2048 columns' worth of transforms)
+        have = next_signal(ct, c);
+        if (have) issue_next();
+        fft.template fwd_lead<NR>(v, lds, j);
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = m_;
+            const R t = tr[m];
+            // (wave-uniform: the rule only where some lane of the wave holds a signal pixel in this register)
+            if (__builtin_amdgcn_ballot_w64(t != (R)0 && t == t) == 0) return;
+            const Cx<R> F = cmul(v[m], om);
+            const R p2 = F.x * F.x + F.y * F.y;
+            const R w0 = wr[m] * wsc;
+            R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
+            fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
+            R w1 = w0 * fc;
+            if (is_nan(w1)) w1 = (R)0.0001;
+            // (w0 NaN -- weights nobody has updated yet -- cannot occur: the engine takes this path only behind an update)
+            acc += (double)w1 * (double)w1 - (double)w0 * (double)w0;
+            if constexpr (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+        // (consecutive forward transforms need no extra rendezvous: the first exchange of the next one is wave-local, in the
+        //  wave's own regions, and this one ended with the barrier behind its cross-wave gather -- as between the columns of
+        //  col_tile_kernel)
+    }
+    const double s = block_sum(acc, scratch);
+    if (j == 0) a.wpartial[(size_t)b * gridDim.x + blockIdx.x] = s;
+}
+
+// (A form of this pre-pass compiled for FOUR waves per SIMD -- <= 128 VGPRs: two 512-lane workgroups per CU at 8192 rows; no
+//  tile registers, stage twiddles per use, weights requested after the transform; 7 .. 18 spilled VGPRs -- was measured and
+//  removed again: 54.6 against 51.2 us at cfg 5, NOTEBOOK.md round 6.)
 // =====================================================================================================
 // FUSED column kernel, HALF-width tile-resident form (round 5): a lane group of T = N / 16 lanes keeps TWO adjacent
 // columns of a 4-column tile (16 bytes per tile row and lane) in registers and transforms them from / to those
@@ -2772,7 +2937,10 @@ template <typename R> __global__ void multiplane_combine(MpArgs<R> a) {
 
 // ---- sparse targets: which columns hold a non-zero (or NaN) weight or target --------------------------
 // grid = (Pw, batch), one workgroup per column (contiguous Ph values of each array)
-template <typename R> __global__ void scan_active_cols(const R* w, const R* t, int Ph, int Pw, unsigned char* active) {
+// sig_rows[col] (optional): bit m = some pixel of register slot m of the lane-major column layout (stored position % 16) holds a
+// finite non-zero target -- which 16-byte quarters of a lane's weights / targets col_presum_kernel has to fetch
+template <typename R> __global__ void scan_active_cols(const R* w, const R* t, int Ph, int Pw, unsigned char* active,
+                                                       unsigned short* sig_rows = nullptr) {
     // active[col]: bit 0 = the column holds a non-zero (or NaN) weight or target; bit 1 = a finite non-zero target (under
     // MRAF only there is the weighted part of the constrained field non-zero, whatever the weights: NaN and zero targets
     // override it, :1606-1653); bit 2 = a NaN target (MRAF noise pixel)
@@ -2782,17 +2950,24 @@ template <typename R> __global__ void scan_active_cols(const R* w, const R* t, i
     __syncthreads();
     const size_t base = ((size_t)b * Pw + col) * Ph;
     bool nz = false, sig = false, noise = false;
+    unsigned slots = 0;
     for (int i = threadIdx.x; i < Ph; i += blockDim.x) {
         const R wv = w[base + i], tv = t[base + i];
         nz = nz || !(wv == (R)0) || !(tv == (R)0);      // NaN counts as active
-        sig = sig || (tv == tv && tv != (R)0);
+        const bool sg = (tv == tv && tv != (R)0);
+        sig = sig || sg;
+        slots |= sg ? (1u << (i & 15)) : 0u;
         noise = noise || (tv != tv);
     }
     const int bits = (__builtin_amdgcn_ballot_w64(nz) != 0 ? 1 : 0) | (__builtin_amdgcn_ballot_w64(sig) != 0 ? 2 : 0) |
                      (__builtin_amdgcn_ballot_w64(noise) != 0 ? 4 : 0);
     if (bits != 0 && (threadIdx.x & 63) == 0) atomicOr(&any, bits);
+    if (sig_rows != nullptr && slots != 0) atomicOr(&any, (int)(slots << 8));
     __syncthreads();
-    if (threadIdx.x == 0) active[(size_t)b * Pw + col] = (unsigned char)any;
+    if (threadIdx.x == 0) {
+        active[(size_t)b * Pw + col] = (unsigned char)(any & 0xff);
+        if (sig_rows != nullptr) sig_rows[(size_t)b * Pw + col] = (unsigned short)((unsigned)any >> 8);
+    }
 }
 // dil[c] = any active[c - d], d in [lo, hi]: the columns a w-wide integration window around a spot
 // column touches (analysis.take offsets floor(-(w-1)/2) ...).  grid = (ceil(Pw/256), batch)

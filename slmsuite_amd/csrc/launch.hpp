@@ -44,6 +44,12 @@ int launch_tile_split_stats(int N, int phase_mode, int nr, int rule_ok, dim3 gri
 int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<float>& a);
 int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<double>& a);   // float64: rows of 4096 / 8192 (launch_row_f64.hip)
 
+// MRAF with a WGS-Leonardo / WGS-Kim update and ONE inverse per column (round 6; launch_tile_presum_f32.hip): launch_presum
+// leaves the partials of D = sum w'^2 - sum w^2 (signal pixels) in a.wpartial, launch_tile_presum (col_tile_kernel RULE 5) reads
+// them through a.dpartial and rebuilds the field with 1 / sqrt(1 + D)
+int launch_presum(int N, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);      // a.col_flags set
+int launch_tile_presum(int N, int phase_mode, int nr, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0);
+
 // per-column fused kernel with the rule compiled in (fp32, no statistics, none of the MRAF / Nogrette / forward-only extras)
 int launch_fused_rule1(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<float>& a);    // Leonardo / Kim update
 int launch_fused_rule2(int N, int phase_mode, dim3 grid, hipStream_t s, const ColArgs<float>& a);    // no update

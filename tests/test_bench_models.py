@@ -30,7 +30,7 @@ def _lines(rnd="r04"):
     return out
 
 
-def _model(key, method, dtype, batch, streams):
+def _model(key, method, dtype, batch, streams, presum0=True):
     if key in W.SPOT_WORKLOADS:
         shape, slm, grid, _ = W.SPOT_WORKLOADS[key]
         return grid_bytes_models(shape, slm, dtype, batch, streams, method, True, grid[0] * grid[1], False, env={})
@@ -39,8 +39,9 @@ def _model(key, method, dtype, batch, streams):
         return grid_bytes_models(shape, slm, dtype, batch, streams, method, True, 10000, False, env={})
     shape, slm = W.IMAGE_WORKLOADS[key]
     if key == "cfg5mraf":
+        # (the lines of rounds 4 and 5 ran the split form on every update: round 6's single-inverse pass has its own test below)
         return grid_bytes_models(shape, slm, dtype, batch, streams, method, False, 2048 * 2048, True, signal_cols=2048, noise_cols=3072,
-                                 noise_pixels=3072 * 3072 - 2048 * 2048, env={})
+                                 noise_pixels=3072 * 3072 - 2048 * 2048, env={"HGS_MRAF_PRESUM": "0"} if presum0 else {})
     return grid_bytes_models(shape, slm, dtype, batch, streams, method, False, shape[0] * shape[1], False, env={})
 
 
@@ -97,3 +98,16 @@ def test_slot_counts_of_the_shifted_tile_kernel():
             shift = r0 // 16 * 16
             n = tile_slots(Ph, Sh)
             assert n * T >= r0 - shift + Sh > (n - 1) * T          # the rows fit n slots and need all of them
+
+
+def test_single_inverse_mraf_model():
+    """cfg 5, round 6: the column pass moves GH twice, weights, targets and the changed weights -- no second array; the row
+    launch is the plain one; the pre-pass reads the signal columns' GH rows, weights and targets."""
+    m = _model("cfg5mraf", "WGS-Leonardo", "f32", 1, 1, presum0=False)
+    gh, P = 1152 * 8192 * 8, 8192 * 8192
+    assert m["col"] == 2 * gh + 2 * P * 4 + 2048 * 8192 * 4 and m["row"] == 2 * gh and m["col_passes"] == 1
+    assert m["other"] == gh // 4 + 2 * 2048 * 8192 * 4 and m["other_kind"] == "col_fwd"
+    old = _model("cfg5mraf", "WGS-Leonardo", "f32", 1, 1)
+    assert old["other"] == 0 and old["col"] + old["row"] > m["col"] + m["row"]
+    # other rules keep the split form
+    assert _model("cfg5mraf", "WGS-Nogrette", "f32", 1, 1, presum0=False)["col"] == _model("cfg5mraf", "WGS-Nogrette", "f32", 1, 1)["col"]

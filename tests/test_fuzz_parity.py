@@ -184,6 +184,7 @@ def test_random_case_fp32(seed):
     h._release_engine()
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("seed", range(7000, 7012))
 def test_random_large_case_fp32(seed):
     """The same at 4096 / 8192 points per axis, where the tile-resident column kernels, the row kernels that walk rows and the
@@ -404,6 +405,7 @@ def test_random_operation_sequence_fp64(seed):
     report(f"fuzz sequence fp64 [{seed}] {what}", **errs)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("seed", range(9500, 9508))
 def test_random_operation_sequence_fp32_large(seed):
     """The same walk in float32 at 4096 / 8192 points per axis (tile-resident kernels, tile lists, row walks; eight steps).

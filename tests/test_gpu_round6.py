@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 
 def test_callback_reads_phase_ff_of_a_body_the_general_operators_ran():
     """
-    A callback against the device-resident loop whose bodies do NOT run the fused kernels (WGS-Wu: the general operators
-    inside the engine call; a shape that is no power of two: Bluestein lines): the engine keeps no previous phase then --
+    A callback against the device-resident loop whose bodies do NOT run the fused kernels (spot-window feedback on a dense
+    launch: the general operators inside the engine call; a shape that is no power of two: Bluestein lines): the engine keeps no previous phase then --
     HGS_PHASE_FF itself is what the body stored, and that is what ``hologram.phase_ff`` has to show at every invocation, as
     the host-driven loop shows it (before round 6 the callback got the host copy of an earlier read, or None).
     """
-    def views_of(h, method):
+    def views_of(h, method, name):
         seen = []
 
         def cb(hh):
@@ -28,11 +28,13 @@ def test_callback_reads_phase_ff_of_a_body_the_general_operators_ran():
             seen.append(None if pf is None else pf.copy())
             return False
 
-        h.optimize(method, maxiter=4, verbose=False, callback=cb)
+        h.optimize(method, maxiter=4, verbose=False, callback=cb, **({"feedback": "computational_spot"} if "window" in name else {}))
         return seen
 
     cases = {
-        "WGS-Wu 128^2": (lambda: Hologram(synth.random_target(3, (128, 128), 0.2, 1.0), phase=synth.seed_phase(3, (48, 80)), slm_shape=(48, 80)), "WGS-Wu"),
+        "spot window feedback, dense launches": (lambda: SpotHologram.make_rectangular_array(
+            (256, 256), (6, 6), (24, 24), basis="knm", slm_shape=(72, 120), phase=synth.seed_phase(5, (72, 120)),
+            engine_options={L.OPT_SPARSE_COLUMNS: 0}), "WGS-Leonardo"),
         "GS 100x150 (Bluestein)": (lambda: Hologram(synth.random_target(4, (100, 150), 0.2, 1.0), phase=synth.seed_phase(4, (40, 60)), slm_shape=(40, 60)), "GS"),
     }
     for name, (make, method) in cases.items():
@@ -40,7 +42,7 @@ def test_callback_reads_phase_ff_of_a_body_the_general_operators_ran():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             fast, slow = make(), force_stepwise(make())
-        vf, vs = views_of(fast, method), views_of(slow, method)
+        vf, vs = views_of(fast, method, name), views_of(slow, method, name)
         d = dispatch_of(fast)
         assert d.count("col_fused_kernel") + d.count("col_tile_kernel") + d.count("col_tile2_kernel") == 0, d   # general operators
         assert [v is None for v in vf] == [v is None for v in vs], name
@@ -129,3 +131,100 @@ def test_trailing_transform_from_the_kept_g_against_the_stored_phase():
         err = rel_l2(kept, fresh)
         report(f"trailing transform, kept G vs stored phase (sparse={sparse})", farfield=err)
         assert err < 2e-6, err
+
+
+# ---- MRAF with a weight update and ONE inverse per column (col_presum_kernel + col_tile_kernel RULE 5) ------------------------
+def _mraf_target(n, dtype=np.float32):
+    t = np.zeros((n, n), dtype=dtype)
+    a, b = n // 2 - 3 * n // 16, n // 2 + 3 * n // 16
+    t[a:b, a:b] = np.nan
+    a, b = n // 2 - n // 8, n // 2 + n // 8
+    t[a:b, a:b] = synth.random_target(5, (n // 4, n // 4), 0.2, 1.0, dtype=dtype)
+    return t
+
+
+@pytest.mark.parametrize("n, slm, method, extra, sparse", [
+    (4096, (800, 1280), "WGS-Leonardo", {}, 0),                              # SLM rows in 4 register slots
+    (4096, (1152, 1920), "WGS-Leonardo", {}, 0),                             # 6-slot instance
+    (4096, (800, 1280), "WGS-Kim", dict(fix_phase_iteration=2), 0),          # phase_ff stored (body 2), read back (bodies 3, 4)
+    (4096, (1152, 1920), "WGS-Leonardo", {}, 1),                             # engine default: the tile list around the noise box
+    (8192, (1152, 1920), "WGS-Leonardo", {}, 0),                             # cfg 5's own geometry (4-slot instance, staged tiles)
+])
+def test_mraf_single_inverse_matches_the_split_form(n, slm, method, extra, sparse, monkeypatch):
+    """
+    MRAF with a WGS-Leonardo / WGS-Kim update (_hologram.py:1606-1653 after :1786-1879).  The weights that enter an update
+    are normalised, so ||w'||^2 = 1 + D, D = sum over the signal pixels of w'^2 - w^2: a forward-only pre-pass over the
+    columns that hold signal pixels forms D (col_presum_kernel) and the column pass rebuilds the field with the FINAL scale
+    (col_tile_kernel RULE 5) -- one inverse per column and a plain row launch, where the split form (RULE 3 / 4 + row_kernel
+    SPLIT) runs a second inverse in every noise column and joins the parts in the row kernel.  Same algebra, the scale
+    applied before instead of after the inverse: bodies 3 .. 5 of a run against the split form on every update
+    (HGS_MRAF_PRESUM=0, read by hgs_create).  The first update after new weights (body 2) takes the split form in both.
+    """
+    target = _mraf_target(n)
+    phase0 = synth.seed_phase(7, slm)
+    out = {}
+    for presum in ("1", "0"):
+        monkeypatch.setenv("HGS_MRAF_PRESUM", presum)
+        h = Hologram(target, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+        h.optimize(method, maxiter=3, verbose=False, mraf_factor=0.5, **extra)
+        d = dispatch_of(h)
+        lst = ["list"] if sparse else []
+        nolst = [] if sparse else ["list"]
+        if presum == "1":
+            assert d.count("col_presum_kernel", N=n) == 1, d
+            assert d.count("col_tile_kernel", N=n, RULE=5, EXTRAS=True, flags=lst, without=nolst) == 1, d
+            assert d.count("col_tile_kernel", RULE=3) + d.count("col_tile_kernel", RULE=4) == 1, d        # body 2: weights not yet behind an update
+            assert d.count("row_kernel", SPLIT=True) == 1, d
+        else:
+            assert d.count("col_presum_kernel") == 0 and d.count("col_tile_kernel", RULE=5) == 0, d
+            assert d.count("col_tile_kernel", RULE=3) + d.count("col_tile_kernel", RULE=4) == 2 and d.count("row_kernel", SPLIT=True) == 2, d
+        three = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
+        h.optimize(method, maxiter=2, verbose=False, mraf_factor=0.5, **extra)
+        d = dispatch_of(h)
+        if presum == "1":      # the state survives the call boundary: both bodies on the single-inverse pass
+            assert d.count("col_presum_kernel", N=n) == 2 and d.count("col_tile_kernel", RULE=5) == 2 and d.count("row_kernel", SPLIT=True) == 0, d
+        out[presum] = three + (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)))
+        if presum == "1":
+            # new weights from the host: the next update cannot assume them normalised -- the split form once, then again RULE 5
+            h.weights = np.array(h.weights, copy=True) * 3.0
+            h.optimize(method, maxiter=2, verbose=False, mraf_factor=0.5, **extra)
+            d = dispatch_of(h)
+            assert d.count("col_tile_kernel", RULE=3) + d.count("col_tile_kernel", RULE=4) == 1 and d.count("col_tile_kernel", RULE=5) == 1, d
+            assert np.all(np.isfinite(h.phase))
+        h._release_engine()
+    ep3, ew3 = phase_rel_l2(out["1"][0], out["0"][0]), rel_l2(out["1"][1], out["0"][1])
+    ep5, ew5 = phase_rel_l2(out["1"][2], out["0"][2]), rel_l2(out["1"][3], out["0"][3])
+    nrm = float(np.sqrt(np.sum(out["1"][1].astype(np.float64) ** 2)))
+    report(f"single-inverse MRAF vs split {n} {slm} {method} sparse={sparse}", phase_3_bodies=ep3, weights_3_bodies=ew3,
+           phase_5_bodies=ep5, weights_5_bodies=ew5, weight_norm=nrm)
+    assert np.all(np.isfinite(out["1"][0])) and np.all(np.isfinite(out["1"][2]))
+    assert abs(nrm - 1.0) < 2e-6, nrm          # the weights a caller reads are normalised as ever (wscale from the pass' own sums)
+    assert ew3 < 1e-6, ew3                     # body 3's update sees the same farfield in both forms
+    assert ep3 < 3e-6, ep3                     # ... its rebuilt field differs by where the scale is applied, i.e. by rounding
+    assert ep3 > 0                             # (the two forms really are different launches)
+    # two more bodies: the pixel-wise rule on a dense image amplifies rounding 50 - 500 x per body (test_single_pass_mraf_...)
+    assert ep5 < 5e-2 and ew5 < 5e-2, (ep5, ew5)
+
+
+def test_mraf_single_inverse_against_the_oracle():
+    """Three bodies at 4096 x 4096 (SLM 800 x 600) -- the second and third on the single-inverse pass -- against the
+    float64 oracle next to the float32 oracle's own distance from it."""
+    from oracle import hgs_oracle as orc
+    shape, slm = (4096, 4096), (800, 600)
+    t = np.zeros(shape, dtype=np.float32)
+    t[1400:2700, 600:1500] = np.nan
+    t[1600:2500, 700:1400] = synth.random_target(6, (900, 700), 0.2, 1.0)
+    phase0 = synth.seed_phase(8, slm)
+    h = Hologram(t, phase=phase0.copy(), slm_shape=slm, dtype=np.float32, engine_options={L.OPT_SPARSE_COLUMNS: 0})
+    h.optimize("WGS-Leonardo", maxiter=3, verbose=False, mraf_factor=0.7)
+    d = dispatch_of(h)
+    assert d.count("col_tile_kernel", N=4096, RULE=5) == 1 and d.count("col_presum_kernel", N=4096) == 1, d
+    runs = {}
+    for dt in (np.float32, np.float64):
+        o = orc.OracleHologram(t.astype(dt), phase=phase0.astype(dt), slm_shape=slm, dtype=dt)
+        o.optimize("WGS-Leonardo", maxiter=3, mraf_factor=0.7, populate=False)
+        runs[dt] = (o.phase, np.nan_to_num(o.weights))
+    yp, yw = phase_rel_l2(runs[np.float32][0], runs[np.float64][0]), rel_l2(runs[np.float32][1], runs[np.float64][1])
+    ep, ew = phase_rel_l2(h.phase, runs[np.float64][0]), rel_l2(np.nan_to_num(h.weights), runs[np.float64][1])
+    report("single-inverse MRAF vs float64 oracle, 3 bodies", phase=ep, weights=ew, oracle_fp32_vs_fp64_phase=yp, oracle_fp32_vs_fp64_weights=yw)
+    assert ep < 3 * yp and ew < 3 * yw, (ep, yp, ew, yw)

@@ -49,9 +49,20 @@ def grid_bytes_models(shape, slm, dtype, batch, streams, method, sparse_target, 
     other = 0                                     # launches of an iteration besides the column pass(es) and the row launch
     row = 2 * gh                                  # MODE 2 (between fused iterations): H read, G written
     mraf_note = ""
+    other_kind, other_name = "col_inv", "col_kernel<double, N, LOAD | INV> over the columns that hold a NaN target"
     if mraf and wgs:
         slots = tile_slots(Ph, Sh)
-        if dtype == "f32" and Ph >= 4096 and Pw >= 4096 and slots <= 6 and env.get("HGS_MRAF_SPLIT", "1") != "0":
+        if (dtype == "f32" and Ph >= 4096 and Pw >= 4096 and slots <= 6 and env.get("HGS_MRAF_SPLIT", "1") != "0"
+                and env.get("HGS_MRAF_PRESUM", "1") != "0" and m in ("WGS-Leonardo", "WGS-Kim") and signal_cols):
+            # round 6: ||w'|| known BEFORE the field is rebuilt.  A forward-only pre-pass over the tiles that hold a signal
+            # column (col_presum_kernel: reads their GH rows, weights and targets, writes a partial per workgroup), then ONE
+            # column pass with one inverse per column (col_tile_kernel RULE 5: reads GH, w, t; writes w and GH), plain row launch.
+            # (the steady state of a loop; the first update after new weights takes the split form below)
+            other = gh * signal_cols // Pw + 2 * signal_cols * Ph * r
+            other_kind, other_name = "col_fwd", "col_presum_kernel (forward-only pre-pass over the columns that hold signal pixels)"
+            mraf_note = ("; MRAF with a weight update and ONE inverse per column: 1 / ||w'|| = 1 / sqrt(1 + D) from a forward-only "
+                         f"pre-pass over the {signal_cols} columns that hold signal pixels (its own launch, reported beside this one)")
+        elif dtype == "f32" and Ph >= 4096 and Pw >= 4096 and slots <= 6 and env.get("HGS_MRAF_SPLIT", "1") != "0":
             # one column pass (col_tile_kernel RULE 3): reads GH, w, t; writes w and the two parts of the rebuilt field
             # (signal part un-normalised, noise part); the row kernel (SPLIT) reads both
             gh2 = gh * noise_cols // Pw if env.get("HGS_GH2_MASK", "1") != "0" else gh
@@ -82,7 +93,7 @@ def grid_bytes_models(shape, slm, dtype, batch, streams, method, sparse_target, 
     canon_col = (4 * P * c + (3 if wgs else 1) * P * r)
     canon_iter = ((15 if wgs else 13) * P + 2 * S) * r
     ws = gh + P * r * (2 if (wgs or mraf) else 1)           # GH + weights (+ target)
-    return dict(col=col * B, col_passes=passes, row=row * B, other=other * B, canon_col=canon_col * B, canon_iter=canon_iter * B,
+    return dict(col=col * B, col_passes=passes, row=row * B, other=other * B, other_kind=other_kind, other_name=other_name, canon_col=canon_col * B, canon_iter=canon_iter * B,
                 working_set=ws * B,
                 col_model=f"GH tile read + write (2 x Sh*Pw*{c} B) + weights read (P*{r}) + "
                           f"{'target read (P*%d) + ' % r if (wgs or mraf) else ''}"
@@ -91,4 +102,4 @@ def grid_bytes_models(shape, slm, dtype, batch, streams, method, sparse_target, 
                           + mraf_note,
                 row_model=f"H read + G written, SLM rows only (2 x Sh*Pw*{c} B); the phase itself is only "
                           "written by the last row launch of a call"
-                          + ("; single-pass MRAF: the noise part is read as well, in the columns where it exists" if mraf_note and passes == 1 else ""))
+                          + ("; single-pass MRAF: the noise part is read as well, in the columns where it exists" if row != 2 * gh else ""))

@@ -23,6 +23,18 @@ run6() {
       b --workload cfg5pad --steps 50 --warmup 5
       b --workload hd --steps 100 --warmup 10
       b --workload cfg3 --steps 100 --warmup 10 ;;
+    mraf) OUT=gpurun_out/r6_mraf.jsonl; : > $OUT        # single-inverse MRAF (col_presum_kernel + RULE 5) against the split form
+      b() { timeout 600 python bench.py --cpu-iters 0 --pmc ${PMC:-0} "$@" 2>gpurun_out/r6_mraf.err | grep '^{' | tee -a $OUT | line; }
+      for v in 0 1 0 1; do echo "HGS_MRAF_PRESUM=$v"; HGS_MRAF_PRESUM=$v b --workload cfg5mraf --steps 40 --warmup 5; done
+      HGS_MRAF_PRESUM=1 b --workload cfg5mraf --steps 40 --warmup 5 --method WGS-Kim ;;
+    presum) OUT=gpurun_out/r6_presum.jsonl; : > $OUT     # the pre-pass' forms: tile-register form (1 workgroup per CU at 8192) against the lean one
+      b() { timeout 600 python bench.py --cpu-iters 0 --pmc 0 --no-extra-pass "$@" 2>gpurun_out/r6_presum.err | grep '^{' | tee -a $OUT | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); r=d['roofline']; print('   it/s %7.0f col %6.1f row %5.1f presum %5.1f us'%(d['value'],r['launch_us'],r['row_launch_us'],(r.get('presum_launch') or {}).get('launch_us',0)))"; }
+      for v in "HGS_PRESUM_LEAN=0" "HGS_PRESUM_LEAN=1" "HGS_PRESUM_LEAN=1 HGS_PRESUM_BLOCKS=256" "HGS_PRESUM_LEAN=1 HGS_PRESUM_BLOCKS=768" "HGS_PRESUM_LEAN=0 HGS_PRESUM_BLOCKS=512" "HGS_PRESUM_LEAN=0" "HGS_PRESUM_LEAN=1"; do
+        echo "$v"; env $v bash -c "$(declare -f b); b --workload cfg5mraf --steps 40 --warmup 5"; done ;;
+    t) shift; timeout ${TMO:-1200} python -m pytest "$@" -m gpu -q -x -p no:cacheprovider 2>&1 | tail -${TAIL:-25} ;;
     *) bash tools/gpu_r5.sh "$@" ;;
   esac
 }
