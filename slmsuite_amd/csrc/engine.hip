@@ -256,6 +256,10 @@ template <typename R> struct Engine : EngineBase {
     unsigned short* lane_mask_tmp = nullptr;
     int n_noise_max = 0;
     bool noise_valid = false;              // col_list_noise matches the current target
+    int* col_list_signal = nullptr;        // [B][Pw] columns with a finite non-zero target (bit 1 of col_active), compacted: the
+    int* n_signal_dev = nullptr;           // [B]     per-column pre-pass of the single-inverse MRAF update walks them
+    int n_signal_max = 0;
+    bool signal_valid = false;
     bool ffb_zeroed = false;               // ... and so do the zeros of ffb (written since at NaN-target pixels only)
     bool row_split_noise_only = false;     // ... and the row kernel must read gh2 in those columns only (nothing else was written)
     int opt_mraf_split64 = 1;              // developer A/B (HGS_MRAF_SPLIT64=0 at create): float64 MRAF weight updates in two passes
@@ -332,7 +336,7 @@ template <typename R> struct Engine : EngineBase {
     ~Engine() override {
         if (stream) hipStreamSynchronize(stream);
         if (tw_col == tw_row) tw_col = nullptr;
-        void* ptrs[] = {phase_prev, ffb, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial, dpartial,
+        void* ptrs[] = {phase_prev, ffb, col_list_signal, n_signal_dev, col_list_noise, n_noise_dev, lane_mask_tmp, lane_mask_noise, phase, amp, kern, gh, gh2, w, t, pff, ff, aff, zw, staging, tw_row, tw_col, wpartial, dpartial,
                         fpartial, epartial, sums, wscale, spot_xy, spot_amp, ext_amp, spot_fb, nfbuf, nog_dev, stats_scratch, stats_dxy, col_active, sig_rows, col_list, n_active_dev, lane_mask, col_active_d, col_list_d, n_active_d_dev, lane_mask_d, stat_partial, stat_tsum, xg, yg, mono, coeff, cpartial, cnorm, ext_r, sep_c, sep_g, sep_ex, sep_exT, sep_ey, sep_nfT, sep_b2, sep_c1, sep_c2, sep_norm, run_rec, run_ys, run_nf, sk_tab};
         for (void* p : ptrs)
             if (p) hipFree(p);
@@ -1656,6 +1660,26 @@ template <typename R> struct Engine : EngineBase {
         sparse_dirty = false;
         dil_valid = false;
         noise_valid = false;
+        signal_valid = false;
+        return 0;
+    }
+    // the columns that hold a finite non-zero target as a list (the per-column pre-pass of the single-inverse MRAF update)
+    int refresh_signal() {
+        if (int e = refresh_sparse()) return e;
+        if (signal_valid) return 0;
+        if (!col_list_signal) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list_signal), (size_t)B * g.Pw * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_signal_dev), (size_t)B * sizeof(int)));
+        }
+        if (!lane_mask_tmp) HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_tmp), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
+        hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
+                           col_list_signal, n_signal_dev, lane_mask_tmp, 2);
+        HIPCHK(hipGetLastError());
+        std::vector<int> h(B);
+        HIPCHK(hipMemcpyAsync(h.data(), n_signal_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        n_signal_max = *std::max_element(h.begin(), h.end());
+        signal_valid = true;
         return 0;
     }
     // per-column single-pass MRAF: the columns that hold a NaN target as a list (the buffer of the noise part is zeroed by the
@@ -1667,8 +1691,8 @@ template <typename R> struct Engine : EngineBase {
         if (!col_list_noise) {
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&col_list_noise), (size_t)B * g.Pw * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&n_noise_dev), (size_t)B * sizeof(int)));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_tmp), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
         }
+        if (!lane_mask_tmp) HIPCHK(hipMalloc(reinterpret_cast<void**>(&lane_mask_tmp), (size_t)B * (g.Pw / 16) * sizeof(unsigned short)));
         ffb_zeroed = false;
         hipLaunchKernelGGL(compact_active_cols, dim3(B), dim3(256), 0, stream, (const unsigned char*)col_active, g.Pw,
                            col_list_noise, n_noise_dev, lane_mask_tmp, 4);
@@ -2132,7 +2156,10 @@ template <typename R> struct Engine : EngineBase {
             const bool split64_ok = two_pass && !tile_path && g.Pw >= 4096 && opt_mraf_split && opt_mraf_split64;
             // (a column list: only where at most half of the listed columns hold noise -- where every one does, as around a noise
             //  box, the single pass saves no transform and pays the extra launch: measured 119 against 105 us at 4096^2)
-            bool split64 = split64_ok;
+            // (not where the single-inverse form below takes the update: presum_ok)
+            const bool presum_ok = two_pass && opt_mraf_presum && w_unit && !stat_ctx &&
+                                   (st->method == HGS_WGS_LEONARDO || st->method == HGS_WGS_KIM);
+            bool split64 = split64_ok && !presum_ok;
             if (split64) {
                 if (int e = refresh_noise()) return e;
                 if (sp && n_noise_max * 2 > n_active_max) split64 = false;
@@ -2150,15 +2177,25 @@ template <typename R> struct Engine : EngineBase {
                     ffb_zeroed = true;
                 }
             }
-            const bool split_any = split || split64;
             // ... and with ONE inverse per column where ||w'|| can be had BEFORE the field is rebuilt (round 6): the weights that
             // enter this update are normalised (w_unit), so ||w'||^2 = 1 + D, D = sum over the signal pixels of w'^2 - w^2, which a
             // forward-only pre-pass over the columns that hold signal pixels forms (col_presum_kernel; a quarter of the columns
             // at cfg 5).  The main pass (col_tile_kernel RULE 5) rebuilds with the final scale: no second inverse in the noise
             // columns, no noise part parked in LDS, nothing for the row kernel to join.  WGS-Leonardo / WGS-Kim without in-pass
             // statistics; the first update after new weights or a new target (and every other rule) takes the split form.
-            const bool presum = split && opt_mraf_presum && w_unit && !stat_ctx && sizeof(R) == 4 &&
-                                (st->method == HGS_WGS_LEONARDO || st->method == HGS_WGS_KIM);
+            const bool presum = presum_ok && split && sizeof(R) == 4;
+            // ... and everywhere else the fused path runs an MRAF update (float64; float32 geometries outside the tile-resident
+            // kernel's or narrower than 4096 columns): the per-column kernel makes the pre-pass over the list of signal columns
+            // (CParams::presum) and the main pass -- per-column or the generic tile kernel -- rebuilds with the pre-summed scale.
+            // Replaces the float64 split form (pass + inverse-only launch over the noise columns + joining row launch) and the
+            // two-pass form.
+            bool presum_col = presum_ok && !presum;
+            if (presum_col) {
+                if (int e = refresh_signal()) return e;
+                if (n_signal_max <= 0) presum_col = false;
+                else if (!dpartial) { if (dalloc(&dpartial, (size_t)B * std::max(std::max(col_blocks, tile_blocks), n_cu * 3))) return HGS_ERR_DEVICE; }
+            }
+            // (a target without a single finite non-zero pixel: D = 0 trivially, but nothing to gain either -- two plain passes)
             // (the pre-pass' grid: one workgroup per CU slot it can hold)
             const int presum_blocks = std::max(1, std::min(g.Pw / 4, (env_presum_blocks > 0 ? std::min(env_presum_blocks, 3 * n_cu)
                                                                          : (g.Ph >= 8192 ? 1 : 2) * n_cu) / B));
@@ -2166,6 +2203,7 @@ template <typename R> struct Engine : EngineBase {
                 if (int e = refresh_sparse()) return e;         // the column flags (clean unless the weights / target moved)
                 if (!dpartial) { if (dalloc(&dpartial, (size_t)B * std::max(std::max(col_blocks, tile_blocks), n_cu * 3))) return HGS_ERR_DEVICE; }
             }
+            const bool split_any = split || split64;
             if (split_any && !presum && !gh2) { if (dalloc(&gh2, (size_t)B * g.Sh * g.Pw)) return HGS_ERR_DEVICE; }
             // WGS-Nogrette needs nanmean(feedback / target) over the whole farfield before the update (:1851):
             // one more forward-only pass that just accumulates it
@@ -2194,7 +2232,32 @@ template <typename R> struct Engine : EngineBase {
                 });
                 if (r) return r;
             }
-            for (int pass = nog ? -1 : 0; pass < (two_pass && !split_any ? 2 : 1) && !r; ++pass) {
+            int presum_col_blocks = 0;
+            if (presum_col) {             // the per-column pre-pass over the signal columns
+                r = timed(HGS_K_COL_FWD, [&]() -> int {
+                    ColArgs<R> pa = col_args();
+                    pa.cp = cparams(st, p);
+                    pa.cp.weights_only = 1;
+                    pa.cp.presum = 1;
+                    pa.col_list = col_list_signal;
+                    pa.n_active = n_signal_dev;
+                    pa.wpartial = dpartial;
+                    // (no more workgroups than the dense launch of this geometry keeps resident: at 8192 rows in float64 one per CU --
+                    //  the list over three rounds of workgroups cost the pre-pass a prologue per round)
+                    presum_col_blocks = std::max(1, std::min(list_blocks(n_signal_max), env_presum_blocks > 0 ? env_presum_blocks : col_blocks));
+                    // (fewer than four columns per workgroup pass: the groups of a 4-column run of the list on one XCD, as for
+                    //  the column-list launches of the loop -- the signal columns of an image fill their tiles)
+                    const int gp = 8 * (4 / col_cpar());
+                    if (list_xmap && col_cpar() < 4 && presum_col_blocks >= gp) {
+                        presum_col_blocks -= presum_col_blocks % gp;
+                        pa.list_xmap = 1;
+                    }
+                    LCHK(launch_fused<R>(g.Ph, 0, dim3(presum_col_blocks, B), stream, pa));
+                    return 0;
+                });
+                if (r) return r;
+            }
+            for (int pass = nog ? -1 : 0; pass < (two_pass && !split_any && !presum_col ? 2 : 1) && !r; ++pass) {
                 r = timed(HGS_K_COL_FUSED, [&]() -> int {
                     ColArgs<R> a = col_args();
                     a.cp = cparams(st, p);
@@ -2206,9 +2269,13 @@ template <typename R> struct Engine : EngineBase {
                     } else if (nog) {
                         a.cp.nog = nog_dev;
                     }
-                    if (two_pass && !split_any && pass == 0) {
+                    if (two_pass && !split_any && !presum_col && pass == 0) {
                         a.cp.weights_only = 1;
                         phase_mode = 0;
+                    }
+                    if (presum_col) {
+                        a.dpartial = dpartial;
+                        a.n_dpartial = presum_col_blocks;
                     }
                     if (split64 && pass == 0) {
                         a.cp.split = 1;
@@ -2289,7 +2356,7 @@ template <typename R> struct Engine : EngineBase {
                     }
                     // (the single-inverse pass needs wscale only from the NEXT column launch on: the row launch below folds the
                     //  partials, as after a plain update -- one 4.7 us launch less per iteration)
-                    if (two_pass && pass == 0 && !presum) {
+                    if (two_pass && pass == 0 && !presum && !presum_col) {
                         hipLaunchKernelGGL(reduce_to_scale<R>, dim3(B), dim3(256), 0, stream, (const double*)wpartial, wpartial_n,
                                            sums + 2 * B, wscale);
                         HIPCHK(hipGetLastError());
@@ -2324,7 +2391,7 @@ template <typename R> struct Engine : EngineBase {
             // so that whatever comes next (another call, the transform that ends optimize()) can start from it on every path
             const int last_mode = (opt_keep_g && sizeof(R) == 4 && !row_split) ? 3 : 1;
             const bool last = i + 1 == n;
-            if (int e = run_row(last ? last_mode : 2, p.do_update != 0 && (!two_pass || presum), sp ? 1 : 0, (last && last_mode == 3) ? 0 : (sp ? store_sparse : 0)))
+            if (int e = run_row(last ? last_mode : 2, p.do_update != 0 && (!two_pass || presum || presum_col), sp ? 1 : 0, (last && last_mode == 3) ? 0 : (sp ? store_sparse : 0)))
                 return e;
             p = pn;
         }

@@ -68,6 +68,12 @@
 #ifndef HGS_SPLIT_L2_PREFETCH
 #define HGS_SPLIT_L2_PREFETCH 0 // 1: single-pass MRAF tile kernel, the next tile's rows requested ahead of the first transform: 332.6 vs 330.4 us
 #endif
+#ifndef HGS_F64_POW_LEAN
+#define HGS_F64_POW_LEAN 1      // float64 rule kernels: pow_lean / Newton rsqrt instead of ocml's log2 + exp2 / sqrt + division (round 6)
+#endif
+#ifndef HGS_F64_PARK_AHEAD
+#define HGS_F64_PARK_AHEAD 0    // 1: float64 fused kernel, the parked value of pixel m + 1 requested before pixel m is evaluated: 620 vs 599 us (slower; round 6)
+#endif
 #ifndef HGS_ABL_WT
 #define HGS_ABL_WT 0
 #endif
@@ -130,6 +136,9 @@ template <typename R> struct CParams {
     R p_exp, p_fac, mraf_factor, zero_factor;
     R inv_fnorm;      // 1/||amp_ff|| (Parseval constant ||amp|| in the fused path)
     R log2_inv_fnorm;
+    int presum;       // fused kernels, with weights_only: the forward-only PRE-PASS of the single-inverse MRAF update (round 6) -- the
+                      // rule is evaluated as the update would, nothing is written, and wpartial receives D = sum w'^2 - sum w^2
+                      // (the main pass then finds it through ColArgs::dpartial and rebuilds with 1 / sqrt(1 + D))
     int split;        // col_fused_kernel: MRAF with a weight update in ONE pass -- the signal part (un-normalised new weights)
                       // is transformed back here, the noise part mraf_factor * F leaves as farfield values through
                       // ColArgs::ffb (only the pixels with a NaN target are written: the rest of the buffer stays zero) and a
@@ -251,7 +260,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // each wave folds into that wave's private LDS slots (no barrier); slots go to global at kernel end.
 constexpr int STAT_N = 8;            // tf, es, es2, cnt, rmin, rmax, emin, emax
 constexpr int STAT_WAVES = 16;       // slots per workgroup in the partial buffer (max 1024 lanes)
-constexpr int SCRATCH_DOUBLES = 16 + STAT_WAVES * STAT_N;
+constexpr int SCRATCH_DOUBLES = 16 + STAT_WAVES * STAT_N + 2;     // (+ 2: the last slot holds the pre-summed 1 / ||w'|| of col_fused_kernel)
 
 // (workgroups of the small transforms have fewer than 64 lanes: values shuffled in from lanes that do
 // not exist are ignored)
@@ -352,6 +361,44 @@ __device__ __forceinline__ float pow_split(float x, float c) {
 
 __device__ __forceinline__ float Math<float>::powneg(float x, float p) { return pow_split(x, -p); }
 
+// The same power in double for the float64 rule kernels (round 6).  ocml's log2 + exp2 behind ::pow / exp2(c log2 x) are some
+// three hundred double instructions per pixel with their special-case ladders -- at the half-rate float64 pipe the rule was
+// 22 % of a float64 column (profiles/r05/trace8k_timeline.txt: constraint 13.9 k of 47 k cycles).  Here, for finite x > 0:
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172: ten terms; log2 m in two
+// pieces (the product with log2(e) split high / low); c e split into its nearest integer and an fma residual as in
+// pow_split; 2^g for |g| <= 1/2 as a degree-13 polynomial of g ln 2.  About 45 double operations, no table, no branch;
+// against powl over x in 2^[-80, 80] and c in [-2, -0.35]: at most 2.9 ulp, 0.16 ulp on average (tools/microbench/pow_rule64).
+// x = 0 gives +inf for c < 0 like the library form (callers map it, :1867); NaN propagates; x = +inf is the caller's.
+__device__ __forceinline__ double pow_lean(double x, double c) {
+    double m = __builtin_amdgcn_frexp_mant(x);                 // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m * 2.0 : m;
+    e = low ? e - 1 : e;
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 21;
+    p = __builtin_fma(p, z, 1.0 / 19); p = __builtin_fma(p, z, 1.0 / 17); p = __builtin_fma(p, z, 1.0 / 15);
+    p = __builtin_fma(p, z, 1.0 / 13); p = __builtin_fma(p, z, 1.0 / 11); p = __builtin_fma(p, z, 1.0 / 9);
+    p = __builtin_fma(p, z, 1.0 / 7); p = __builtin_fma(p, z, 1.0 / 5); p = __builtin_fma(p, z, 1.0 / 3);
+    constexpr double L2E_HI = 1.4426950408889634, L2E_LO = 2.0355273740931033e-17;
+    const double t2 = 2.0 * s, lm = t2 * z * p;
+    const double hi = t2 * L2E_HI;
+    const double lo = __builtin_fma(t2, L2E_HI, -hi) + t2 * L2E_LO + lm * L2E_HI;
+    const double ed = (double)e;
+    const double n = __builtin_rint(c * ed);
+    double f = __builtin_fma(c, ed, -n) + c * hi;
+    f += c * lo;
+    const double k = __builtin_rint(f);
+    const double g = (f - k) * 0.69314718055994530942;
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, g, 1.0 / 479001600.0); q = __builtin_fma(q, g, 1.0 / 39916800.0); q = __builtin_fma(q, g, 1.0 / 3628800.0);
+    q = __builtin_fma(q, g, 1.0 / 362880.0); q = __builtin_fma(q, g, 1.0 / 40320.0); q = __builtin_fma(q, g, 1.0 / 5040.0);
+    q = __builtin_fma(q, g, 1.0 / 720.0); q = __builtin_fma(q, g, 1.0 / 120.0); q = __builtin_fma(q, g, 1.0 / 24.0);
+    q = __builtin_fma(q, g, 1.0 / 6.0); q = __builtin_fma(q, g, 0.5); q = __builtin_fma(q, g, 1.0); q = __builtin_fma(q, g, 1.0);
+    const double r = __builtin_amdgcn_ldexp(q, (int)(n + k));
+    return x == 0.0 ? (c < 0 ? (double)INFINITY : 0.0) : r;
+}
+
 // (|F| c / T)^-p for the Leonardo / Kim rule of the fused kernels, from |F|^2: the ratio is formed FIRST (log2 of the
 // three factors separately cancels ~20 against ~20 and leaves 1e-6 relative noise per update).
 template <typename R> __device__ __forceinline__ R leonardo_factor(R p2, R t, R inv_fnorm, R p_exp) {
@@ -361,7 +408,11 @@ template <typename R> __device__ __forceinline__ R leonardo_factor(R p2, R t, R 
     if (!(r2 < (R)INFINITY)) return (R)1;          // overflow of the ratio (:1840) and NaN targets (:1843) -> 1
     // r2 = 0 -> inf: callers map it to 1 (:1867)
     if constexpr (sizeof(R) == 4) return pow_split(r2, -0.5f * p_exp);
+#if HGS_F64_POW_LEAN
+    else return pow_lean(r2, (R)-0.5 * p_exp);
+#else
     else return M::exp2_fast((R)-0.5 * p_exp * M::log2_fast(r2));
+#endif
 }
 
 // ---- the WGS weight rule for one element (rows 9-10; _hologram.py:1830-1873) -------------------------
@@ -431,7 +482,20 @@ __device__ __forceinline__ float rsqrt_full(float x) {
     const float r = __builtin_amdgcn_rsqf(tiny ? x * 0x1p+100f : x);
     return tiny ? r * 0x1p+50f : r;
 }
-__device__ __forceinline__ double rsqrt_full(double x) { return 1.0 / ::sqrt(x); }
+// float64: the hardware estimate and two Newton steps (x > 0; a sqrt and a division in double are some fifty instructions)
+__device__ __forceinline__ double rsqrt_full(double x) {
+#if HGS_F64_POW_LEAN
+    const bool tiny = x < 0x1p-900;
+    const double xs = tiny ? x * 0x1p+200 : x;
+    double y = __builtin_amdgcn_rsq(xs);
+    const double h = 0.5 * xs;
+    y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+    return tiny ? y * 0x1p+100 : y;
+#else
+    return 1.0 / ::sqrt(x);
+#endif
+}
 
 // =====================================================================================================
 // ROW kernels: transforms along x over the Sh SLM rows.
@@ -1165,6 +1229,20 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     const bool x_nog = RULE != 0 ? false : cp.nog_pass != 0;
     const bool x_wonly = RULE != 0 ? false : cp.weights_only != 0;
     const bool x_split = RULE != 0 ? false : (cp.split != 0 && cp.mraf != 0);
+    const bool x_presum = RULE != 0 ? false : cp.presum != 0;
+    // the main pass behind such a pre-pass: every workgroup folds the partials itself (fixed order: the same bits everywhere).
+    // The scale lives in LDS and is read where a pixel is rebuilt: a register held across the transforms is what the float64
+    // instances at 8192 points do not have (they went from 0 to 8 .. 35 spilled VGPRs with it)
+    double* snew_slot = scratch + (SCRATCH_DOUBLES - 1);
+    if constexpr (RULE == 0) {
+        double d = 0;
+        if (a.dpartial != nullptr) {
+            for (int i = tid; i < a.n_dpartial; i += (int)blockDim.x) d += a.dpartial[(size_t)blockIdx.y * a.n_dpartial + i];
+            d = block_sum(d, scratch);
+        }
+        if (tid == 0) *snew_slot = 1.0 / ::sqrt(1.0 + d);
+        __syncthreads();
+    }
     const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
@@ -1340,11 +1418,18 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         R* wc = a.w + cb;
         R* pfc = (PHASE != 0) ? a.pff + cb : nullptr;
         bool w_changed = false;
+        // fp64: the parked value of pixel m + 1 is requested before pixel m is evaluated (one pixel at a time -- a scheduling
+        // barrier per pixel -- otherwise meant one exposed LDS round trip per pixel, sixteen per column)
+        Cx<R> vnext = mk<R>(0, 0);
+        if constexpr (LEAN && HGS_F64_PARK_AHEAD) vnext = park[0];
         auto cons = [&](auto m_) {
             constexpr int m = m_;
             const unsigned idx = lane_pos<T>(j, m);
             Cx<R> vm;
-            if constexpr (LEAN) vm = park[m * T]; else vm = v[m];
+            if constexpr (LEAN && HGS_F64_PARK_AHEAD) {
+                vm = vnext;
+                if constexpr (m + 1 < 16) vnext = park[(m + 1) * T];
+            } else if constexpr (LEAN) vm = park[m * T]; else vm = v[m];
             [&]() {
             // wave-uniform skip of pixels with zero weight and zero target (see col_tile_kernel)
             if (PHASE != 1 && !(STATS && (a.do_stats & 2)) && HGS_SPARSE_SKIP &&
@@ -1378,9 +1463,16 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                     wv *= weight_factor<R>(cp.method, M::sqrt(p2) * cp.inv_fnorm, t, cp.p_exp, cp.p_fac, nogv);
                 }
                 if (is_nan(wv)) wv = (R)0.0001;            // :1873
-                w_changed |= (wv != wraw);                 // stored after the loop; unchanged lanes (zeros of a
-                wr[m] = wv;                                // sparse target) write nothing
-                acc_w += wv * wv;
+                if (x_presum) {                            // pre-pass: what this update adds to sum w^2 -- nothing is kept,
+                    const double w0 = (double)wraw * (double)wsc;      // nothing rebuilt (float64: the phasor alone is a double rsqrt)
+                    acc_w += (R)((double)wv * (double)wv - w0 * w0);   // (each term in double; a lane adds a few hundred of them)
+                    vm = mk<R>(0, 0);
+                    return;
+                } else {
+                    w_changed |= (wv != wraw);             // stored after the loop; unchanged lanes (zeros of a
+                    wr[m] = wv;                            // sparse target) write nothing
+                    acc_w += wv * wv;
+                }
             }
             if constexpr (STATS) {
                 const R af = M::sqrt(p2);
@@ -1406,7 +1498,9 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 if constexpr (PHASE == 1) { if (vcol) pfc[idx] = M::atan2(F.y, F.x); }
             }
             // inverse-transform input = (-1)^k * ff (SHIFTED: times the conjugate shift factor)
-            if constexpr (SHIFTED) vm = cmulc(mk<R>(co, si), omu) * wv; else vm = mk<R>(wv * co * sgn, wv * si * sgn);
+            // (snew: 1, or the new weights' final normalisation where a pre-pass has summed it -- the stored weight stays raw)
+            const R wvs = (RULE == 0) ? wv * (R)*snew_slot : wv;
+            if constexpr (SHIFTED) vm = cmulc(mk<R>(co, si), omu) * wvs; else vm = mk<R>(wvs * co * sgn, wvs * si * sgn);
             if (x_mraf) {                                   // mixed-region amplitude freedom (:1606-1653)
                 const R t = tr[m];
                 if (is_nan(t)) {
@@ -1642,7 +1736,10 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     // PRESUM: every workgroup folds the pre-pass' partials itself (a few hundred doubles, fixed order: all workgroups get
     // the same bits) instead of waiting for one more launch
     R snew = 1;
-    if constexpr (PRESUM) {
+    constexpr bool PRESUM_RT = EXTRAS && RULE == 0;     // the generic form behind a per-column pre-pass (a.dpartial set; Pw < 4096)
+    bool presum_on = PRESUM;
+    if constexpr (PRESUM_RT) presum_on = a.dpartial != nullptr;
+    if (presum_on) {
         double d = 0;
         for (int i = j; i < a.n_dpartial; i += T) d += a.dpartial[(size_t)b * a.n_dpartial + i];
         d = block_sum(d, scratch);
@@ -1849,7 +1946,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 }
                 // ff = wv * ph; inverse-transform input = (-1)^k * ff * conj(shift factor)
                 // (PRESUM: with the new weights' final normalisation -- the stored weight stays un-normalised as on every path)
-                if constexpr (PRESUM) v[m] = cmulc(ph, om) * (wv * snew);
+                if constexpr (PRESUM || PRESUM_RT) v[m] = cmulc(ph, om) * (wv * snew);
                 else v[m] = cmulc(ph, om) * wv;
                 if (EXTRAS && (FIXED || cp.mraf)) {                              // mixed-region amplitude freedom (:1606-1653)
                     const R t = tr[m];

@@ -293,6 +293,7 @@ def test_float64_single_pass_mraf(shape, slm, method, extra, sparse, monkeypatch
     target = _mraf_frame(shape, dt, box=bool(sparse))
     phase0 = synth.seed_phase(17, slm, dtype=dt)
     out = {}
+    monkeypatch.setenv("HGS_MRAF_PRESUM", "0")        # (round 6: the second update would take the single-inverse form -- tests/test_gpu_round6.py)
     for split in ("1", "0"):
         monkeypatch.setenv("HGS_MRAF_SPLIT64", split)
         h = Hologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
@@ -356,10 +357,11 @@ def test_float32_single_pass_mraf_on_the_per_column_kernel(shape, slm, method, e
     assert gp < max(3e-5, 3 * yp) and gw < max(1e-5, 3 * yw), (gp, yp, gw, yw)
 
 
-def test_float64_single_pass_mraf_in_a_batch():
+def test_float64_single_pass_mraf_in_a_batch(monkeypatch):
     """Three holograms in one engine, per-hologram noise columns (one of them has no NaN at all): the noise list, the
     farfield buffer of the noise part and the SPLIT row launch are per hologram -- against the same holograms one at a time."""
     from slmsuite_amd.batch import HologramBatch
+    monkeypatch.setenv("HGS_MRAF_PRESUM", "0")        # (the split form on both updates; round 6's form: tests/test_gpu_round6.py)
     shape, slm, dt = (64, 4096), (40, 1500), np.float64
     targets = np.stack([_mraf_frame(shape, dt, box=False), _mraf_frame(shape, dt, box=True),
                         synth.random_target(9, shape, 0.2, 1.0, dtype=dt)])

@@ -321,6 +321,7 @@ def test_float64_row_kernel_shifted_form(n, slm, monkeypatch):
     single-pass MRAF (the row kernel that joins the two parts): the same numbers up to the rounding of the shift factors.
     """
     out = {}
+    monkeypatch.setenv("HGS_MRAF_PRESUM", "0")        # (the row kernel that JOINS is what is tested: the split form on both updates)
     for sh in ("1", "0"):
         monkeypatch.setenv("HGS_ROW_SHIFT64", sh)
         res = []

@@ -228,3 +228,68 @@ def test_mraf_single_inverse_against_the_oracle():
     ep, ew = phase_rel_l2(h.phase, runs[np.float64][0]), rel_l2(np.nan_to_num(h.weights), runs[np.float64][1])
     report("single-inverse MRAF vs float64 oracle, 3 bodies", phase=ep, weights=ew, oracle_fp32_vs_fp64_phase=yp, oracle_fp32_vs_fp64_weights=yw)
     assert ep < 3 * yp and ew < 3 * yw, (ep, yp, ew, yw)
+
+
+def _mraf_frame(shape, dtype, box):
+    """A noise frame around an image: NaN rows across the whole width (box False) or a NaN box (few noise columns)."""
+    H, W = shape
+    t = np.zeros(shape, dtype=dtype)
+    r0, r1, c0, c1 = H // 4, 3 * H // 4, W // 2 - W // 6, W // 2 + W // 6
+    if box:
+        t[r0 - H // 16:r1 + H // 16, c0 - W // 32:c1 + W // 32] = np.nan
+    else:
+        t[r0 - H // 16:r1 + H // 16, :] = np.nan
+    t[r0:r1, c0:c1] = synth.random_target(21, (r1 - r0, c1 - c0), 0.2, 1.0, dtype=dtype)
+    return t
+
+
+@pytest.mark.parametrize("dt, shape, slm", [(np.float64, (64, 4096), (40, 1500)), (np.float64, (256, 8192), (100, 3000)),
+                                            (np.float64, (4096, 4096), (600, 900)),
+                                            (np.float32, (256, 4096), (100, 1500)),          # short columns: the per-column kernel in float32
+                                            (np.float32, (4096, 2048), (800, 600)),          # tile-resident rows, fewer than 4096 columns: the generic tile kernel
+                                            (np.float32, (1024, 1024), (300, 400))])
+@pytest.mark.parametrize("method, extra", [("WGS-Leonardo", {}), ("WGS-Kim", dict(fix_phase_iteration=2))])
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_mraf_single_inverse_on_the_per_column_kernel(dt, shape, slm, method, extra, sparse, monkeypatch):
+    """
+    The same update wherever the fused path runs MRAF outside col_tile_kernel RULE 5: float64 (no tile-resident kernel) and
+    the float32 geometries it does not cover.  The per-column kernel makes the pre-pass over the list of signal columns
+    (CParams::presum: forward transform + rule, nothing written but D) and the main pass -- col_fused_kernel, or the generic
+    tile kernel -- rebuilds with 1 / sqrt(1 + D): two launches and a plain row launch where the split form takes a pass, an
+    inverse-only launch over the noise columns and a joining row launch, and the two-pass form two full passes.  Four bodies
+    (the third and fourth on the new form) against the old forms (HGS_MRAF_PRESUM=0) and, in float64, against the oracle.
+    """
+    if shape == (4096, 4096) and (method != "WGS-Leonardo" or sparse):
+        pytest.skip("one case at the large float64 size")
+    target = _mraf_frame(shape, dt, box=bool(sparse))
+    phase0 = synth.seed_phase(17, slm, dtype=dt)
+    out = {}
+    for presum in ("1", "0"):
+        monkeypatch.setenv("HGS_MRAF_PRESUM", presum)
+        h = Hologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt, engine_options={L.OPT_SPARSE_COLUMNS: sparse})
+        h.optimize(method, maxiter=4, verbose=False, mraf_factor=0.5, **extra)
+        d = dispatch_of(h)
+        if presum == "1":
+            assert d.count("col_presum_kernel") == 0 and d.count("col_tile_kernel", RULE=5) == 0, d
+            # bodies 2, 3: pre-pass over the signal list (per-column kernel, RULE 0) + ONE main pass + a plain row launch
+            assert d.count("col_fused_kernel", N=shape[0], RULE=0, flags=["list"]) >= 2, d
+            assert d.count("row_kernel", SPLIT=True) + d.count("col_kernel", MODE=24) <= 2, d          # at most body 1's split form
+        out[presum] = (h.phase.copy(), np.nan_to_num(np.array(h.weights, copy=True)), h.amp_ff.copy())
+        h._release_engine()
+    ep, ew = phase_rel_l2(out["1"][0], out["0"][0]), rel_l2(out["1"][1], out["0"][1])
+    errs = dict(phase_vs_old_form=ep, weights_vs_old_form=ew)
+    if dt == np.float64:
+        from oracle import hgs_oracle as orc
+        o = orc.OracleHologram(target.copy(), phase=phase0.copy(), slm_shape=slm, dtype=dt)
+        o.optimize(method, maxiter=4, mraf_factor=0.5, **extra)
+        errs.update(phase=phase_rel_l2(out["1"][0], o.phase), weights=rel_l2(out["1"][1], np.nan_to_num(o.weights)),
+                    amp_ff=rel_l2(out["1"][2], o.amp_ff))
+    report(f"single-inverse MRAF, per-column pre-pass {np.dtype(dt).name} {shape} {slm} {method} sparse={sparse}", **errs)
+    # (ep may be exactly 0 on a small float32 grid: 1 / sqrt(1 + D) and 1 / sqrt(sum w'^2) round to the same float there and
+    #  the two-pass form then multiplies the same numbers in the same order; the dispatch record above is what shows the path)
+    assert np.all(np.isfinite(out["1"][0]))
+    if dt == np.float64:
+        assert max(errs.values()) < 1e-9, errs
+    else:
+        # float32: two update bodies apart on a dense image (rounding amplified 50 - 500 x per body, see the split-form tests)
+        assert ep < 5e-3 and ew < 5e-3, errs

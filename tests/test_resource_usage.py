@@ -15,7 +15,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "slmsuite_amd", "csrc")
 UNITS = ["launch_tile_rule_f32.hip", "launch_tile_list_f32.hip", "launch_tile2_f32.hip", "launch_row_f32.hip", "launch_fused_rule1_f32.hip",
-         "launch_fused_rule2_f32.hip", "launch_tile_split_f32.hip"]
+         "launch_fused_rule2_f32.hip", "launch_tile_split_f32.hip", "launch_tile_presum_f32.hip"]
 
 # instantiations that keep a few spilled registers, by (kernel, substring of the template arguments)
 KNOWN = {

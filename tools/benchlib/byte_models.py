@@ -62,6 +62,17 @@ def grid_bytes_models(shape, slm, dtype, batch, streams, method, sparse_target, 
             other_kind, other_name = "col_fwd", "col_presum_kernel (forward-only pre-pass over the columns that hold signal pixels)"
             mraf_note = ("; MRAF with a weight update and ONE inverse per column: 1 / ||w'|| = 1 / sqrt(1 + D) from a forward-only "
                          f"pre-pass over the {signal_cols} columns that hold signal pixels (its own launch, reported beside this one)")
+        elif env.get("HGS_MRAF_PRESUM", "1") != "0" and m in ("WGS-Leonardo", "WGS-Kim") and signal_cols:
+            # the same update on the per-column kernel (float64; float32 outside the tile-resident geometry): the pre-pass is a
+            # forward-only launch of col_fused_kernel over the list of signal columns (CParams::presum), the main pass one plain
+            # launch with one inverse per column, the row launch the plain one
+            if dtype == "f64":
+                w_write = n_targets * r            # (float64 leaves changed weights four pixels = 32 bytes at a time)
+                col = 2 * gh + 2 * P * r + w_write
+            other = gh * signal_cols // Pw + 2 * signal_cols * Ph * r
+            other_kind, other_name = "col_fwd", "col_fused_kernel over the list of signal columns, forward only (CParams::presum)"
+            mraf_note = ("; MRAF with a weight update and ONE inverse per column: 1 / ||w'|| = 1 / sqrt(1 + D) from a forward-only "
+                         f"pre-pass over the {signal_cols} columns that hold signal pixels (its own launch, reported beside this one)")
         elif dtype == "f32" and Ph >= 4096 and Pw >= 4096 and slots <= 6 and env.get("HGS_MRAF_SPLIT", "1") != "0":
             # one column pass (col_tile_kernel RULE 3): reads GH, w, t; writes w and the two parts of the rebuilt field
             # (signal part un-normalised, noise part); the row kernel (SPLIT) reads both
