@@ -621,12 +621,17 @@ def main():
                        "unit": "iterations/s", "ms_per_step": w1[m1] * 1e3 / args.steps}
 
     # roofline pass: same K steps again with per-launch HIP events on the engine stream
-    prof = None
+    prof, ran = None, None
     if not args.no_roofline_pass:
         prob.engine.profile_enable(True)
+        if hasattr(prob.engine, "dispatch_read"):
+            prob.engine.dispatch_read()              # (clear: the record of the roofline pass alone)
         getattr(prob, "run_profiled", prob.run)(args.steps)
         prof = prob.engine.profile_read()
         prob.engine.profile_enable(False)
+        # which template instances that pass launched -- the engine's own record (hgs_dispatch_read), not a guess
+        if hasattr(prob.engine, "dispatch_read"):
+            ran = sorted(prob.engine.dispatch_read(), key=lambda r: -r["count"])
 
     # the engine's default for spot targets: only the columns that hold a spot are transformed
     sparse_ms, sprof = None, None
@@ -738,7 +743,9 @@ def main():
                 elif res is not None:
                     tnote = "kernel not found in the PMC pass: " + json.dumps(res)
             iter_s = args.steps / (ms_events * 1e-3)
-            roof = {"bound": "hbm", "kernel": kernel_ran or col_kernel_name(args, prob),
+            launched = [r for r in (ran or []) if r["kernel"] in ("col_tile_kernel", "col_tile2_kernel", "col_fused_kernel")]
+            roof = {"bound": "hbm", "kernel": kernel_ran or (launched[0]["name"] if launched else "(no dispatch record)"),
+                    "kernels_launched": [f"{r['name']} x{r['count']}" for r in (ran or [])],
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                     "traffic": traffic, "traffic_note": tnote,
                     # scalars of the nested objects below (a parser that keeps only flat fields still carries them):
@@ -946,23 +953,6 @@ def traffic_explanation(args, prob, roof):
         return ("partial-line accesses: 32-byte tile rows of GH and 64-byte lane groups of the weights are fetched as whole "
                 "128-byte lines where the neighbouring pieces are not in the same L2 at the same time")
     return "unexplained: treat `traffic` as the moved bytes and `frac_on_traffic` as the fraction"
-
-
-def col_kernel_name(args, prob):
-    """Which fused column kernel the dense path launches for this geometry (engine.hip, iterate())."""
-    Ph = prob.shape[0]
-    T = Ph // 16
-    r0 = (Ph - prob.slm[0]) // 2
-    slots = (r0 + prob.slm[0] - 1) // T - r0 // T + 1
-    tile_off = any(o.upper().replace(" ", "") == "TILE_KERNEL=0" for o in args.opt)
-    # plain passes (Leonardo / Kim update or none) that neither store nor read the farfield phase run the half-width tile kernel
-    # at 4096 rows (three workgroups per CU) and at 2048 rows
-    plain = args.method in ("GS", "WGS-Leonardo") and not getattr(prob, "mraf", False) and args.workload != "cfg5mraf"
-    if args.dtype == "f32" and plain and not tile_off and ((Ph == 4096 and slots <= 6) or (Ph == 2048 and slots <= 10)):
-        return f"col_tile2_kernel<float, {Ph}, ...> (half-width tile-resident fused column kernel)"
-    if args.dtype == "f32" and Ph >= 4096 and slots <= 6 and not tile_off:
-        return f"col_tile_kernel<float, {Ph}, ...> (tile-resident fused column kernel)"
-    return f"col_fused_kernel<{'float' if args.dtype == 'f32' else 'double'}, {Ph}, ...> (per-column fused kernel)"
 
 
 if __name__ == "__main__":

@@ -1293,7 +1293,9 @@ class SpotHologram(FeedbackHologram):
             for x, y in np.rint(np.hstack((self.null_knm, self.spot_knm))).T:
                 toolbox.imprint_disk_zero(raster, x, y, diameter)
         raster[nearest[1], nearest[0]] = self.spot_amp
-        raster /= _norm(raster)
+        # (without null points the raster holds no NaN: nansum's NaN-free copy of it -- a third of this call at 4096^2 -- is the
+        #  array itself, and np.sum over it gives nansum's bits)
+        raster /= _norm(raster) if self.null_knm is not None else np.sqrt(np.sum(np.square(raster)))
         if not reset_weights:
             self._materialise_weights()
             self._weights_reset = False

@@ -396,7 +396,6 @@ def _cfg5_target(n=8192, dtype=np.float32):
     return t
 
 
-@pytest.mark.slow
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_cfg5_mraf_8192_steps(dtype):
     """
