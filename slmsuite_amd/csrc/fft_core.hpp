@@ -618,7 +618,16 @@ __device__ __forceinline__ void wave_lds_order() {
 // LDS-DMA loads (global_load_lds) in flight across the transform: with such a load outstanding hipcc drains vmcnt(0)
 // ahead of every __syncthreads(), i.e. the prefetch would be waited for at the first exchange.
 // ES: element stride of the LDS image (8192 points: the two images interleaved element by element, ES = 2).
-template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false, int ES = 1> struct WgFftL {
+// LTW (with RESIDENT = false: the float64 column kernels, which have no registers to keep the stage twiddles in): the twiddles
+// come from two small tables in LDS instead of per-use global loads -- A[m] = W_4096^(16 m), m < 256, and B[n] = W_4096^n,
+// n < 192: a stage-1 twiddle W_256^(q k) is A[(q k) & 255]; a stage-2 twiddle W_4096^(q p), p = 16 p_hi + p_lo, is
+// A[(q p_hi) & 255] * B[q p_lo] (one complex product, 1.5 ulp).  7 KB per workgroup; filled by ltw_fill at kernel start.
+// What it buys is not the fetch itself (the table is L2-resident) but the in-order vmcnt queue: with twiddle loads inside
+// the transform, anything requested AHEAD of it -- the column's weights and targets -- is waited for at the first twiddle
+// (round 5, HGS_F64_WT_EARLY: slower), so they were requested after it and cost a full memory round trip per column
+// (tools/microbench/trace8k f64main: 11.6 k of 45 k cycles).
+constexpr int LTW_A = 256, LTW_B = 192, LTW_N = LTW_A + LTW_B;
+template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false, int ES = 1, bool LTW = false> struct WgFftL {
     static __device__ __forceinline__ void wg_barrier() {
         if constexpr (RAWBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
@@ -627,15 +636,26 @@ template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false, int
     static constexpr int NTW = RESIDENT ? 12 : 1;
     Cx<R> tw[NTW];
     const Cx<R>* table_ = nullptr;
+    const Cx<R>* ltw_ = nullptr;    // LTW: the two tables in LDS
     int tr_n = 0;       // HGS_TRACE event counter (dead otherwise)
 
     static __host__ __device__ __forceinline__ int space_lane(int p) { return (p >> 4) + 16 * (p & 15); }
+    // all lanes of the workgroup call; the caller puts a barrier between this and the first transform
+    static __device__ __forceinline__ void ltw_fill(const Cx<R>* __restrict__ table, Cx<R>* ltw, int tid, int nthreads) {
+        for (int i = tid; i < LTW_N; i += nthreads)
+            ltw[i] = i < LTW_A ? table[TS * ((16 * i) & (N - 1))] : table[TS * (i - LTW_A)];
+    }
+    __device__ __forceinline__ void set_ltw(const Cx<R>* ltw) { ltw_ = ltw; }
 
     // twiddle IDX of stage s (1 or 2): IDX 0..2 = W^(4 q k), 3..5 = W^(q k), q = IDX % 3 + 1;
     // stage 1: W_256, k = p & 15; stage 2: W_4096, k = p
     template <int s, int IDX> __device__ __forceinline__ Cx<R> twv(int p) const {
         if constexpr (RESIDENT) {
             return tw[(s - 1) * 6 + IDX];
+        } else if constexpr (LTW) {
+            constexpr int q = (IDX < 3 ? 4 : 1) * (IDX % 3 + 1);
+            if constexpr (s == 1) return ltw_[(q * (p & 15)) & (LTW_A - 1)];
+            else return cmul(ltw_[(q * ((p >> 4) & 15)) & (LTW_A - 1)], ltw_[LTW_A + q * (p & 15)]);
         } else {
             constexpr int q = (IDX < 3 ? 4 : 1) * (IDX % 3 + 1);
             return s == 1 ? table_[TS * ((q * (p & 15) * 16) & (N - 1))] : table_[TS * ((q * p) & (N - 1))];
@@ -768,7 +788,7 @@ template <typename R, bool RESIDENT = true, int TS = 1, bool RAWBAR = false, int
 // tools/fft_local8k_model.py is the index model.  Zero / unwanted slots: NZ leading non-zero registers (NZ <= 8: the
 // partner x[n + 4096] is zero, the radix-2 step is a copy and a twiddle) become 2 NZ leading slots of the 4096-point
 // transforms; likewise NOUT on the way back.
-template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k {
+template <typename R, bool RESIDENT = true, bool RAWBAR = false, bool LTW = false> struct WgFftL8k {
 #ifndef HGS_8K_INTERLEAVE
 #define HGS_8K_INTERLEAVE 1
 #endif
@@ -778,8 +798,10 @@ template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k
     //  write 2-way conflicted, SQ_LDS_BANK_CONFLICT 40 % of the array cycles.)
     static constexpr bool IL = HGS_8K_INTERLEAVE != 0;
     static constexpr int N = 8192, T = 512, IMG = IL ? 1 : 16 * 272 + 16, X1 = IL ? 513 : IMG + 1, WREG = IL ? 1088 : 544;
-    using Core = WgFftL<R, RESIDENT, 2, RAWBAR, IL ? 2 : 1>;
+    using Core = WgFftL<R, RESIDENT, 2, RAWBAR, IL ? 2 : 1, LTW>;
     Core core;
+    static __device__ __forceinline__ void ltw_fill(const Cx<R>* __restrict__ table, Cx<R>* ltw, int tid, int nthreads) { Core::ltw_fill(table, ltw, tid, nthreads); }
+    __device__ __forceinline__ void set_ltw(const Cx<R>* ltw) { core.set_ltw(ltw); }
     Cx<R> w2;            // W_8192^(space_lane(j))
     int tr_n = 0;
 
@@ -871,14 +893,14 @@ template <typename R, bool RESIDENT = true, bool RAWBAR = false> struct WgFftL8k
 #ifndef HGS_LOCAL_FFT
 #define HGS_LOCAL_FFT 1
 #endif
-template <typename R, int N, bool RESIDENT, bool RAWBAR = false> struct FftSel {
+template <typename R, int N, bool RESIDENT, bool RAWBAR = false, bool LTW = false> struct FftSel {
     using type = WgFft<R, N, RESIDENT>;
     static constexpr bool local = false;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return j; }
 };
 #if HGS_LOCAL_FFT
-template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 4096, RESIDENT, RAWBAR> {
-    using type = WgFftL<R, RESIDENT, 1, RAWBAR>;
+template <typename R, bool RESIDENT, bool RAWBAR, bool LTW> struct FftSel<R, 4096, RESIDENT, RAWBAR, LTW> {
+    using type = WgFftL<R, RESIDENT, 1, RAWBAR, 1, LTW>;
     static constexpr bool local = true;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL<R, RESIDENT>::space_lane(j); }
 };
@@ -886,8 +908,8 @@ template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 4096, RESIDEN
 #define HGS_LOCAL_FFT8K 1
 #endif
 #if HGS_LOCAL_FFT8K
-template <typename R, bool RESIDENT, bool RAWBAR> struct FftSel<R, 8192, RESIDENT, RAWBAR> {
-    using type = WgFftL8k<R, RESIDENT, RAWBAR>;
+template <typename R, bool RESIDENT, bool RAWBAR, bool LTW> struct FftSel<R, 8192, RESIDENT, RAWBAR, LTW> {
+    using type = WgFftL8k<R, RESIDENT, RAWBAR, LTW>;
     static constexpr bool local = true;
     static __host__ __device__ __forceinline__ int space_lane(int j) { return WgFftL8k<R, RESIDENT>::space_lane(j); }
 };

@@ -107,6 +107,16 @@ struct Geo {
 #ifndef HGS_CONS_GROUP
 #define HGS_CONS_GROUP 16    // pixels of a lane whose rule evaluation the scheduler may interleave (fp32; fp64: 4)
 #endif
+#ifndef HGS_TRACE_CONS
+#define HGS_TRACE_CONS 0      // traced builds (tools/microbench/trace8k): one event per pixel of the float64 constraint
+#endif
+#ifndef HGS_F64_EAGER
+#define HGS_F64_EAGER 0       // 1: float64 rule and phasor evaluated for every lane and selected, as in float32, so that HGS_CONS_GROUP_F64
+                              //    pixels form one scheduling region (also with -amdgpu-sched-strategy=max-ilp): 543 vs 543 us, nothing (round 6)
+#endif
+#ifndef HGS_CONS_GROUP_F64
+#define HGS_CONS_GROUP_F64 1  // float64: one pixel at a time (four interleaved double atan2 / sincos / log2 chains cost 100+ registers)
+#endif
 #ifndef HGS_LANE_MAJOR
 #define HGS_LANE_MAJOR 1
 #endif
@@ -1009,6 +1019,16 @@ template <int N> struct ColCfg {
     static constexpr int PASSES = 4 / CPAR;
 };
 
+#ifndef HGS_F64_LTW
+#define HGS_F64_LTW 1
+#endif
+#ifndef HGS_F64_WT_BUF
+#define HGS_F64_WT_BUF 1
+#endif
+// col_fused_kernel: LDS twiddle tables (float64, the row-local transforms) and the dynamic LDS they add behind the scratch
+template <typename R, int N> constexpr bool fused_ltw() { return HGS_F64_LTW && sizeof(R) == 8 && (N == 4096 || N == 8192); }
+template <typename R, int N> constexpr size_t fused_ltw_bytes() { return fused_ltw<R, N>() ? (size_t)LTW_N * sizeof(Cx<R>) : 0; }
+
 template <typename R> struct ColArgs {
     Geo g;
     Cx<R>* gh;
@@ -1220,9 +1240,18 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     // fp64 doubles every register: keep the weight/target prefetch, drop the resident stage twiddles and the
     // prefetch of the next column's G (both spilled to scratch otherwise: 662 spilled VGPRs at 8192)
     constexpr bool LEAN = sizeof(R) == 8;
-    using Sel = FftSel<R, N, !LEAN>;
+    // float64 at 4096 / 8192 rows: the stage twiddles from two small LDS tables (WgFftL LTW) -- nothing of the transform is in
+    // the vmcnt queue any more, so the column's weights and targets can be requested ahead of it (round 6)
+    constexpr bool LTW = fused_ltw<R, N>();
+    using Sel = FftSel<R, N, !LEAN, false, LTW>;
     typename Sel::type fft;
     fft.init(a.tw, j);
+    if constexpr (LTW) {
+        Cx<R>* ltab = reinterpret_cast<Cx<R>*>(scratch + SCRATCH_DOUBLES);
+        Sel::type::ltw_fill(a.tw, ltab, tid, (int)blockDim.x);
+        fft.set_ltw(ltab);
+        __syncthreads();
+    }
     const CParams<R> cp = a.cp;
     const bool do_upd = RULE == 1 ? true : (RULE == 2 ? false : cp.do_update != 0);
     const bool x_mraf = RULE != 0 ? false : cp.mraf != 0;
@@ -1323,6 +1352,28 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         // one (wave-uniform where T >= 64) branch around the whole group: a select per element turns every load into
         // its own predicated dword access instead of four 16-byte ones
         const bool need_t = do_upd || STATS || x_mraf;
+        // float64: straight-line loads through buffer resources (an empty resource reads as zero), no branch.  With the loads
+        // inside uniform branches the compiler does not know at the join how many are in flight and waits for the OLDER loads
+        // of the column's G rows with vmcnt(0..3) -- i.e. for the weights and targets just requested as well: the in-order
+        // queue then costs a full memory round trip per column exactly where the request was meant to run ahead of the
+        // transform (tools/microbench/trace8k f64main: 11 k of 45 k cycles; what HGS_F64_WT_EARLY ran into in round 5).
+        if constexpr (LEAN && HGS_LANE_MAJOR && HGS_COL_BUF && T % 64 == 0 && HGS_F64_WT_BUF) {
+            constexpr unsigned RB = sizeof(R), PER = 16 / RB;           // values per 16-byte load
+            const unsigned bytes = col_valid(q) ? (unsigned)g.Ph * RB : 0u;
+            const Buf bw(wc, bytes), bt(tc, need_t ? bytes : 0u);
+            const unsigned vo = lane_pos<T>(j, 0) * RB;
+            static_for<0, 16 / PER>([&](auto c_) {
+                constexpr int c = c_;
+                const Cx<R> x = bw.template ld<Cx<R>>(vo + 16u * c, 0u);       // (two doubles: 16 bytes)
+                wr[PER * c] = x.x; wr[PER * c + 1] = x.y;
+            });
+            static_for<0, 16 / PER>([&](auto c_) {
+                constexpr int c = c_;
+                const Cx<R> x = bt.template ld<Cx<R>>(vo + 16u * c, 0u);
+                tr[PER * c] = x.x; tr[PER * c + 1] = x.y;
+            });
+            return;
+        }
         if (col_valid(q)) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; wr[m] = wc[lane_pos<T>(j, m)]; });
             if constexpr (PF_AHEAD) {        // (a lane's sixteen values are 64 contiguous bytes: lane_pos<T>(j, m) = 16 j + m)
@@ -1385,7 +1436,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         static_for<0, NRS>([&](auto m_) { constexpr int m = m_; v[m] = v[m] * sgs; });
         // fp64: this column's weights / targets land under its forward transform (8192: after it -- the 64 registers
         // would not fit next to the transform's own)
-        if constexpr (LEAN && (N < 8192 || (SHIFTED && HGS_F64_WT_EARLY))) issue_wt(q);
+        if constexpr (LEAN && (N < 8192 || (SHIFTED && (HGS_F64_WT_EARLY || LTW)))) issue_wt(q);
         // 8192 points: the 64 registers of this column's weights / targets do not fit next to the forward transform, so they
         // are requested after it.  (Experiment, off: one word of each of the lane's two 128-byte lines requested BEFORE the
         // transform, so that the real loads are L2 hits -- the launch got 3 % slower, HGS_F64_WT_PREFETCH.)
@@ -1407,7 +1458,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
         Cx<R>* park = lds + j;
         if constexpr (LEAN) {
             static_for<0, 16>([&](auto m_) { constexpr int m = m_; park[m * T] = v[m]; });
-            if constexpr (N >= 8192 && !(SHIFTED && HGS_F64_WT_EARLY)) issue_wt(q);
+            if constexpr (N >= 8192 && !(SHIFTED && (HGS_F64_WT_EARLY || LTW))) issue_wt(q);
         }
 #if HGS_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1454,7 +1505,9 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                     // evaluated for every lane and selected (a branch per pixel splits the pass into 16 blocks):
                     // T == 0 -> factor 1 (:1841); inf (:1840,:1867) and nan (:1843) -> 1
                     // (fp64: the rule is some hundred instructions of double log2 / exp2 -- worth the branch)
-                    if (sizeof(R) == 4 || t != (R)0) {
+                    // (float64 too since round 6: pow_lean is 45 operations, and without the per-lane branch the pixels of a group
+                    //  are one basic block whose dependent chains the scheduler can interleave, HGS_CONS_GROUP_F64)
+                    if (sizeof(R) == 4 || HGS_F64_EAGER || t != (R)0) {
                         R fc = leonardo_factor<R>(p2, t, cp.inv_fnorm, cp.p_exp);
                         fc = (t != (R)0 && fc < (R)INFINITY) ? fc : (R)1;
                         wv *= fc;
@@ -1487,7 +1540,7 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
                 }
                 else M::sincos_phase(pfc[idx], &si, &co);
             } else {
-                if (sizeof(R) == 4 || p2 > (R)0) {         // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
+                if (sizeof(R) == 4 || HGS_F64_EAGER || p2 > (R)0) {         // exp(i*atan2(F)) == F/|F|; atan2(0,0) = 0 (quirk A6)
                     const R inv = rsqrt_full(p2);
                     co = (p2 > (R)0) ? F.x * inv : (R)1;
                     si = (p2 > (R)0) ? F.y * inv : (R)0;
@@ -1522,8 +1575,11 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
             }
             }();
             if constexpr (LEAN) park[m * T] = vm; else v[m] = vm;
+#if HGS_TRACE_CONS
+            HGS_T(fft.tr_n, 40 + m);
+#endif
             // (fp64: one pixel at a time -- four interleaved double atan2 / sincos / log2 chains cost 100+ registers)
-            if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : 1) == (sizeof(R) == 4 ? HGS_CONS_GROUP : 1) - 1) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m % (sizeof(R) == 4 ? HGS_CONS_GROUP : HGS_CONS_GROUP_F64) == (sizeof(R) == 4 ? HGS_CONS_GROUP : HGS_CONS_GROUP_F64) - 1) __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (!LEAN) {
             static_for<0, 16>(cons);

@@ -31,7 +31,7 @@ constexpr bool kExtras = HGS_TILE_EXTRAS_TU != 0;
 #if !HGS_TILE_EXTRAS_TU
 template <typename R, int N, int PHASE, int NRS = 16>
 static int launch_fused_one(dim3 grid, hipStream_t s, const ColArgs<R>& a) {
-    constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double);
+    constexpr size_t lds = (size_t)ColCfg<N>::CPAR * lds_elems<N>() * sizeof(Cx<R>) + SCRATCH_DOUBLES * sizeof(double) + fused_ltw_bytes<R, N>();
     auto k = col_fused_kernel<R, N, PHASE, kStats, 0, NRS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),

@@ -19,5 +19,9 @@ hipcc $F $TR -DWHICH=0 -DNRT=4 trace8k.hip -o trace8k_pad4_t &
 hipcc $F $TR -DWHICH=0 -DNRT=3 trace8k.hip -o trace8k_pad3_t &
 hipcc $F $TR -DWHICH=1 trace8k.hip -o trace8k_mraf_t &
 hipcc $F $TR -DWHICH=2 -mllvm -disable-machine-licm trace8k.hip -o trace8k_f64_t &
+hipcc $F -DWHICH=3 -mllvm -disable-machine-licm trace8k.hip -o trace8k_f64main &
+hipcc $F -DWHICH=4 -mllvm -disable-machine-licm trace8k.hip -o trace8k_f64pre &
+hipcc $F $TR -DWHICH=3 -mllvm -disable-machine-licm trace8k.hip -o trace8k_f64main_t &
+hipcc $F $TR -DWHICH=4 -mllvm -disable-machine-licm trace8k.hip -o trace8k_f64pre_t &
 wait
 ls -la trace8k_*

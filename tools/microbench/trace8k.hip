@@ -21,7 +21,7 @@ using namespace hgs;
 #ifndef NRT
 #define NRT 6
 #endif
-#if WHICH == 2
+#if WHICH >= 2
 typedef double Rt;
 #else
 typedef float Rt;
@@ -81,13 +81,36 @@ int main() {
     lds = col_tile_split_lds_bytes<float, 8192>();
     ca.cp.mraf = 1; ca.cp.has_mraf_factor = 1; ca.cp.mraf_factor = 0.5f;
     const char* name = "col_tile_kernel<float, 8192, 0, 4, false, true, 3, -1> (cfg 5 single-pass MRAF)";
-#else
+#elif WHICH == 2
     auto k = col_fused_kernel<double, 8192, 0, false, 0>;
-    lds = (size_t)lds_elems<8192>() * sizeof(Ct) + SCRATCH_DOUBLES * sizeof(double);
+    lds = (size_t)lds_elems<8192>() * sizeof(Ct) + SCRATCH_DOUBLES * sizeof(double) + fused_ltw_bytes<double, 8192>();
     hipMalloc(&ffb, P * sizeof(Ct)); hipMemset(ffb, 0, P * sizeof(Ct));
     ca.cp.mraf = 1; ca.cp.has_mraf_factor = 1; ca.cp.mraf_factor = 0.5; ca.cp.split = 1; ca.ffb = ffb; ca.col_xmap = 1;
     grid = 512;
     const char* name = "col_fused_kernel<double, 8192, 0, false, 0> split (cfg 5 float64)";
+#else
+    // round 6: the shifted float64 kernel (NRS = 4) as the engine launches it for cfg 5 -- WHICH 3: the main pass of the
+    // single-inverse MRAF update (update + rebuild + one inverse); WHICH 4: its pre-pass (CParams::presum, forward only) over the
+    // list of the 2048 signal columns
+    auto k = col_fused_kernel<double, 8192, 0, false, 0, 4>;
+    lds = (size_t)lds_elems<8192>() * sizeof(Ct) + SCRATCH_DOUBLES * sizeof(double) + fused_ltw_bytes<double, 8192>();
+    ca.cp.mraf = 1; ca.cp.has_mraf_factor = 1; ca.cp.mraf_factor = 0.5; ca.col_xmap = 1;
+    ca.fshift = (g.r0 / 16) * 16; ca.fnr = 3;
+    grid = 512;
+    int *clist = nullptr, *nact = nullptr;
+#if WHICH == 4
+    {
+        std::vector<int> hl(N);
+        for (int i = 0; i < 2048; ++i) hl[i] = N / 2 - 1024 + i;
+        const int n = 2048;
+        hipMalloc(&clist, N * sizeof(int)); hipMalloc(&nact, sizeof(int));
+        hipMemcpy(clist, hl.data(), N * sizeof(int), hipMemcpyHostToDevice); hipMemcpy(nact, &n, sizeof(int), hipMemcpyHostToDevice);
+        ca.col_list = clist; ca.n_active = nact; ca.cp.weights_only = 1; ca.cp.presum = 1; ca.list_xmap = 1;
+    }
+    const char* name = "col_fused_kernel<double, 8192, 0, false, 0, 4> pre-pass over 2048 signal columns (cfg 5 float64)";
+#else
+    const char* name = "col_fused_kernel<double, 8192, 0, false, 0, 4> main pass, one inverse per column (cfg 5 float64)";
+#endif
 #endif
 #if HGS_TRACE
     if (lds > (size_t)HGS_TRACE_OFF) { printf("HGS_TRACE_OFF too small: kernel needs %zu bytes\n", lds); return 1; }
@@ -97,7 +120,7 @@ int main() {
     if (e != hipSuccess) { printf("hipFuncSetAttribute(%zu): %s\n", lds, hipGetErrorString(e)); return 1; }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
-#if WHICH == 2
+#if WHICH >= 2
         hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, 0, ca);
 #else
         hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, 0, ca, m0);
@@ -126,14 +149,16 @@ int main() {
             a.first += (double)((ev[i] & M56) - (ev[i - 1] & M56)); a.second++;
         }
     }
-    const char* names[40] = {};
-    names[1] = WHICH == 2 ? "column start" : "tile start"; names[2] = WHICH == 2 ? "G landed" : "tile landed"; names[3] = "fwd done";
-    names[4] = "w/t landed"; names[5] = "constraint(+issue) done"; names[6] = WHICH == 2 ? "inv + store issued" : "before tile store";
+    const char* names[64] = {};
+    names[1] = WHICH >= 2 ? "column start" : "tile start"; names[2] = WHICH >= 2 ? "G landed" : "tile landed"; names[3] = "fwd done";
+    names[4] = "w/t landed"; names[5] = "constraint(+issue) done"; names[6] = WHICH >= 2 ? "inv + store issued" : "before tile store";
     names[7] = "end"; names[8] = "signal part stored"; names[9] = "noise part done";
     names[10] = "fwd: enter core"; names[11] = "fwd: s0 done"; names[12] = "fwd: local xchg done"; names[13] = "fwd: s1 done";
     names[14] = "fwd: global xchg done"; names[15] = "fwd: s2 done"; names[16] = "fwd: radix-2 + pair xchg done";
     names[20] = "inv: enter core"; names[21] = "inv: s2 done"; names[22] = "inv: global xchg done"; names[23] = "inv: s1 done";
     names[24] = "inv: local xchg done"; names[25] = "inv: s0 done"; names[26] = "inv: pair xchg + radix-2 done";
+    static char pix[16][16];
+    for (int m = 0; m < 16; ++m) { snprintf(pix[m], 16, "pixel %d done", m); names[40 + m] = pix[m]; }
     double tot = 0;
     for (auto& kv : acc) tot += kv.second.first;
     printf("  transitions (mean ticks = shader cycles per wave; count per wave over the recorded window; share of the window)\n");
