@@ -83,6 +83,20 @@
 
 namespace hgs {
 
+#ifndef HGS_F64_LTW
+#define HGS_F64_LTW 1
+#endif
+#ifndef HGS_F64_WT_BUF
+#define HGS_F64_WT_BUF 1
+#endif
+#ifndef HGS_F64_LTW_ROW
+#define HGS_F64_LTW_ROW 0       // 1: the float64 row kernel's stage twiddles from the LDS tables too: 106.3 vs 106.4 us at cfg 5, nothing (round 6)
+#endif
+// float64 transform kernels at 4096 / 8192 points (col_fused_kernel, row_kernel): stage twiddles from the two LDS tables of
+// WgFftL LTW, and the dynamic LDS they add behind the kernel's other LDS
+template <typename R, int N> constexpr bool fused_ltw() { return HGS_F64_LTW && sizeof(R) == 8 && (N == 4096 || N == 8192); }
+template <typename R, int N> constexpr size_t fused_ltw_bytes() { return fused_ltw<R, N>() ? (size_t)LTW_N * sizeof(Cx<R>) : 0; }
+
 struct Geo {
     int Ph, Pw, Sh, Sw, r0, c0, batch;
     int lane_T;     // Ph / 16 when the columns of the farfield-sized arrays are stored lane-major (below), 0 = natural
@@ -618,9 +632,18 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
     // (fp32 instances that ran out of registers with them -- every phase-extracting launch, i.e. one per engine call, and the
     //  unshifted 8192-wide form -- fetch them per use as well: 8 .. 48 spilled VGPRs -> 0, tools/resusage.sh)
     constexpr bool TW_RES = sizeof(R) == 8 ? false : (MODE == 1 || MODE == 3 || (N >= 8192 && NS == 16)) ? false : HGS_ROW_TW_RESIDENT;
-    using Sel = FftSel<R, N, TW_RES, PREF>;
+    // float64 rows of 4096 / 8192 columns: the per-use stage twiddles from LDS tables instead of global loads inside the
+    // transform's dependent chain (round 6; the tables sit behind the transform image)
+    constexpr bool LTW = fused_ltw<R, N>() && !TW_RES && HGS_F64_LTW_ROW;
+    using Sel = FftSel<R, N, TW_RES, PREF, LTW>;
     typename Sel::type fft;
     fft.init(a.tw, j);
+    if constexpr (LTW) {
+        Cx<R>* ltab = reinterpret_cast<Cx<R>*>(smem) + FPW * lds_elems<N>();
+        Sel::type::ltw_fill(a.tw, ltab, tid, (int)blockDim.x);
+        fft.set_ltw(ltab);
+        __syncthreads();
+    }
 
     // lane j owns elements j + m*T of the frequency side (GH columns) and js + m*T of the space side (SLM columns)
     const int js = Sel::space_lane(j);
@@ -1018,16 +1041,6 @@ template <int N> struct ColCfg {
     static constexpr int WG = T * CPAR;
     static constexpr int PASSES = 4 / CPAR;
 };
-
-#ifndef HGS_F64_LTW
-#define HGS_F64_LTW 1
-#endif
-#ifndef HGS_F64_WT_BUF
-#define HGS_F64_WT_BUF 1
-#endif
-// col_fused_kernel: LDS twiddle tables (float64, the row-local transforms) and the dynamic LDS they add behind the scratch
-template <typename R, int N> constexpr bool fused_ltw() { return HGS_F64_LTW && sizeof(R) == 8 && (N == 4096 || N == 8192); }
-template <typename R, int N> constexpr size_t fused_ltw_bytes() { return fused_ltw<R, N>() ? (size_t)LTW_N * sizeof(Cx<R>) : 0; }
 
 template <typename R> struct ColArgs {
     Geo g;

@@ -22,7 +22,7 @@ static int launch_row_one(dim3 grid, hipStream_t s, const RowArgs<R>& a) {
     // a masked launch (active columns only) gains from the fourth -- 20.5 -> 19.0 us, 103 -> 88 us -- a dense one does
     // not (28.2 us either way; batch 174 -> 195 us: the load bursts of 1,024 rows at once).  Asking for 48 KB of LDS
     // keeps a dense launch at three.
-    constexpr size_t lds_need = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<R>);
+    constexpr size_t lds_need = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<R>) + (HGS_F64_LTW_ROW ? fused_ltw_bytes<R, N>() : 0);
     const bool masked = a.load_mask != nullptr || a.store_mask != nullptr;
     const size_t lds = (NS < 16 && N == 4096 && !masked && lds_need < 48 * 1024) ? (size_t)48 * 1024 : lds_need;
     auto k = row_kernel<R, N, MODE, NS>;
@@ -96,7 +96,7 @@ template <> int launch_row<HGS_REAL>(int N, int mode, dim3 grid, hipStream_t s, 
 // the two parts, H = gh * wscale + gh2 (a.gh2 and a.gh2_mask set); rows of 4096 / 8192 (the split form has one-row workgroups)
 template <int N, int MODE, int NS = 16>
 static int launch_row_split64_one(dim3 grid, hipStream_t s, const RowArgs<double>& a) {
-    constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<double>);
+    constexpr size_t lds = (size_t)RowCfg<N>::FPW * lds_elems<N>() * sizeof(Cx<double>) + (HGS_F64_LTW_ROW ? fused_ltw_bytes<double, N>() : 0);
     auto k = row_kernel<double, N, MODE, NS, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -119,7 +119,8 @@ int launch_row_split(int N, int mode, dim3 grid, hipStream_t s, const RowArgs<do
 
 template <> size_t row_lds_bytes<HGS_REAL>(int N) {
     const int T = N / 16, WG = T >= 256 ? T : 256;
-    return (size_t)(WG / T) * (N + N / 16) * sizeof(Cx<HGS_REAL>);
+    return (size_t)(WG / T) * (N + N / 16) * sizeof(Cx<HGS_REAL>) +
+           ((HGS_F64_LTW_ROW && sizeof(HGS_REAL) == 8 && (N == 4096 || N == 8192)) ? (size_t)LTW_N * sizeof(Cx<HGS_REAL>) : 0);
 }
 
 }  // namespace hgs
