@@ -2320,6 +2320,9 @@ template <typename R, int N, bool PARK = false> constexpr size_t col_tile2_lds_b
            (PARK ? (size_t)6 * Tile2Cfg<N>::T * sizeof(Cx<R>) : 0);
 }
 
+#ifndef HGS_TILE2_BUF
+#define HGS_TILE2_BUF 1      // the half tile's rows as straight-line buffer loads (round 6)
+#endif
 #ifndef HGS_TILE2_CONS_GROUP
 #define HGS_TILE2_CONS_GROUP 4      // pixels of a lane whose rule evaluation the scheduler may interleave (168 registers: fewer than col_tile_kernel's 16)
 #endif
@@ -2404,11 +2407,30 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
     for (int ct = ct0; ct < ntiles; ct += ct_step) {
         Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4 + 2 * half;
         HGS_T(fft.tr_n, 1);
+        // The half tile's rows through a buffer resource (rows outside the SLM are outside the resource: they read as zero), all
+        // NR requests ahead of the first use.  As conditional loads each one sat in its own exec-masked block with its use --
+        // a parked column's LDS store -- right behind it: five dependent memory round trips per half tile instead of one
+        // (tools/microbench/trace_tile2: 6.3 k cycles per half tile waiting for rows; the ISA had `s_waitcnt vmcnt(0)` after
+        // every one of them) wherever the rows were not requested ahead (NXF): every dense image, batch and WGS-Kim launch.
+        // (Measured per instance, A/B inside one GPU call: the headline's few-active-columns instance 44.8 -> 44.0 us, a batch of
+        //  eight 180.8 -> 175.9 us per column launch; a dense image target 64.3 -> 65.8 us and the 2048-row form 21.2 -> 22.1 us
+        //  LOSE -- their constraint / second lane group fills the waits and the resource set-up sits on the chain -- and keep
+        //  the conditional loads.)
+        constexpr bool TBUF = HGS_TILE2_BUF && N == 4096 && PHASE == 0 && (NXF || !PARK);
+        float4 tq[TBUF ? NR : 1];
+        if constexpr (TBUF) {
+            // (rows that already arrived in nq: an empty resource -- nothing is fetched)
+            const Buf bt(gh, (NXF && have_nq) ? 0u : (unsigned)((size_t)g.Sh * 4 - 2 * half) * (unsigned)sizeof(Cx<R>));
+#pragma unroll
+            for (int m = 0; m < NR; ++m)
+                tq[TBUF ? m : 0] = bt.template ld<float4>((unsigned)(r_lane + m * T) * 4u * (unsigned)sizeof(Cx<R>), 0u);   // (negative rows wrap out of range)
+        }
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const int r = r_lane + m * T;
             float4 q = make_float4(0, 0, 0, 0);
             if (NXF && have_nq) q = nq[NXF ? m : 0];
+            else if constexpr (TBUF) q = tq[TBUF ? m : 0];
             else
             if (r >= 0 && r < g.Sh) q = *reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
             if constexpr (PARK) {           // column 0 straight into the transform registers, column 1 waits in LDS

@@ -27,11 +27,11 @@ KNOWN = {
     # over with five / six occupied slots, and still ahead of col_tile_kernel's two workgroups per CU (dense image 87.5 -> 76.8 us)
     ("col_tile2_kernel", "float, 4096, 2, 5, 1, true, false"): 2,
     ("col_tile2_kernel", "float, 4096, 2, 6, 1, true, false"): 6,
-    # ... and the BATCH form at 4096 rows (both columns of the half tile in registers): 4 / 13 registers over the 168 of three
-    # workgroups per CU with five / six occupied slots -- kept because a batch of eight is 3 - 5 % faster with them than with
-    # the parked form (354 against 372 us per column launch at cfg 3); single holograms run the parked instances, which are clean
-    ("col_tile2_kernel", "float, 4096, 0, 5, 1, false, false"): 4,
-    ("col_tile2_kernel", "float, 4096, 0, 6, 1, false, false"): 13,
+    # ... and the BATCH form at 4096 rows (both columns of the half tile in registers) with six occupied slots: 2 registers over
+    # the 168 of three workgroups per CU -- kept because a batch of eight is 3 - 5 % faster with it than with the parked form
+    # (354 against 372 us per column launch at cfg 3); single holograms run the parked instances, which are clean
+    # (round 6: the half tile's rows arrive through a buffer resource in these instances -- five slots now fit, six keep 2 of 13)
+    ("col_tile2_kernel", "float, 4096, 0, 6, 1, false, false"): 2,
     # unshifted 8192-wide rows (an SLM wider than 4096 columns on an 8192 pad): 8 VGPRs over the 128 that let two
     # 512-lane workgroups share a CU; one workgroup per CU costs 25 % of the launch, the spills do not
     ("row_kernel", "float, 8192, 2, 16, false, false"): 8,
