@@ -42,6 +42,9 @@
 #ifndef HGS_ROW_PHASOR
 #define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
 #endif
+#ifndef HGS_ROW_AMP_PREFETCH
+#define HGS_ROW_AMP_PREFETCH 1
+#endif
 #ifndef HGS_SPARSE_SKIP
 #define HGS_SPARSE_SKIP 1
 #endif
@@ -815,6 +818,17 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 HGS_T(fft.tr_n, 5);
             }
         } else {
+        // An array-valued source amplitude (a measured beam: the usual laboratory case) is requested HERE, ahead of the inverse
+        // transform, through a buffer resource (columns outside the SLM are outside it and read as zero; no array: an empty
+        // one).  Fetched where it is used -- inside the per-slot exec-masked block of the phasor, `s_waitcnt vmcnt(0)` right
+        // behind each load -- it was NS dependent memory round trips per row: cfg 2 with a Gaussian amplitude 73.0 against
+        // 65.5 us per iteration with the scalar one (tools/amp_array_probe.py, round 6).
+        constexpr bool AMPF = HGS_ROW_AMP_PREFETCH && MODE >= 2 && T % 64 == 0 && !(N >= 8192 && NS == 16);
+        R amr[AMPF ? NS : 1];
+        if constexpr (AMPF) {
+            const Buf bam(am, (am != nullptr && valid) ? (unsigned)g.Sw * (unsigned)sizeof(R) : 0u);
+            static_for<0, NS>([&](auto m_) { constexpr int m = m_; amr[m] = bam.template ld<R>((unsigned)(c_lane + m * T) * (unsigned)sizeof(R), 0u); });
+        }
         if constexpr (MODE != 0) {
             // ---- load H row, centred inverse transform along x ----
             if constexpr (PREF) {
@@ -927,7 +941,9 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 const int c = c_lane + m * T;
                 Cx<R> nf = mk<R>(0, 0);
                 if (valid && c >= 0 && c < g.Sw) {
-                    const R amv = (am != nullptr) ? am[c] : a.amp_scalar;
+                    R amv;
+                    if constexpr (AMPF) amv = (am != nullptr) ? amr[m] : a.amp_scalar;
+                    else amv = (am != nullptr) ? am[c] : a.amp_scalar;
                     if constexpr (MODE == 3) {                  // the phase exactly as MODE 1 stores it ...
                         const R scs = sgs * a.scale;
                         R p = M::atan2(v[m].y * scs, v[m].x * scs);
