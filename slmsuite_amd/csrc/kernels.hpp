@@ -1957,8 +1957,13 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             bool noise_any = false;
             // RULE 4 with the column flags of the scan (list launches): a column without a finite non-zero target has an
             // all-zero signal part, one without a NaN target an all-zero noise part -- known before the column is touched
+            // (the tile's four scan bytes as one aligned word through the scalar cache: a uniform BYTE load is a vector memory
+            //  instruction with a full round trip and a vmcnt(0) drain behind it)
             int cflags = -1;
-            if constexpr (FIXED) { if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c]; }
+            if constexpr (FIXED) {
+                if (a.col_flags != nullptr)
+                    cflags = (int)((__builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(a.col_flags + (size_t)b * g.Pw)[ct]) >> (8 * c)) & 0xffu);
+            }
             // (PRESUM: one inverse carries both parts -- skipped only where the column holds neither)
             const bool has_sig = cflags < 0 || (cflags & (PRESUM ? 6 : 2)) != 0;
             fft.template fwd_lead<NR>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
@@ -2219,12 +2224,21 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_presum_kernel(ColAr
     R wr[16], tr[16], wn[16], tn[16];
     // the signal columns of this workgroup's tiles (ct = blockIdx.x + k gridDim.x), in order: (tile, column) -> the next one.
     // Uniform scalar walk over the scan bits; a workgroup owns a handful of tiles.
+    // (the four scan bytes of a tile as ONE aligned word, the 16-bit slot masks likewise: uniform dword loads go through the
+    //  scalar cache; as byte / half-word loads they were vector memory instructions with `s_waitcnt vmcnt(0)` behind each --
+    //  one to four dependent memory round trips per column before its weights could even be requested, and a drain of
+    //  whatever else was in flight)
     const int ntile = g.Pw / 4;
+    const unsigned* flags4 = reinterpret_cast<const unsigned*>(flags);      // (Pw is a multiple of 4)
+    unsigned f4 = 0;
+    int ct_f4 = -1;
     auto next_signal = [&](int& ct, int& c) -> bool {          // advances (ct, c); false at the end
         for (;;) {
             if (++c >= 4) { c = 0; ct += (int)gridDim.x; }
             if (ct >= ntile) return false;
-            if ((flags[ct * 4 + c] & 2) != 0) return true;
+            if (ct != ct_f4) { f4 = __builtin_amdgcn_readfirstlane(flags4[ct]); ct_f4 = ct; }
+            if ((f4 & 0x02020202u) == 0) { c = 3; continue; }        // no signal column in this tile
+            if (((f4 >> (8 * c)) & 2u) != 0) return true;
         }
     };
     int ct = blockIdx.x, c = -1;
@@ -2237,7 +2251,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_presum_kernel(ColAr
 #if HGS_PRESUM_ABL
         presum_abl_loads<R, T>(a.w + cb, a.t + cb, true, j, wn, tn);
 #else
-        const unsigned sl = a.sig_rows != nullptr ? a.sig_rows[(size_t)b * g.Pw + ct * 4 + c] : 0xffffu;
+        unsigned sl = 0xffffu;
+        if (a.sig_rows != nullptr) {
+            const size_t si = (size_t)b * g.Pw + ct * 4 + c;
+            sl = (__builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(a.sig_rows)[si >> 1]) >> (16 * (int)(si & 1))) & 0xffffu;
+        }
         const float4* wq = reinterpret_cast<const float4*>(a.w + cb + lane_pos<T>(j, 0));
         const float4* tq = reinterpret_cast<const float4*>(a.t + cb + lane_pos<T>(j, 0));
         static_for<0, 4>([&](auto q_) {
@@ -2255,15 +2273,19 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_presum_kernel(ColAr
     while (have) {
         if (ct != ct_loaded) {
             const Cx<R>* gh = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)ct * g.Sh * 4;
+            // (straight-line buffer loads -- rows outside the SLM are outside the resource -- so that the NR row requests are in
+            //  flight together: as conditional loads each slot's pair was waited for before the next was issued)
+            const Buf bt(gh, (unsigned)g.Sh * 4u * (unsigned)sizeof(Cx<R>));
+            float4 lo_[NR], hi_[NR];
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
-                const int r = r_lane + m * T;
-                float4 lo = make_float4(0, 0, 0, 0), hi = lo;
-                if (r >= 0 && r < g.Sh) {
-                    const float4* q = reinterpret_cast<const float4*>(gh + (unsigned)r * 4u);
-                    lo = q[0];
-                    hi = q[1];
-                }
+                const unsigned vo = (unsigned)(r_lane + m * T) * 4u * (unsigned)sizeof(Cx<R>);
+                lo_[m] = bt.template ld<float4>(vo, 0u);
+                hi_[m] = bt.template ld<float4>(vo + 16u, 0u);
+            }
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const float4 lo = lo_[m], hi = hi_[m];
                 gtx[m][0] = lo.x; gty[m][0] = lo.y; gtx[m][1] = lo.z; gty[m][1] = lo.w;
                 gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
             }
