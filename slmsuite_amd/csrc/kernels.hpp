@@ -1960,9 +1960,11 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // (the tile's four scan bytes as one aligned word through the scalar cache: a uniform BYTE load is a vector memory
             //  instruction with a full round trip and a vmcnt(0) drain behind it)
             int cflags = -1;
-            if constexpr (FIXED) {
+            if constexpr (PRESUM) {
                 if (a.col_flags != nullptr)
                     cflags = (int)((__builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(a.col_flags + (size_t)b * g.Pw)[ct]) >> (8 * c)) & 0xffu);
+            } else if constexpr (FIXED) {      // (RULE 4, the split form over a list: runs once per new set of weights since round 6; left as it was)
+                if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c];
             }
             // (PRESUM: one inverse carries both parts -- skipped only where the column holds neither)
             const bool has_sig = cflags < 0 || (cflags & (PRESUM ? 6 : 2)) != 0;
@@ -2358,6 +2360,9 @@ template <typename R, int N, bool PARK = false> constexpr size_t col_tile2_lds_b
            (PARK ? (size_t)6 * Tile2Cfg<N>::T * sizeof(Cx<R>) : 0);
 }
 
+#ifndef HGS_TILE2_BUF_ST
+#define HGS_TILE2_BUF_ST 1   // ... and, in the instances that request the next half tile ahead (NXF), those requests and the stores behind them
+#endif
 #ifndef HGS_TILE2_BUF
 #define HGS_TILE2_BUF 1      // the half tile's rows as straight-line buffer loads (round 6)
 #endif
@@ -2614,6 +2619,20 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
                 outq[m] = make_float4(h0.x, h0.y, h1.x, h1.y);
             }
             have_nq = NXF && ct + ct_step < ntiles;
+            if constexpr (TBUF && NXF && HGS_TILE2_BUF_ST) {
+                // straight-line: NR loads through a resource that is empty when there is no next half tile, then NR stores through
+                // one that drops rows outside the SLM -- the compiler can count what is in flight, so the wait for the new rows at
+                // the top of the loop is vmcnt(NR), not vmcnt(0): it no longer includes the acknowledgement of these stores
+                const Cx<R>* ghn = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)(have_nq ? ct + ct_step : ct) * g.Sh * 4 + 2 * half;
+                const unsigned tbytes = (unsigned)((size_t)g.Sh * 4 - 2 * half) * (unsigned)sizeof(Cx<R>);
+                const Buf bn(ghn, have_nq ? tbytes : 0u), bs(gh, tbytes);
+#pragma unroll
+                for (int m = 0; m < NR; ++m)
+                    nq[NXF ? m : 0] = bn.template ld<float4>((unsigned)(r_lane + m * T) * 4u * (unsigned)sizeof(Cx<R>), 0u);
+#pragma unroll
+                for (int m = 0; m < NR; ++m)
+                    bs.template st<float4>(outq[m], (unsigned)(r_lane + m * T) * 4u * (unsigned)sizeof(Cx<R>), 0u);
+            } else {
             if (NXF && have_nq) {
                 const Cx<R>* ghn = a.gh + (size_t)b * g.Sh * g.Pw + (size_t)(ct + ct_step) * g.Sh * 4 + 2 * half;
 #pragma unroll
@@ -2627,6 +2646,7 @@ __global__ __launch_bounds__(Tile2Cfg<N>::WG, (N >= 4096 ? 3 : 2)) void col_tile
             for (int m = 0; m < NR; ++m) {
                 const int r = r_lane + m * T;
                 if (r >= 0 && r < g.Sh) *reinterpret_cast<float4*>(gh + (unsigned)r * 4u) = outq[m];
+            }
             }
         }
     }

@@ -37,13 +37,14 @@ KNOWN = {
     ("row_kernel", "float, 8192, 2, 16, false, false"): 8,
     # single-pass MRAF with the SLM rows over five or six register slots: the noise tile no longer fits in registers and
     # the rule-specialised / phase-storing forms run 4 .. 16 registers over; cfg 5 and every geometry of 1152 / 1080 / 1200
-    # rows on 8192 runs the four-slot instances, which are clean
-    ("col_tile_kernel", "float, 4096, 1, 6, false, true, 4, -1"): 16,
-    ("col_tile_kernel", "float, 4096, 2, 6, false, true, 4, -1"): 8,
-    ("col_tile_kernel", "float, 8192, 0, 6, false, true, 4, -1"): 8,
-    ("col_tile_kernel", "float, 8192, 1, 6, false, true, 4, -1"): 20,
-    ("col_tile_kernel", "float, 8192, 2, 6, false, true, 4, -1"): 8,
-    ("col_tile_kernel", "float, 8192, 1, 6, false, true, 3, -1"): 8,
+    # rows on 8192 runs the four-slot instances, which are clean.  (Since round 6 the split form runs once per new set of weights:
+    # every later update takes col_tile_kernel RULE 5 behind its pre-pass, whose instances are all clean.)
+    ("col_tile_kernel", "float, 4096, 1, 6, false, true, 4, -1"): 12,
+    ("col_tile_kernel", "float, 4096, 2, 6, false, true, 4, -1"): 6,
+    ("col_tile_kernel", "float, 8192, 0, 6, false, true, 4, -1"): 4,
+    ("col_tile_kernel", "float, 8192, 1, 6, false, true, 4, -1"): 16,
+    ("col_tile_kernel", "float, 8192, 2, 6, false, true, 4, -1"): 4,
+    ("col_tile_kernel", "float, 8192, 1, 6, false, true, 3, -1"): 4,
     # the SPLIT row kernel (joins the two parts of a single-pass MRAF field) reads a second H row: the 8192-wide forms are
     # compiled for 128 VGPRs (two workgroups per CU: 66 against 86 us, NOTEBOOK round 4) and keep 2 .. 54 spilled ones
     ("row_kernel", "float, 8192, 1, 8, false, true"): 24,
