@@ -198,8 +198,12 @@ int hgs_sync(hgs_engine* e);
  *   Where the tile-resident kernel applies (fp32, pad_h >= 4096) and the active columns fill their 4-column tiles at
  *   least half (images, MRAF noise boxes), the active set is rounded up to whole tiles and that kernel walks the tile
  *   list; results are those of the dense launch bit for bit.
- *   MRAF with a weight update runs ONE column pass on that kernel (the signal and the noise part of the rebuilt field are
- *   transformed separately and joined by the row kernel once ||w'|| is known), two passes elsewhere.
+ *   MRAF with a weight update runs ONE column pass with ONE inverse per column (round 6): the weights that enter an update are
+ *   normalised, so ||w'||^2 = 1 + D, D = the sum over the signal pixels of w'^2 - w^2, which a forward-only pre-pass over the
+ *   columns that hold signal pixels forms before the pass rebuilds the field (WGS-Leonardo / WGS-Kim without in-pass statistics;
+ *   float32 and float64).  The first update after new weights or a new target -- and the other rules -- split the rebuilt field
+ *   instead (its signal and noise part are transformed separately and joined by the row kernel once ||w'|| is known), or take
+ *   two passes where neither form applies.
  * HGS_OPT_FORCE_STEPWISE (default 0): hgs_iterate / hgs_iterate_stats loop the three general operators
  *   (materialised farfield) even where a fused kernel exists -- the reference's own op sequence; used by tests.
  * HGS_OPT_TILE_KERNEL (default 1): use the tile-resident fused column kernels where they apply (fp32: col_tile_kernel at
@@ -213,7 +217,8 @@ int hgs_sync(hgs_engine* e);
  * hgs_create (which reads the developer overrides once: the grid sizes HGS_ROW_BLOCKS / HGS_COL_BLOCKS / HGS_TILE_BLOCKS /
  * HGS_TILE2_BLOCKS / HGS_ROW_PREF_BLOCKS, and the A/B switches HGS_ROW_XCD, HGS_COL_XMAP, HGS_ROW_SHIFT, HGS_ROW_SHIFT64, HGS_ROW_PREF,
  * HGS_ROW_PREF_BATCH, HGS_TILE_RULE, HGS_MRAF_SPLIT, HGS_MRAF_SPLIT64, HGS_GH2_MASK, HGS_TILE_LIST, HGS_TILE_SHIFT16, HGS_TILE_NR4,
- * HGS_TILE2, HGS_TILE2_MIN_BATCH, HGS_TILE2_PHASE2, HGS_KEEP_G, HGS_FUSED_SHIFT, HGS_MONO_TAB -- all default to the tuned path;
+ * HGS_TILE2, HGS_TILE2_MIN_BATCH, HGS_TILE2_PHASE2, HGS_KEEP_G, HGS_FUSED_SHIFT, HGS_MONO_TAB, HGS_MRAF_PRESUM, HGS_PRESUM_ROWS,
+ * HGS_PRESUM_BLOCKS -- all default to the tuned path;
  * HGS_TRACE_INIT=1 prints where hgs_create spends its time).
  *   HGS_KEEP_G (default 1): the last row launch of a float32 hgs_iterate call leaves G of the next body behind, and the next
  *   call -- or hgs_nearfield2farfield -- on an unchanged phase starts from it.  That G is the loop's own un-rounded phasor

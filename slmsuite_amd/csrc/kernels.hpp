@@ -42,6 +42,9 @@
 #ifndef HGS_ROW_PHASOR
 #define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
 #endif
+#ifndef HGS_LIST_SLOAD
+#define HGS_LIST_SLOAD 1
+#endif
 #ifndef HGS_ROW_AMP_PREFETCH
 #define HGS_ROW_AMP_PREFETCH 1
 #endif
@@ -502,6 +505,12 @@ struct Buf {
         else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, x), r, voff, soff, 0);
     }
 };
+// one int at a wave-uniform address through the scalar cache (memory the kernel itself does not write)
+__device__ __forceinline__ int uniform_load_i32(const int* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 // 1 / sqrt(x) from the hardware instruction (1 ulp), pre-scaled where x is too small for it (v_rsq_f32 takes
 // denormal inputs as zero): the values of rsqrtf() without its inlined control flow
 __device__ __forceinline__ float rsqrt_full(float x) {
@@ -1357,9 +1366,22 @@ __global__ __launch_bounds__(ColCfg<N>::WG, HGS_FUSED_OCC) void col_fused_kernel
     constexpr bool PF_AHEAD = PHASE == 2 && !LEAN && HGS_PF_AHEAD && HGS_LANE_MAJOR;
     float4 pfq0 = make_float4(0, 0, 0, 0), pfq1 = pfq0, pfq2 = pfq0, pfq3 = pfq0;      // (four 16-byte registers, not an array: R[16] left 12 bytes on the stack)
 
+    // (list launches: the entry of sweep q is asked for three times per column -- at the top of the loop, by the weight /
+    //  target prefetch and by the G prefetch of the column after it.  As a plain load of a uniform address it was a VECTOR load
+    //  each time (the list is not provably invariant, so no scalar load) with `s_waitcnt vmcnt(0)` behind it: the second one
+    //  waited for the weight stores just issued, the third for the weight / target prefetch just requested -- which was
+    //  meant to land under the inverse transform.  Where a lane group is whole waves the entry comes through the scalar cache
+    //  (inline `s_load_dword`: lgkmcnt, not vmcnt) and is kept for the next two askers.)
+    int col_cache_q = -1, col_cache = 0;
     auto col_of = [&](int q, int& ct, int& c4) {
         if (listed) {
-            const int col = clist[min(grp_of(q) * CPAR + cpar, n_act - 1)];
+            int col;
+            if constexpr (T % 64 == 0 && HGS_LIST_SLOAD) {
+                if (q != col_cache_q) { col_cache = uniform_load_i32(clist + min(grp_of(q) * CPAR + cpar, n_act - 1)); col_cache_q = q; }
+                col = col_cache;
+            } else {
+                col = clist[min(grp_of(q) * CPAR + cpar, n_act - 1)];
+            }
             ct = col >> 2;
             c4 = col & 3;
             return;

@@ -34,6 +34,22 @@ for l in sys.stdin:
     d=json.loads(l); r=d['roofline']; print('   it/s %7.0f col %6.1f row %5.1f presum %5.1f us'%(d['value'],r['launch_us'],r['row_launch_us'],(r.get('presum_launch') or {}).get('launch_us',0)))"; }
       for v in "HGS_PRESUM_LEAN=0" "HGS_PRESUM_LEAN=1" "HGS_PRESUM_LEAN=1 HGS_PRESUM_BLOCKS=256" "HGS_PRESUM_LEAN=1 HGS_PRESUM_BLOCKS=768" "HGS_PRESUM_LEAN=0 HGS_PRESUM_BLOCKS=512" "HGS_PRESUM_LEAN=0" "HGS_PRESUM_LEAN=1"; do
         echo "$v"; env $v bash -c "$(declare -f b); b --workload cfg5mraf --steps 40 --warmup 5"; done ;;
+    final)    # the evidence of the round on the final tree: gpurun_out/ -> profiles/r06/ (copied by hand)
+      HGS_TEST_BUDGET_S=0 timeout 900 python -m pytest tests/test_fuzz_parity.py -m gpu -q -k "large" -p no:cacheprovider 2>&1 | tail -5 > gpurun_out/r6_slow_cases.log
+      timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6_bench_cfg2_driver_protocol.json 2> gpurun_out/r6_bench_driver.err
+      timeout 600 python bench.py > gpurun_out/r6_bench_cfg2_n1.json 2> gpurun_out/r6_bench_n1.err
+      bash tools/gpu_r4.sh profiles r06
+      bash tools/gpu_r4.sh configs
+      python tools/call_overhead_probe.py > gpurun_out/r6_call_overhead.json 2> gpurun_out/r6_call_overhead.err
+      python tools/e2e_timing.py gpurun_out/r6_e2e.json > /dev/null 2> gpurun_out/r6_e2e.err
+      : > gpurun_out/r6_first_use.jsonl
+      for m in "" dense "" dense; do python tools/first_use_probe.py $m 2>/dev/null >> gpurun_out/r6_first_use.jsonl; done
+      python tools/amp_array_probe.py > gpurun_out/r6_amp_array.json 2>/dev/null
+      bash tools/cfg3_steadiness.sh 10 > /dev/null 2>&1
+      tools/microbench/pow_rule64 > gpurun_out/r6_pow_rule64.log 2>&1
+      for v in 0 1; do HGS_MRAF_PRESUM=$v timeout 300 python bench.py --cpu-iters 0 --pmc 0 --workload cfg5mraf --steps 40 --warmup 5 2>/dev/null | grep '^{' >> gpurun_out/r6_ab_mraf_presum.jsonl
+                       HGS_MRAF_PRESUM=$v timeout 300 python bench.py --cpu-iters 0 --pmc 0 --workload cfg5mraf --dtype f64 --steps 20 --warmup 3 2>/dev/null | grep '^{' >> gpurun_out/r6_ab_mraf_presum.jsonl; done
+      ls gpurun_out | head -80 ;;
     t) shift; timeout ${TMO:-1200} python -m pytest "$@" -m gpu -q -x -p no:cacheprovider 2>&1 | tail -${TAIL:-25} ;;
     *) bash tools/gpu_r5.sh "$@" ;;
   esac
