@@ -2332,6 +2332,14 @@ template <typename R> struct Engine : EngineBase {
                     } else if (tile_path) {
                         wpartial_n = tile_grid;
                         const bool extras = a.cp.mraf || a.cp.nog_pass || a.cp.weights_only;
+                        // MRAF without a weight update (GS, iteration 0, the no-update bodies of WGS): the rule-free MRAF form
+                        // compiled per slot count (col_tile_kernel RULE 6) instead of the generic six-slot instance
+                        const bool mraf_plain = a.cp.mraf && !a.cp.do_update && !a.cp.nog_pass && !a.cp.weights_only &&
+                                                !a.do_stats && opt_tile_rule && opt_mraf_presum && sizeof(R) == 4 && !a.cp.zero_mode;
+                        if (mraf_plain) {
+                            if (sp) a.col_flags = col_active;
+                            LCHK(tile_presum(g.Ph, phase_mode, m1 - m0 + 1, dim3(tile_grid, B), stream, a, m0));
+                        } else
                         if (extras) {
                             if (a.do_stats) LCHK(launch_tile_extras_stats<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));
                             else LCHK(launch_tile_extras<R>(g.Ph, phase_mode, dim3(tile_grid, B), stream, a, m0));

@@ -1779,6 +1779,7 @@ template <typename R, int N> constexpr size_t col_tile_split_lds_bytes() {
 // the columns that hold signal pixels (a quarter of them at cfg 5) before this launch.  The field is rebuilt with the final
 // scale: no second inverse in the columns that hold noise, no parked noise part in LDS (the next tile is staged again), no
 // second array for the row kernel to join.
+// 6 = MRAF without a weight update, compiled per slot count like 5 (GS on an MRAF target: 240 -> 2xx us at cfg 5).
 // LISTED: -1 = the tile schedule is decided at run time (a.col_list), 0 / 1 = compiled in (the hot dense launches lose
 // 0.4 us of 51.5 with the run-time form).
 template <typename R, int N, int PHASE, int NR, bool STATS = false, bool EXTRAS = true, int RULE = 0, int LISTED = -1>
@@ -1795,14 +1796,16 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
 
     constexpr bool TPREF = N >= 8192;
     constexpr bool SPLIT = RULE == 3 || RULE == 4;     // 4: ... with the WGS-Leonardo / WGS-Kim update compiled in, MRAF on, no
-    constexpr bool FIXED = RULE == 4 || RULE == 5;     //    Nogrette sum, not forward-only (the cfg 5 launch)
+    constexpr bool FIXED = RULE == 4 || RULE == 5 || RULE == 6;     //    Nogrette sum, not forward-only (the cfg 5 launch)
+    constexpr bool NOUPD = RULE == 6;                  // 6: MRAF compiled in, NO weight update (GS, iteration 0 of a WGS run, the steps of a
+                                                       //    callback loop between updates): the generic form ran the six-slot instance
     constexpr bool PRESUM = RULE == 5;                 // 5: the same rule, the field rebuilt with the pre-summed 1 / ||w'||
-    static_assert(!(SPLIT || PRESUM) || EXTRAS, "col_tile_kernel: RULE 3 / 4 / 5 are EXTRAS forms");
+    static_assert(!(SPLIT || PRESUM || RULE == 6) || EXTRAS, "col_tile_kernel: RULE 3 / 4 / 5 / 6 are EXTRAS forms");
     using Sel = FftSel<R, N, true, TPREF>;
     typename Sel::type fft;
     fft.init(a.tw, j);
     const CParams<R> cp = a.cp;
-    const bool do_upd = (RULE == 1 || FIXED) ? true : (RULE == 2 ? false : cp.do_update != 0);
+    const bool do_upd = NOUPD ? false : (RULE == 1 || FIXED) ? true : (RULE == 2 ? false : cp.do_update != 0);
     const int js = Sel::space_lane(j);       // rows js + m*T (space side), farfield pixels j + m*T (frequency side)
     const R sgn = (j & 1) ? (R)-1 : (R)1;
     const R sgs = (js & 1) ? (R)-1 : (R)1;
@@ -1982,14 +1985,14 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // (the tile's four scan bytes as one aligned word through the scalar cache: a uniform BYTE load is a vector memory
             //  instruction with a full round trip and a vmcnt(0) drain behind it)
             int cflags = -1;
-            if constexpr (PRESUM) {
+            if constexpr (PRESUM || NOUPD) {
                 if (a.col_flags != nullptr)
                     cflags = (int)((__builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(a.col_flags + (size_t)b * g.Pw)[ct]) >> (8 * c)) & 0xffu);
             } else if constexpr (FIXED) {      // (RULE 4, the split form over a list: runs once per new set of weights since round 6; left as it was)
                 if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c];
             }
             // (PRESUM: one inverse carries both parts -- skipped only where the column holds neither)
-            const bool has_sig = cflags < 0 || (cflags & (PRESUM ? 6 : 2)) != 0;
+            const bool has_sig = cflags < 0 || (cflags & ((PRESUM || NOUPD) ? 6 : 2)) != 0;
             fft.template fwd_lead<NR>(v, lds, j);     // slots NR.. are zero (rows outside the SLM)
 
             R* wc = a.w + cb;

@@ -5,21 +5,27 @@
 
 namespace hgs {
 
-template <int N, int PHASE, int NR>
+template <int N, int PHASE, int NR, int RULE>
 static int launch_tile_presum_one(dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
     constexpr size_t lds = col_tile_lds_bytes<float, N>();
-    auto k = col_tile_kernel<float, N, PHASE, NR, false, true, 5>;
+    auto k = col_tile_kernel<float, N, PHASE, NR, false, true, RULE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    dispatch_note(dispatch_site<KTile, float, N, PHASE, NR, false, true, 5, -1>(), col_flags(grid, a));
+    dispatch_note(dispatch_site<KTile, float, N, PHASE, NR, false, true, RULE, -1>(), col_flags(grid, a));
     hipLaunchKernelGGL(k, grid, dim3(N / 16), lds, s, a, m0);
     return (int)hipGetLastError();
 }
+// rule 5: the update behind its pre-pass (a.dpartial set); rule 6: MRAF without a weight update
 template <int N, int NR>
 static int launch_tile_presum_n(int phase, dim3 grid, hipStream_t s, const ColArgs<float>& a, int m0) {
-    if (phase == 0) return launch_tile_presum_one<N, 0, NR>(grid, s, a, m0);
-    if (phase == 1) return launch_tile_presum_one<N, 1, NR>(grid, s, a, m0);
-    return launch_tile_presum_one<N, 2, NR>(grid, s, a, m0);
+    if (a.cp.do_update) {
+        if (phase == 0) return launch_tile_presum_one<N, 0, NR, 5>(grid, s, a, m0);
+        if (phase == 1) return launch_tile_presum_one<N, 1, NR, 5>(grid, s, a, m0);
+        return launch_tile_presum_one<N, 2, NR, 5>(grid, s, a, m0);
+    }
+    if (phase == 0) return launch_tile_presum_one<N, 0, NR, 6>(grid, s, a, m0);
+    if (phase == 1) return launch_tile_presum_one<N, 1, NR, 6>(grid, s, a, m0);
+    return launch_tile_presum_one<N, 2, NR, 6>(grid, s, a, m0);
 }
 
 // the main pass; a.dpartial / a.n_dpartial from launch_presum

@@ -336,13 +336,15 @@ def test_single_pass_mraf_matches_the_two_pass_form(n, slm, method, extra, monke
         # body 0 has no weight update (one plain MRAF pass); body 1 updates: ONE pass of RULE 3 + a SPLIT row launch, or
         # two passes of the generic kernel (forward + rule, then forward + rebuild + inverse) + a plain row launch
         nog = 1 if method == "WGS-Nogrette" else 0          # its forward-only pass that sums feedback / target
+        # (round 6: an MRAF pass WITHOUT a weight update -- body 0, the rebuilding pass of the two-pass form -- runs the rule-free
+        #  instance compiled per slot count, col_tile_kernel RULE 6, instead of the generic six-slot one)
         if split == "1":
             assert d.count("col_tile_kernel", N=n, NR=nr, EXTRAS=True, RULE=3) == 1, d
             assert d.count("row_kernel", N=n, SPLIT=True) == 1, d
-            assert d.count("col_tile_kernel", EXTRAS=True, RULE=0) == 1 + nog, d
+            assert d.count("col_tile_kernel", EXTRAS=True, RULE=6) == 1 and d.count("col_tile_kernel", EXTRAS=True, RULE=0) == nog, d
         else:
             assert d.count("col_tile_kernel", RULE=3) + d.count("col_tile_kernel", RULE=4) == 0 and d.count("row_kernel", SPLIT=True) == 0, d
-            assert d.count("col_tile_kernel", N=n, NR=6, EXTRAS=True, RULE=0) == 3 + nog, d
+            assert d.count("col_tile_kernel", N=n, NR=6, EXTRAS=True, RULE=0) == 1 + nog and d.count("col_tile_kernel", N=n, EXTRAS=True, RULE=6) == 2, d
         assert d.count("col_fused_kernel") == 0, d
         first = (h.phase.copy(), np.array(h.weights, copy=True))
         h.optimize(method, maxiter=1, verbose=False, mraf_factor=0.5, **extra)
