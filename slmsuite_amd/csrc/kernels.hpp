@@ -42,6 +42,9 @@
 #ifndef HGS_ROW_PHASOR
 #define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
 #endif
+#ifndef HGS_ROW_PREF_BUFST
+#define HGS_ROW_PREF_BUFST 0   // 1: the prefetching row walk stores G through a buffer resource, straight-line (no mask test, no 64-bit address
+#endif                         //    per store): row launch 26.0 -> 28.1 us, headline 15.17 k -> 14.65 k it/s -- slower (round 6)
 #ifndef HGS_LIST_SLOAD
 #define HGS_LIST_SLOAD 1
 #endif
@@ -997,6 +1000,20 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 // slot m + 1 -- eight store instructions instead of sixteen, the same bytes at the same addresses.
                 // (measured: a batch of eight, one-row workgroups: row launch 89.8 -> 86.9 us; the prefetching walk of a single
                 //  hologram LOSES 1.2 us to the swaps on its chain and keeps the 8-byte stores; 8192-wide rows: level)
+                if constexpr (PREF && HGS_ROW_PREF_BUFST) {
+                    // the prefetching walk (dense launches only: no store mask): sixteen straight-line stores through a buffer
+                    // resource -- the lane part of the address one VGPR offset, the register part an SGPR offset.  As plain stores
+                    // each sat in its own exec-masked block (the mask test) with a 64-bit address computed in front of it
+                    // (launch_row_f32.s: s_and_saveexec / s_cbranch / s_mul / s_add / v_lshl_add_u64 per store)
+                    const Buf bg(gh, (unsigned)((size_t)g.Sh * g.Pw * sizeof(Cx<R>)));
+                    const unsigned vo = (gh_lane + (unsigned)rr * 4u) * (unsigned)sizeof(Cx<R>);
+                    static_for<0, 16>([&](auto m_) {
+                        constexpr int m = m_;
+                        Cx<R> e;
+                        if constexpr (NS < 16) e = cmul(v[m], omsc); else e = v[m] * sc;
+                        bg.template st<Cx<R>>(e, vo, (unsigned)m * gh_step * (unsigned)sizeof(Cx<R>));
+                    });
+                } else
                 if constexpr (sizeof(R) == 4 && HGS_ROW_ST16 && T % 64 == 0 && !PREF) {
                     if (a.store_mask == nullptr) {
                         const bool odd = (j & 1) != 0;
