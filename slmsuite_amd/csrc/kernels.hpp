@@ -42,6 +42,9 @@
 #ifndef HGS_ROW_PHASOR
 #define HGS_ROW_PHASOR 1     // MODE 2 row kernel: nf/|nf| instead of atan2 + sincos
 #endif
+#ifndef HGS_ROW_PREF_NOMASK
+#define HGS_ROW_PREF_NOMASK 0  // 1: ... or keeps its flat stores but drops the mask test (one block of sixteen stores): 26.0 -> 27.9 us -- slower too:
+#endif                         //    the per-store blocks keep the stores spread between the last butterflies instead of bunched behind them
 #ifndef HGS_ROW_PREF_BUFST
 #define HGS_ROW_PREF_BUFST 0   // 1: the prefetching row walk stores G through a buffer resource, straight-line (no mask test, no 64-bit address
 #endif                         //    per store): row launch 26.0 -> 28.1 us, headline 15.17 k -> 14.65 k it/s -- slower (round 6)
@@ -1042,7 +1045,8 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 } else
                 static_for<0, 16>([&](auto m_) {
                     constexpr int m = m_;
-                    if ((smask >> m) & 1u) {
+                    // (the prefetching walk is launched dense-only: no mask test, so that its sixteen stores are one block)
+                    if ((PREF && HGS_ROW_PREF_NOMASK) || ((smask >> m) & 1u)) {
                         if constexpr (NS < 16) (ghr + (size_t)m * gh_step)[gh_lane] = cmul(v[m], omsc);
                         else (ghr + (size_t)m * gh_step)[gh_lane] = v[m] * sc;
                     }
