@@ -50,6 +50,15 @@ for l in sys.stdin:
       for v in 0 1; do HGS_MRAF_PRESUM=$v timeout 300 python bench.py --cpu-iters 0 --pmc 0 --workload cfg5mraf --steps 40 --warmup 5 2>/dev/null | grep '^{' >> gpurun_out/r6_ab_mraf_presum.jsonl
                        HGS_MRAF_PRESUM=$v timeout 300 python bench.py --cpu-iters 0 --pmc 0 --workload cfg5mraf --dtype f64 --steps 20 --warmup 3 2>/dev/null | grep '^{' >> gpurun_out/r6_ab_mraf_presum.jsonl; done
       ls gpurun_out | head -80 ;;
+    final2)   # the lines that later kernel changes of the round touched, re-taken on the final tree
+      timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6_bench_cfg2_driver_protocol.json 2> gpurun_out/r6_bench_driver.err
+      timeout 600 python bench.py > gpurun_out/r6_bench_cfg2_n1.json 2> gpurun_out/r6_bench_n1.err
+      bash tools/gpu_r4.sh configs
+      prof() { n=$1; shift; bash tools/profile.sh r06_$n "$@" > gpurun_out/prof_$n.log 2>&1; }
+      prof cfg5mraf --workload cfg5mraf; prof cfg5mraf_gs --workload cfg5mraf --method GS; prof cfg5mraf_f64 --workload cfg5mraf --dtype f64; prof cfg2kim --method WGS-Kim
+      prof cfg2 ; prof refbench --workload refbench
+      python tools/e2e_timing.py gpurun_out/r6_e2e.json > /dev/null 2> gpurun_out/r6_e2e.err
+      ls gpurun_out | wc -l ;;
     t) shift; timeout ${TMO:-1200} python -m pytest "$@" -m gpu -q -x -p no:cacheprovider 2>&1 | tail -${TAIL:-25} ;;
     *) bash tools/gpu_r5.sh "$@" ;;
   esac
