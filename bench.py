@@ -787,6 +787,15 @@ def main():
             roof["noise_inverse_launch" if ok_ == "col_inv" else "presum_launch"] = {
                 "kernel": bm.get("other_name"), "launch_us": inv_dur * 1e6, "bytes_per_launch": bm["other"],
                 "frac": bm["other"] / inv_dur / HBM_PEAK}
+        if (roof is not None and roof.get("presum_launch") and roof.get("traffic") is not None
+                and str(bm.get("other_name", "")).startswith("col_fused_kernel")):
+            # the pre-pass IS the column kernel (same instance, forward only): the PMC pass knows kernels by name, so its mean per
+            # dispatch runs over both launches of an iteration -- held against the mean of the two models
+            mean_model = (bm["col"] + bm["other"]) / 2
+            roof["traffic_over_model"] = roof["traffic"] / mean_model
+            roof["frac_on_traffic"] = None
+            roof["traffic_note"] += ("; the forward-only pre-pass is a launch of the same kernel: `traffic` is the mean over both "
+                                     f"launches of an iteration, `traffic_over_model` holds it against (col + pre-pass) / 2 = {int(mean_model)} B")
         if roof is not None and roof.get("traffic_over_model") is not None and abs(roof["traffic_over_model"] - 1) > 0.05:
             roof["traffic_explanation"] = traffic_explanation(args, prob, roof)
         cpu = cpu_baseline(args) if world == 1 else None

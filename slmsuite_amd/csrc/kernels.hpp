@@ -65,6 +65,12 @@
 // Round-5 experiments on the 8192-row column kernels, all measured and NOT adopted (NOTEBOOK.md; A/B builds through
 // tools/microbench/build_trace8k.sh): the s_memtime trace of a build that drains vmcnt at every phase boundary suggested
 // memory waits that the product build does not have.
+#ifndef HGS_ROW_AMP_LATE
+#define HGS_ROW_AMP_LATE 0      // row_kernel PREF: 1 = the amplitude requests behind the pick-up of the staged row (measured, below)
+#endif
+#ifndef HGS_TILE_TOUCH
+#define HGS_TILE_TOUCH 1        // col_tile_kernel, 8192 rows: the wait for a column's weights / targets sits at the END of the previous column
+#endif                          // (an empty asm that names their registers), not at its head -- see the kernel
 #ifndef HGS_TILE_STAGE_WAIT
 #define HGS_TILE_STAGE_WAIT 1   // 0: no vmcnt(0) ahead of reading the staged tile (the loads have landed by then): 213.9 vs 214.5 us, noise
 #endif
@@ -840,10 +846,14 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
         // 65.5 us per iteration with the scalar one (tools/amp_array_probe.py, round 6).
         constexpr bool AMPF = HGS_ROW_AMP_PREFETCH && MODE >= 2 && T % 64 == 0 && !(N >= 8192 && NS == 16);
         R amr[AMPF ? NS : 1];
-        if constexpr (AMPF) {
+        auto issue_amp = [&]() {
             const Buf bam(am, (am != nullptr && valid) ? (unsigned)g.Sw * (unsigned)sizeof(R) : 0u);
             static_for<0, NS>([&](auto m_) { constexpr int m = m_; amr[m] = bam.template ld<R>((unsigned)(c_lane + m * T) * (unsigned)sizeof(R), 0u); });
-        }
+        };
+        // (PREF: behind the pick-up of the staged row -- ahead of it, the `s_waitcnt vmcnt(0)` that waits for the staged pieces
+        //  waited for these requests as well, a round trip at the head of every row)
+        constexpr bool AMP_LATE = AMPF && PREF && MODE != 0 && HGS_ROW_AMP_LATE;
+        if constexpr (AMPF && !AMP_LATE) issue_amp();
         if constexpr (MODE != 0) {
             // ---- load H row, centred inverse transform along x ----
             if constexpr (PREF) {
@@ -862,6 +872,7 @@ __global__ __launch_bounds__(RowCfg<N>::WG, (sizeof(R) == 8 ? 2 : (((MODE == 1 |
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 HGS_T(fft.tr_n, 32);
                 if (rbase + row_stride < g.Sh) prefetch_row(rbase + row_stride);
+                if constexpr (AMP_LATE) issue_amp();
                 HGS_T(fft.tr_n, 33);
             } else {
             // dense fp32 launches: the H row in 16-byte pieces, the lane pair swapping one value per slot pair (see the G stores)
@@ -1772,6 +1783,16 @@ __device__ __forceinline__ void issue_wt_loads(const R* __restrict__ wc, const R
     });
 }
 
+// an empty asm statement that names the registers: whatever request fills them is waited for HERE (col_tile_kernel TOUCH)
+template <typename R, bool BOTH>
+__device__ __forceinline__ void touch_regs16(R (&x)[16], R (&y)[16]) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        asm volatile("" : "+v"(x[m]));
+        if constexpr (BOTH) asm volatile("" : "+v"(y[m]));
+    }
+}
+
 // EXTRAS = false compiles the MRAF / Nogrette / forward-only branches out (2.7 us of the 58 us dense launch)
 // dynamic LDS of col_tile_kernel: transform image + reduction scratch
 // (8192 points: one workgroup per CU, so nobody covers the 5.8 k cycles a tile's rows take to arrive; the NEXT tile of
@@ -1901,10 +1922,27 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
         }
     };
+    // TOUCH (8192 rows): where the compiler waits for a column's weights and targets.  Left alone it waits at the HEAD of the column
+    // (the sparse-skip tests are hoisted there, and the loop header joins paths with different numbers of younger requests, so the
+    // wait is vmcnt(0)) -- which, at the first column of a tile, also waits for the staging requests of the NEXT tile issued a few
+    // instructions earlier and for the tile stores before them: a full memory round trip per tile that the staging was there to
+    // hide (s_memtime: "tile start -> tile landed" 3.9 k + 1.4 k cycles of a tile's 58 k).  An empty asm statement that names the
+    // registers at the END of a column puts the wait there, an inverse transform after the requests, and leaves the head without one.
+    // (measured, one GPU call, two runs each, with and without: plain rule instance at cfg5pad 201.9 -> 198.2 us; the MRAF form without
+    //  an update 201.6 -> 201.2; the MRAF form WITH the update 212.9 -> 214.7 -- left as it was.  Builds that differ in nothing but the
+    //  form of an unrelated loop move these kernels by +- 1.5 %, so only the first figure says much.  The rows of a workgroup's first
+    //  tile as straight-line buffer loads on top of it: +6 VGPRs and 2 % slower everywhere, not kept.)
+    constexpr bool TOUCH = HGS_TILE_TOUCH && TPREF && !SPLIT && RULE != 5;
+    constexpr bool TR_DEAD = RULE == 2 && !STATS && !EXTRAS;      // (the target is never read: its registers are constants)
+    auto touch_wt = [&]() { touch_regs16<R, !TR_DEAD>(wr, tr); };
 #pragma unroll 1
     for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
         HGS_T(fft.tr_n, 1);
         const int ct = tile_of(it);
+        if constexpr (TOUCH) {       // the first tile's weights / targets ahead of its rows (one round trip for both)
+            if (it == (int)blockIdx.x)
+                issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
+        }
         // this workgroup's next tile, `more` = there is one (LISTED 0 keeps the plain arithmetic of the dense schedule: the
         // hot launches are sensitive to the form of these scalar expressions, 0.6 us of 51.5)
         int ct_nl = -1;
@@ -1923,10 +1961,16 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             // this wave's own pieces (no other wave reads them).  (They were issued a whole tile ago and every column since has
             // waited for weights / targets requested after them, so the wait is formally redundant -- and it also waits for
             // the tile stores issued just before; without it the launch measured the same, HGS_TILE_STAGE_WAIT.)
-            if (HGS_TILE_STAGE_WAIT && staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (TOUCH: the wait at the end of the previous column covered them -- they are older than that column's weight requests)
+            if (HGS_TILE_STAGE_WAIT && !TOUCH && staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int m = 0; m < NR; ++m) {
+        auto put_row = [&](auto m_, const float4& lo, const float4& hi) {
+            constexpr int m = m_;
+            gtx[m][0] = lo.x; gty[m][0] = lo.y; gtx[m][1] = lo.z; gty[m][1] = lo.w;
+            gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
+        };
+        static_for<0, NR>([&](auto m_) {
+            constexpr int m = m_;
             const int r = r_lane + m * T;
             float4 lo = make_float4(0, 0, 0, 0), hi = lo;
             if (TPREF && staged) {
@@ -1944,9 +1988,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
                 lo = q[0];
                 hi = q[1];
             }
-            gtx[m][0] = lo.x; gty[m][0] = lo.y; gtx[m][1] = lo.z; gty[m][1] = lo.w;
-            gtx[m][2] = hi.x; gty[m][2] = hi.y; gtx[m][3] = hi.z; gty[m][3] = hi.w;
-        }
+            put_row(m_, lo, hi);
+        });
         if constexpr (TPREF) {
             if (tpref && more(next_ct())) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the image has been read into registers
@@ -1969,6 +2012,9 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
         }
         int tile_noise = 0;          // SPLIT: any column of this tile with a noise pixel (wave-uniform)
+        if constexpr (TOUCH) {
+            if (it == (int)blockIdx.x) touch_wt();
+        } else
         if (it == (int)blockIdx.x)   // later tiles were prefetched at the end of the previous one
             issue_wt_loads<R, T>(wbase + (size_t)(ct * 4) * g.Ph, tbase + (size_t)(ct * 4) * g.Ph, upd, j, wr, tr);
 #if HGS_TRACE
@@ -2129,9 +2175,13 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
 
             HGS_T(fft.tr_n, 5);
-            if (EXTRAS && !FIXED && cp.weights_only) continue;
+            if (EXTRAS && !FIXED && cp.weights_only) {
+                if constexpr (TOUCH) touch_wt();
+                continue;
+            }
             if (has_sig) fft.template inv_after_fwd_trail<NR>(v, lds, j);      // slots NR.. (rows outside the SLM) are not stored
             else static_for<0, NR>([&](auto m_) { constexpr int m = m_; v[m] = mk<R>(0, 0); });
+            if constexpr (TOUCH) touch_wt();
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
                 const Cx<R> h = v[m] * (sgs * a.scale);

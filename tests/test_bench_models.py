@@ -75,6 +75,24 @@ def test_models_reproduce_round_5_lines_and_traffic(line):
         assert abs(roof["traffic"] / m["col"] - 1) < band, roof["traffic"] / m["col"]
 
 
+@pytest.mark.parametrize("line", _lines("r06"), ids=[f"r06-{l[0]}-{l[1]}-{l[2]}-b{l[3]}s{l[4]}" for l in _lines("r06")])
+def test_models_reproduce_round_6_lines_and_traffic(line):
+    """Round 6 (profiles/r06/configs.jsonl): cfg 5 with a weight update runs the single-inverse pass now (the column launch
+    moves no second array; the pre-pass is reported beside it), every other line the kernels of round 5 with other loads."""
+    key, method, dtype, batch, streams, roof = line
+    m = _model(key, method, dtype, batch, streams, presum0=False)
+    assert m["col"] == roof["bytes_per_launch"], (m["col"], roof["bytes_per_launch"])
+    assert m["row"] == roof["row_kernel"]["bytes_per_launch"]
+    pre = roof.get("presum_launch")
+    if pre:
+        assert pre["bytes_per_launch"] == m["other"], (pre["bytes_per_launch"], m["other"])
+    if roof.get("traffic"):
+        band = 0.10 if dtype == "f64" or key in ("cfg1", "cfg3") else 0.05
+        # (float64: the pre-pass is a launch of the same kernel instance, and the counters' mean per dispatch runs over both)
+        model = (m["col"] + m["other"]) / 2 if pre and m["other_name"].startswith("col_fused_kernel") else m["col"]
+        assert abs(roof["traffic"] / model - 1) < band, roof["traffic"] / model
+
+
 def test_canonical_counts_are_surveys():
     P, S = 4096 * 4096, 1152 * 1920
     assert canonical_bytes(P, S, 4, True) == 1_024_327_680              # SURVEY 8(d), cfg 2 / 3 (WGS, f32)
