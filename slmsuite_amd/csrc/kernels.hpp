@@ -1862,7 +1862,8 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
     const bool listed = LISTED < 0 ? a.col_list != nullptr : LISTED != 0;
     const int* clist = listed ? a.col_list + (size_t)b * g.Pw : nullptr;
     const int ntiles = listed ? (a.n_active[b] >> 2) : g.Pw / 4;
-    auto tile_of = [&](int it) -> int { return listed ? (clist[4 * it] >> 2) : it; };
+    // (list entries through the scalar cache: as plain loads they were vector loads with a drain behind each, two per tile)
+    auto tile_of = [&](int it) -> int { return listed ? (uniform_load_i32(clist + 4 * it) >> 2) : it; };
     R acc_w = 0;
 
     Cx<R> v[16];
@@ -2012,6 +2013,12 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             }
         }
         int tile_noise = 0;          // SPLIT: any column of this tile with a noise pixel (wave-uniform)
+        // PRESUM / NOUPD over a column list: the scan bytes of the tile's four columns, one aligned word through the scalar cache,
+        // once per tile (as a plain load inside the column loop it was a vector load with a drain behind it at the head of every column)
+        int cflags4 = -1;
+        if constexpr (PRESUM || NOUPD) {
+            if (a.col_flags != nullptr) cflags4 = uniform_load_i32(reinterpret_cast<const int*>(a.col_flags + (size_t)b * g.Pw) + ct);
+        }
         if constexpr (TOUCH) {
             if (it == (int)blockIdx.x) touch_wt();
         } else
@@ -2053,8 +2060,7 @@ __global__ __launch_bounds__(N / 16, HGS_FUSED_OCC) void col_tile_kernel(ColArgs
             //  instruction with a full round trip and a vmcnt(0) drain behind it)
             int cflags = -1;
             if constexpr (PRESUM || NOUPD) {
-                if (a.col_flags != nullptr)
-                    cflags = (int)((__builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(a.col_flags + (size_t)b * g.Pw)[ct]) >> (8 * c)) & 0xffu);
+                if (a.col_flags != nullptr) cflags = (int)(((unsigned)cflags4 >> (8 * c)) & 0xffu);
             } else if constexpr (FIXED) {      // (RULE 4, the split form over a list: runs once per new set of weights since round 6; left as it was)
                 if (a.col_flags != nullptr) cflags = a.col_flags[(size_t)b * g.Pw + ct * 4 + c];
             }
