@@ -59,6 +59,13 @@ for l in sys.stdin:
       prof cfg2 ; prof refbench --workload refbench
       python tools/e2e_timing.py gpurun_out/r6_e2e.json > /dev/null 2> gpurun_out/r6_e2e.err
       ls gpurun_out | wc -l ;;
+    final3)   # ... and once more after the 8192-row tile kernel's waits moved (cfg 5 / cfg5pad lines and profiles, every bench line)
+      bash tools/gpu_r4.sh configs
+      prof() { n=$1; shift; bash tools/profile.sh r06_$n "$@" > gpurun_out/prof_$n.log 2>&1; }
+      prof cfg5pad --workload cfg5pad; prof cfg5mraf --workload cfg5mraf; prof cfg5mraf_gs --workload cfg5mraf --method GS
+      for m in WGS-Leonardo GS; do timeout 300 python bench.py --workload cfg5mraf --method $m --sparse-columns 1 --steps 60 --warmup 8 --cpu-iters 0 --pmc 0 2>/dev/null; done > gpurun_out/r6_cfg5_engine_default.jsonl
+      timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6_bench_cfg2_driver_protocol.json 2> gpurun_out/r6_bench_driver.err
+      ls gpurun_out | wc -l ;;
     t) shift; timeout ${TMO:-1200} python -m pytest "$@" -m gpu -q -x -p no:cacheprovider 2>&1 | tail -${TAIL:-25} ;;
     *) bash tools/gpu_r5.sh "$@" ;;
   esac
