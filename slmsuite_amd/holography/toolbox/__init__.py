@@ -75,27 +75,49 @@ def format_2vectors(vectors):
     return v
 
 
+def _pair_distance(diff, metric):
+    if metric == "chebyshev":
+        return np.max(diff, axis=0)
+    if metric == "euclidean":
+        return np.sqrt(np.sum(diff * diff, axis=0))
+    if metric == "cityblock":
+        return np.sum(diff, axis=0)
+    raise ValueError(f"smallest_distance: unknown metric {metric!r}")
+
+
 def smallest_distance(vectors, metric="chebyshev"):
-    """Minimum pairwise distance (inf for < 2 points).  toolbox/__init__.py:1127-1250."""
+    """
+    Minimum pairwise distance (inf for < 2 points).  toolbox/__init__.py:1127-1250.
+
+    A sweep over the points sorted by x: point i against point i + k for k = 1, 2, ... until no pair that far apart in the
+    order is closer in x than the best distance found (all three metrics are >= |dx|).  Exact, a few vectorised passes for
+    the usual spot arrays -- and no ``scipy.spatial`` import, which was 180 ms of a process' first ``SpotHologram``
+    (tools/first_use_probe.py).  Point sets on which the sweep would degenerate (thousands of points sharing one x) go to
+    the KD-tree.
+    """
     v = format_2vectors(vectors)
     n = v.shape[1]
     if n < 2:
         return np.inf
-    if n > 400:
-        from scipy.spatial import cKDTree
-        p = {"chebyshev": np.inf, "euclidean": 2, "cityblock": 1}[metric]
-        d, _ = cKDTree(v.T).query(v.T, k=2, p=p)
-        return float(np.min(d[:, 1]))
+    _pair_distance(np.zeros((2, 1)), metric)                 # (unknown metric: fail before any work)
+    # (the axis along which fewer points coincide leads the order)
+    lead = 0 if np.unique(v[0]).size >= np.unique(v[1]).size else 1
+    order = np.lexsort((v[1 - lead], v[lead]))
+    x, y = v[lead, order], v[1 - lead, order]
     best = np.inf
-    for i in range(n - 1):
-        diff = np.abs(v[:, i + 1:] - v[:, i:i + 1])
-        if metric == "chebyshev":
-            d = np.max(diff, axis=0)
-        elif metric == "euclidean":
-            d = np.sqrt(np.sum(diff * diff, axis=0))
-        else:
-            d = np.sum(diff, axis=0)
-        best = min(best, float(np.min(d)))
+    for k in range(1, n):
+        dx = x[k:] - x[:-k]                                  # >= 0: sorted
+        if k > 4096:
+            from scipy.spatial import cKDTree
+            p = {"chebyshev": np.inf, "euclidean": 2, "cityblock": 1}[metric]
+            d, _ = cKDTree(v.T).query(v.T, k=2, p=p)
+            return float(np.min(d[:, 1]))
+        if float(np.min(dx)) >= best:
+            break
+        near = dx < best
+        d = _pair_distance(np.stack((dx[near], np.abs(y[k:] - y[:-k])[near])), metric)
+        if d.size:
+            best = min(best, float(np.min(d)))
     return best
 
 

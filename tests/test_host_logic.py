@@ -554,3 +554,32 @@ def test_update_flags_precedence_and_verbose_print(capsys):
     out = capsys.readouterr().out
     assert "Optimizing with 'WGS-Kim' using the following method-specific flags:" in out
     assert "'fix_phase_iteration': 7" in out and "'method'" not in out and "'some_flag'" not in out
+
+
+def test_smallest_distance_is_exact_without_scipy_spatial():
+    """toolbox.smallest_distance (toolbox/__init__.py:1127-1250 in the reference): the sorted sweep against all pairs, for
+    the three metrics, on random points, integer points with coincidences, grids and points on one line -- and without
+    importing scipy.spatial (180 ms of a process' first SpotHologram)."""
+    import subprocess
+    from slmsuite_amd.holography.toolbox import smallest_distance
+    rng = np.random.default_rng(5)
+
+    def brute(v, metric):
+        d = np.abs(v[:, :, None] - v[:, None, :])
+        m = {"chebyshev": d.max(axis=0), "euclidean": np.sqrt((d * d).sum(axis=0)), "cityblock": d.sum(axis=0)}[metric]
+        m[np.arange(v.shape[1]), np.arange(v.shape[1])] = np.inf
+        return float(m.min())
+
+    grid = np.stack(np.meshgrid(np.arange(20) * 64.0, np.arange(20) * 48.0)).reshape(2, -1)
+    cases = [rng.random((2, 2)), rng.random((2, 3)) * 10, rng.random((2, 700)) * 1000, rng.integers(0, 40, (2, 500)).astype(float),
+             grid, np.stack((np.zeros(300), rng.random(300) * 50)), np.stack((rng.random(300) * 50, np.ones(300)))]
+    for v in cases:
+        for metric in ("chebyshev", "euclidean", "cityblock"):
+            assert abs(smallest_distance(v, metric) - brute(v, metric)) <= 1e-12 * max(1.0, brute(v, metric))
+    assert smallest_distance(np.zeros((2, 1))) == np.inf
+    with pytest.raises(ValueError):
+        smallest_distance(grid, "minkowski")
+    code = ("import sys, numpy as np; from slmsuite_amd.holography.toolbox import smallest_distance; "
+            "smallest_distance(np.stack(np.meshgrid(np.arange(32.), np.arange(32.))).reshape(2, -1)); "
+            "sys.exit(1 if 'scipy.spatial' in sys.modules else 0)")
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT).returncode == 0
