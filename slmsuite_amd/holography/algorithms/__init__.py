@@ -956,6 +956,17 @@ class Hologram:
             raise NotImplementedError(f"Feedback '{fb}' needs camera hardware and is outside this build")
         if fb in ("computational_spot", "external_spot") and self._n_spots() == 0 and "WGS" in self.flags["method"]:
             raise ValueError(f"Feedback '{fb}' is specific to SpotHologram")
+        # Reference quirk A12: with NaN in the target, a phase that is still flagged as fixed and no stored
+        # phase_ff -- reset(reset_flags=False) after a WGS-Kim run -- the MRAF branch evaluates exp(1j * None)
+        # (_hologram.py:1643: no "or self.phase_ff is None" as at :1601) and raises TypeError in the first iteration, unless
+        # that iteration is a WGS one past iteration 0 (Kim stores the phase first, :1582; the other rules clear the flag,
+        # :1585).  Same condition, a clear message, nothing touched yet.
+        fl = self.flags
+        if (fl.get("fixed_phase", False) and "phase_ff" not in self._stale and self._host.get("phase_ff") is None
+                and not ("WGS" in fl["method"] and self.iter > 0) and self._mraf_enabled()):
+            raise RuntimeError("fixed_phase is set but there is no stored phase_ff, and the target holds NaN (MRAF): the reference "
+                               "fails here with a TypeError (_hologram.py:1643).  Clear the flag (reset(reset_flags=True) or "
+                               "flags['fixed_phase'] = False) or run an iteration that stores the phase first.")
 
     def _kim_efficiency_gate(self):
         """fix_phase_efficiency branch of _gs_farfield_routines (:1560-1569), evaluated on the host."""

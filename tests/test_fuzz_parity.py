@@ -286,6 +286,25 @@ def _sparse_blocks(seed, shape, dt):
     return np.where(keep, t, 0).astype(dt)
 
 
+def _both_raise_a12(run_engine, run_oracle, trail, log, k):
+    """Reference quirk A12: a phase still flagged as fixed, no stored phase_ff (a reset() that kept the flags) and NaN in the
+    target -- the reference raises TypeError in the first iteration (_hologram.py:1643), the class a RuntimeError that says
+    why.  Both or neither; True = both raised (the walk ends there: the reference object is half-way through an iteration)."""
+    raised = []
+    for run_one, exc_type in ((run_engine, RuntimeError), (run_oracle, TypeError)):
+        try:
+            run_one()
+            raised.append(False)
+        except exc_type:
+            raised.append(True)
+    assert raised[0] == raised[1], (trail, raised)
+    if raised[0]:
+        trail[-1] += " -> both raise (quirk A12)"
+        if log is not None:
+            log(f"{k:2d} {trail[-1]}")
+    return raised[0]
+
+
 def walk(seed, tol=1e-7, log=None, dt=np.float64, big=False, steps=12):
     """The random walk of test_random_operation_sequence_* (``log``: a callable that gets one line per step)."""
     rng = np.random.default_rng(seed)
@@ -307,7 +326,7 @@ def walk(seed, tol=1e-7, log=None, dt=np.float64, big=False, steps=12):
                 target[: H // 5, :] = np.nan       # (MRAF only acts when a run passes mraf_factor)
             h = Hologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=dt)
             o = orc.OracleHologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=dt)
-        trail = []
+        trail, errs = [], {}
         for k, op in enumerate(_ops(rng, steps, spots)):
             trail.append(op)
             if op == "optimize":
@@ -319,9 +338,10 @@ def walk(seed, tol=1e-7, log=None, dt=np.float64, big=False, steps=12):
                     kw["mraf_factor"] = float(rng.choice([0.5, 1.0]))
                 n = int(rng.integers(1, 4))
                 groups = ["computational"] if rng.random() < 0.3 else []
-                h.optimize(m, maxiter=n, verbose=False, stat_groups=groups, **kw)
-                o.optimize(m, maxiter=n, stat_groups=groups, **kw)
                 trail[-1] = f"optimize({m}, {n}, {kw}, {groups})"
+                if _both_raise_a12(lambda: h.optimize(m, maxiter=n, verbose=False, stat_groups=groups, **kw),
+                                   lambda: o.optimize(m, maxiter=n, stat_groups=groups, **kw), trail, log, k):
+                    break
             elif op == "optimize_callback":        # a callback takes the loop to the host: one engine call per operator
                 m, kw = METHODS[int(rng.integers(len(METHODS)))]
                 kw = dict(kw)
@@ -329,10 +349,11 @@ def walk(seed, tol=1e-7, log=None, dt=np.float64, big=False, steps=12):
                     kw["fix_phase_iteration"] = int(o.iter + rng.integers(0, 3))
                 n = int(rng.integers(1, 4))
                 seen = []
-                h.optimize(m, maxiter=n, verbose=False, callback=lambda hh: seen.append(hh.iter) and False, **kw)
-                o.optimize(m, maxiter=n, **kw)
-                assert len(seen) == n, (trail, seen)
                 trail[-1] = f"optimize_callback({m}, {n}, {kw})"
+                if _both_raise_a12(lambda: h.optimize(m, maxiter=n, verbose=False, callback=lambda hh: seen.append(hh.iter) and False, **kw),
+                                   lambda: o.optimize(m, maxiter=n, **kw), trail, log, k):
+                    break
+                assert len(seen) == n, (trail, seen)
                 op = "optimize"
             elif op == "tensor_phase":             # a phase that lives on the GPU (torch tensor): device -> engine, no host copy
                 import torch

@@ -293,3 +293,42 @@ def test_mraf_single_inverse_on_the_per_column_kernel(dt, shape, slm, method, ex
     else:
         # float32: two update bodies apart on a dense image (rounding amplified 50 - 500 x per body, see the split-form tests)
         assert ep < 5e-3 and ew < 5e-3, errs
+
+
+def test_fixed_phase_without_a_stored_phase_on_an_mraf_target_raises_like_the_reference():
+    """
+    Reference quirk A12 (SURVEY appendix): a WGS-Kim run fixes the phase, ``reset()`` keeps the flags and forgets ``phase_ff``;
+    with NaN in the target the next run's first iteration evaluates ``exp(1j * None)`` (_hologram.py:1643 has no
+    ``or self.phase_ff is None`` as :1601 has) -- TypeError in the reference and in the oracle, a RuntimeError that says why
+    in the class, before anything is touched.  Without NaN in the target the same state is guarded in both (:1601) and runs.
+    """
+    from oracle import hgs_oracle as orc
+    shape, slm = (64, 128), (40, 100)
+    for mraf in (True, False):
+        target = synth.random_target(3, shape, 0.2, 1.0, dtype=np.float64)
+        if mraf:
+            target[:12, :] = np.nan
+        phase = synth.seed_phase(3, slm, dtype=np.float64)
+        h = Hologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=np.float64)
+        o = orc.OracleHologram(target.copy(), phase=phase.copy(), slm_shape=slm, dtype=np.float64)
+        for x in (h, o):
+            kw = {} if x is o else {"verbose": False}
+            x.optimize("WGS-Kim", maxiter=3, fix_phase_iteration=1, **kw)
+        assert h.flags["fixed_phase"] and o.flags["fixed_phase"]
+        h.reset(reset_phase=False, reset_flags=False)
+        o.reset()
+        assert h.phase_ff is None and o.phase_ff is None and h.flags["fixed_phase"] and o.flags["fixed_phase"]
+        if mraf:
+            with pytest.raises(TypeError):                         # (iteration 0 of a call: no weight update, so no rule clears the flag)
+                o.optimize("WGS-Leonardo", maxiter=2)
+            for method in ("GS", "WGS-Leonardo", "WGS-Kim"):
+                with pytest.raises(RuntimeError, match="phase_ff"):
+                    h.optimize(method, maxiter=2, verbose=False)
+                assert h.iter == 0 and h.phase_ff is None
+            h.flags["fixed_phase"] = False                         # what the message says: the run goes through
+            h.optimize("GS", maxiter=2, verbose=False)
+        else:
+            h.optimize("GS", maxiter=2, verbose=False)
+            o.optimize("GS", maxiter=2)
+            assert phase_rel_l2(h.phase, o.phase) < 1e-9
+        h._release_engine()
