@@ -73,7 +73,11 @@ typedef struct {
     int32_t method;              /* HGS_GS ...                                           */
     int32_t feedback;            /* HGS_FB_*                                             */
     int32_t iter;                /* in/out  self.iter (:1490)                            */
-    int32_t fixed_phase;         /* in/out  flags["fixed_phase"] (:1556-1585)            */
+    int32_t fixed_phase;         /* in/out  flags["fixed_phase"] (:1556-1585).  Set while the engine holds
+                                    no phase_ff (after hgs_reset), an iteration stores the phase first --
+                                    the guard of :1601.  The reference's MRAF branch (:1643) lacks that
+                                    guard and raises there; a host that wants the
+                                    reference's behaviour refuses the call, as the Python class does    */
     int32_t fix_phase_iteration; /* flags["fix_phase_iteration"]                         */
     int32_t false_run;           /* in/out  trailing count of contiguous False entries in
                                     stats["flags"]["fixed_phase"] (:1574-1577); -1 = history

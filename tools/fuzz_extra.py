@@ -1,6 +1,6 @@
 """
 More seeds of tests/test_fuzz_parity.py than the suite's time budget holds (other seed ranges, same bounds):
-    python tools/fuzz_extra.py [large_from large_to] ...   ->  one line per case, FAILED lines for anything over its bound.
+    python tools/fuzz_extra.py [+SHIFT] [large fp32 fp64 walk walk32 compressed batch]   ->  one line per case, FAILED lines for anything over its bound.
 Test infrastructure (it runs the oracle through the test module), like tools/fuzz_walk.py.
 """
 import os
@@ -19,7 +19,12 @@ RANGES = {"large": (7100, 7130), "fp32": (6100, 6200), "fp64": (5100, 5200), "wa
 FUNCS = {"large": f.test_random_large_case_fp32, "fp32": f.test_random_case_fp32, "fp64": f.test_random_case_fp64,
          "walk": f.test_random_operation_sequence_fp64, "walk32": f.test_random_operation_sequence_fp32_large,
          "compressed": f.test_random_compressed_case_fp64, "batch": f.test_random_batch_fp64}
-which = sys.argv[1:] or list(RANGES)
+argv = sys.argv[1:]
+shift = 0
+if argv and argv[0].startswith("+"):          # "+200": the same ranges, 200 seeds further on
+    shift = int(argv.pop(0))
+    RANGES = {k: (lo + shift, hi + shift) for k, (lo, hi) in RANGES.items()}
+which = argv or list(RANGES)
 bad = 0
 for name in which:
     lo, hi = RANGES[name]
