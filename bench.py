@@ -262,6 +262,12 @@ class GridProblem:
     def run(self, n):
         return self.hb.time_iterations(self.args.method, n, **self.flags)
 
+    def run_plain(self, n):
+        """The same K steps without the HIP-event pair around them (hgs_iterate instead of hgs_iterate_timed): what the
+        wall-clock regions run -- two event records, the wait on the second and the read-out cost a 20-step region 2 %
+        (tools/region_probe.py: 68.6 -> 67.2 us per step), and they are instrumentation, not steps."""
+        self.hb.optimize(self.args.method, maxiter=n, **self.flags)
+
     def run_profiled(self, n):
         """The K steps of the roofline pass: stream groups one after the other, so that a launch's HIP-event interval holds
         that launch only."""
@@ -315,14 +321,17 @@ class CompressedProblem:
         self.h.optimize(self.args.method, maxiter=max(1, n), verbose=False)
         self.engine = self.h._get_engine()
 
-    def run(self, n):
+    def run(self, n, events=True):
         e = self.h._get_engine()
         st = self.h._make_step()
-        ms = e.iterate_timed(st, n)
+        ms = e.iterate_timed(st, n) if events else e.iterate(st, n)
         self.h.iter = st.iter
         self.h.flags["fixed_phase"] = bool(st.fixed_phase)
         self.h._mark_device_fresh(["phase", "weights"])
         return ms
+
+    def run_plain(self, n):
+        self.run(n, events=False)
 
     def close(self):
         self.h._release_engine()
@@ -572,10 +581,13 @@ def main():
             if dist is not None and not alone:
                 dist.barrier(group=ctl)
         ws, evs, rws = [], [], []
+        # the wall-clock repetitions run the K steps and nothing else; the HIP-event figure of the same K steps (the roofline's
+        # time base) comes from a few repetitions of its own behind them
+        plain = getattr(pb, "run_plain", None)
         for _ in range(args.reps):
             sync_all()
             t0 = time.perf_counter()
-            ms_ev = pb.run(args.steps)
+            ms_ev = pb.run(args.steps) if plain is None else plain(args.steps)
             sync_all()
             mine = time.perf_counter() - t0
             if dist is not None and not alone:        # the slowest rank counts
@@ -587,6 +599,13 @@ def main():
                 mine = float(tmax.item())
             ws.append(mine)
             evs.append(ms_ev)
+        if plain is not None:
+            ev = []
+            for _ in range(max(3, min(10, args.reps // 4))):
+                sync_all()
+                ev.append(pb.run(args.steps))
+            sync_all()
+            evs = [sorted(ev)[len(ev) // 2]] * len(ws)
         mid_ = sorted(range(args.reps), key=lambda i: ws[i])[len(ws) // 2]
         return ws, evs, rws, mid_
 
@@ -814,7 +833,8 @@ def main():
             "repetitions": args.reps, "ms_per_step_min": min(walls) * 1e3 / args.steps,
             "ms_per_step_max": max(walls) * 1e3 / args.steps,
             "timing": f"median of {args.reps} repetitions of the {args.steps}-step region (barrier + synchronize on both sides, "
-                      "max over ranks); state resident in HBM",
+                      "max over ranks); state resident in HBM; the region holds the K steps only -- `event_ms_per_step` (HIP events "
+                      "around the same K steps) is taken in repetitions of its own, since round 6",
             "event_ms_per_step": ms_events / args.steps, "gather_ms": gather_ms,
             "engine": prob.engine.version(),
             "roofline": roof, "cpu_baseline": cpu,

@@ -1,0 +1,44 @@
+"""What the HIP-event pair of hgs_iterate_timed costs a short timed region: cfg 2, 20-step regions bracketed as bench.py brackets
+them (engine sync + torch.cuda.synchronize on both sides), with the events (time_iterations) and without (optimize)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from slmsuite_amd import _lib as L  # noqa: E402
+from slmsuite_amd import synth  # noqa: E402
+from slmsuite_amd.batch import HologramBatch  # noqa: E402
+from slmsuite_amd.holography.algorithms import SpotHologram  # noqa: E402
+
+shape, slm = (4096, 4096), (1152, 1920)
+host = SpotHologram.make_rectangular_array(shape, (32, 32), (64, 64), basis="knm", slm_shape=slm, phase=synth.seed_phase(2, slm))
+hb = HologramBatch(shape, slm, np.asarray(host.target)[None], np.asarray(host.phase)[None], dtype=np.float32)
+hb.set_option(L.OPT_SPARSE_COLUMNS, 0)
+hb.optimize("WGS-Leonardo", maxiter=30)
+hb.sync()
+
+
+def sync_all():
+    hb.sync()
+    torch.cuda.synchronize()
+
+
+out = {}
+for K in (20, 200):
+    for name, fn in (("events", lambda: hb.time_iterations("WGS-Leonardo", K)), ("plain", lambda: hb.optimize("WGS-Leonardo", maxiter=K))):
+        ws = []
+        for _ in range(60):
+            sync_all()
+            t0 = time.perf_counter()
+            fn()
+            sync_all()
+            ws.append(time.perf_counter() - t0)
+        ws.sort()
+        out[f"K{K}_{name}_us_per_step"] = ws[len(ws) // 2] * 1e6 / K
+        out[f"K{K}_{name}_it_s"] = K / ws[len(ws) // 2]
+print(json.dumps(out))
+hb.close()
