@@ -44,6 +44,9 @@ steps between barrier + synchronize on both sides, the slowest rank counting -- 
 repetition; the spread is reported (``ms_per_step_min`` / ``_max``; the first regions after a short warm-up run on clocks
 that are still settling, which is why there are forty of them), with more than one rank also the rate of every
 rank (``per_rank_its``) so that a straggler shows.
+The region holds the K steps and nothing else (``hgs_iterate``); ``event_ms_per_step`` -- HIP events around the same K steps,
+``hgs_iterate_timed`` -- comes from a few repetitions of its own behind the timed ones (an event pair with its wait and
+read-out is 26 - 32 us per call: 2 % of a 20-step region, tools/region_probe.py).
 
 For spot workloads (and the MRAF target, whose frame outside the noise box is empty) the headline is
 timed with the dense kernels forced (every farfield column transformed); the engine's default for
