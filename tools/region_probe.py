@@ -40,5 +40,16 @@ for K in (20, 200):
         ws.sort()
         out[f"K{K}_{name}_us_per_step"] = ws[len(ws) // 2] * 1e6 / K
         out[f"K{K}_{name}_it_s"] = K / ws[len(ws) // 2]
+# the bracket itself: engine sync + torch sync (bench.py) against torch sync alone (a device-wide wait covers the engine's stream)
+for name, sync in (("both_syncs", sync_all), ("torch_sync_only", torch.cuda.synchronize)):
+    ws = []
+    for _ in range(60):
+        sync()
+        t0 = time.perf_counter()
+        hb.optimize("WGS-Leonardo", maxiter=20)
+        sync()
+        ws.append(time.perf_counter() - t0)
+    ws.sort()
+    out[f"K20_plain_{name}_us_per_step"] = ws[len(ws) // 2] * 1e6 / 20
 print(json.dumps(out))
 hb.close()
